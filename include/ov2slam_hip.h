@@ -1,0 +1,123 @@
+/*
+ * ov2slam_hip.h -- C ABI of libov2hip.so: the MI355X (gfx950) implementation of OV2SLAM's per-frame
+ * front-end (CLAHE + optical-flow pyramid + forward-backward pyramidal KLT) and keyframe-rate local
+ * bundle adjustment.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * The reference (chngdickson/ov2slam) has no FFI of its own: the path sits behind C++ member functions
+ * with OpenCV/Eigen types.  Each entry point below names the reference call it replaces (file:line in
+ * /root/reference); INTEGRATION.md shows the C++ adapter a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every call takes an ov2_ctx (device + one HIP stream + scratch).  One ctx per calling thread:
+ *     the reference calls fbKltTracking concurrently from the front-end and the mapper threads
+ *     (src/visual_front_end.cpp:196 and src/map_manager.cpp:510), so contexts are independent.
+ *   - return value: OV2_OK (0) or a negative ov2_status; ov2_last_error(ctx) gives the message.
+ *     No exceptions, no exit(); failures of individual keypoints are reported per keypoint in
+ *     `status` exactly as the reference does (src/feature_tracker.cpp:79-131).
+ *   - `_dev` variants take DEVICE pointers, enqueue on the ctx stream and return without
+ *     synchronising; host-pointer variants copy in/out and synchronise before returning.
+ *   - pixels: float32 (x,y) pairs, same as cv::Point2f.
+ */
+#ifndef OV2SLAM_HIP_H
+#define OV2SLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int ov2_status;
+enum {
+    OV2_OK = 0,
+    OV2_ERR_INVALID = -1,   /* bad argument (null handle, size mismatch, unsupported window ...) */
+    OV2_ERR_HIP = -2,       /* a HIP runtime call failed */
+    OV2_ERR_NOMEM = -3,
+    OV2_ERR_NODEVICE = -4,  /* no gfx950 device visible: the product path never falls back to CPU */
+    OV2_ERR_UNSUPPORTED = -5
+};
+
+typedef struct ov2_ctx ov2_ctx;        /* device, stream, scratch, buffer pool */
+typedef struct ov2_images ov2_images;  /* batch of B same-size u8 images resident in HBM */
+typedef struct ov2_pyr ov2_pyr;        /* ref-counted device pyramid(s): B x levels x {u8 image, s16x2 gradient} */
+
+/* ---- context --------------------------------------------------------------------------------- */
+ov2_status ov2_ctx_create(int device, ov2_ctx **out);
+void ov2_ctx_destroy(ov2_ctx *ctx);
+const char *ov2_last_error(const ov2_ctx *ctx);
+const char *ov2_status_string(ov2_status s);
+ov2_status ov2_ctx_synchronize(ov2_ctx *ctx);
+/* hipEvent pair on the ctx stream (used by bench.py: torch.cuda.Event would only see torch's stream) */
+ov2_status ov2_timer_start(ov2_ctx *ctx);
+ov2_status ov2_timer_stop(ov2_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+/* raw device memory for callers that keep keypoints resident (C++ hosts without torch) */
+ov2_status ov2_dev_alloc(ov2_ctx *ctx, size_t bytes, void **dptr);
+ov2_status ov2_dev_free(ov2_ctx *ctx, void *dptr);
+ov2_status ov2_memcpy_h2d(ov2_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);  /* sync */
+ov2_status ov2_memcpy_d2h(ov2_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);  /* sync */
+
+/* ---- images ---------------------------------------------------------------------------------- */
+ov2_status ov2_images_create(ov2_ctx *ctx, int batch, int w, int h, ov2_images **out);
+ov2_status ov2_images_upload(ov2_ctx *ctx, ov2_images *imgs, int b, const uint8_t *host, int stride);
+void ov2_images_destroy(ov2_images *imgs);
+
+/* ---- pyramid --------------------------------------------------------------------------------- */
+/* Replaces VisualFrontEnd::preprocessImage's  pclahe_->apply(img_raw, cur_img_)  +
+ * cv::buildOpticalFlowPyramid(cur_img_, cur_pyr_, Size(win,win), max_level)
+ * (src/visual_front_end.cpp:1159,1172; right image: src/mapper.cpp:76,81).
+ * use_clahe=0 skips CLAHE (`use_clahe: 0`).  tiles = (w/50, h/50) in the reference (src/ov2slam.cpp:85-89).
+ * The returned pyramid holds levels 0..L (L <= max_level, same early stop as OpenCV), each level a u8 image
+ * padded by `win` px of REFLECT_101 and an int16 (Ix,Iy) Scharr gradient padded by `win` px of zeros.
+ * Handles are ref-counted because the reference shares pyramids by value between threads
+ * (src/ov2slam.cpp:175-180). */
+ov2_status ov2_pyramid_build(ov2_ctx *ctx, const uint8_t *img, int w, int h, int stride, int win, int max_level,
+                             int use_clahe, float clahe_clip, int tiles_x, int tiles_y, ov2_pyr **out);
+/* batched, device-resident form: one pyramid per image of `imgs`, no host traffic, asynchronous. */
+ov2_status ov2_pyramid_build_images(ov2_ctx *ctx, const ov2_images *imgs, int win, int max_level, int use_clahe,
+                                    float clahe_clip, int tiles_x, int tiles_y, ov2_pyr **out);
+void ov2_pyr_retain(ov2_pyr *p);
+void ov2_pyr_release(ov2_pyr *p);
+int ov2_pyr_batch(const ov2_pyr *p);
+int ov2_pyr_nlevels(const ov2_pyr *p);
+ov2_status ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h, int *pad);
+/* copies level `level` of pyramid `b` to host as tight padded planes: img (h+2pad)x(w+2pad) u8,
+ * grad (h+2pad)x(w+2pad)x2 int16.  Either pointer may be NULL.  For parity tests / debugging. */
+ov2_status ov2_pyr_download_level(ov2_ctx *ctx, const ov2_pyr *p, int b, int level, uint8_t *img, int16_t *grad);
+
+/* ---- KLT ------------------------------------------------------------------------------------- */
+/* Replaces FeatureTracker::fbKltTracking(vprevpyr, vcurpyr, nwinsize, nbpyrlvl, ferr, fmax_fbklt_dist,
+ * vkps, vpriorkps, vkpstatus)  (include/feature_tracker.hpp:45, src/feature_tracker.cpp:35-137):
+ * forward pyramidal LK prev->cur from the priors on levels nlevels..0 (flags USE_INITIAL_FLOW |
+ * LK_GET_MIN_EIGENVALS), reject !status / err > err_th / not inBorder(1 px), backward LK cur->prev on level 0
+ * started at the original keypoint, reject |kp - back| > fb_th.  max_iter/eps are the TermCriteria of
+ * include/feature_tracker.hpp:40.  priors_xy is in/out and receives the forward result for every point,
+ * status[i] in {0,1}.  n == 0 returns OV2_OK and touches nothing (src/feature_tracker.cpp:43-46);
+ * nlevels is clamped to the pyramid (:50-52).  Supported window: odd, 3 <= win <= 11 (reference: 9). */
+ov2_status ov2_klt_track_fb(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels,
+                            int max_iter, float eps, float err_th, float fb_th, int n, const float *kps_xy,
+                            float *priors_xy, uint8_t *status);
+/* device-resident, asynchronous, batched form.  img_idx (n int32, may be NULL = all 0) selects which pyramid
+ * of the batch each keypoint lives in.  d_iters
+ * (n uint32, may be NULL) receives per keypoint the number of LK iterations executed, forward levels +
+ * backward pass (drives the algorithmic-bytes model of bench.py). */
+ov2_status ov2_klt_track_fb_dev(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels,
+                                int max_iter, float eps, float err_th, float fb_th, int n, const float *d_kps_xy,
+                                float *d_priors_xy, uint8_t *d_status, const int32_t *d_img_idx,
+                                uint32_t *d_iters);
+
+/* Replaces the two-stage batching of VisualFrontEnd::kltTracking (src/visual_front_end.cpp:132-275) with no
+ * host round trip between the stages: keypoints with has_prior[i] are tracked on 2 levels from prior_xy,
+ * their failures are re-queued on the full pyramid (starting from the failed forward result, :217-219), and
+ * if fewer than 33 % of them succeed every re-queued prior is reset to the keypoint (:228-233) and
+ * *d_p3p_req (per image) is set.  out_xy/out_status per keypoint.  Device pointers, asynchronous. */
+ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, int win,
+                                      int nlevels_full, int max_iter, float eps, float err_th, float fb_th, int n,
+                                      const float *d_kps_xy, const float *d_prior_xy, const uint8_t *d_has_prior,
+                                      const int32_t *d_img_idx, float *d_out_xy, uint8_t *d_out_status,
+                                      int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* n, may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OV2SLAM_HIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of the CPU oracle (libov2oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (ov2slam_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int)
+i64p = C.POINTER(C.c_int64)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libov2oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libov2oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.ov2o_pyramid_build.restype = C.c_void_p
+        L.ov2o_pyramid_build.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ov2o_pyramid_free.argtypes = [C.c_void_p]
+        L.ov2o_pyr_nlevels.argtypes = [C.c_void_p]
+        L.ov2o_pyr_level_info.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]
+        L.ov2o_pyr_image.restype = u8p
+        L.ov2o_pyr_image.argtypes = [C.c_void_p, C.c_int]
+        L.ov2o_pyr_grad.restype = C.POINTER(C.c_int16)
+        L.ov2o_pyr_grad.argtypes = [C.c_void_p, C.c_int]
+        L.ov2o_clahe.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, u8p, C.c_int]
+        L.ov2o_calc_optical_flow_pyr_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, u8p, f32p,
+                                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, i32p]
+        L.ov2o_fb_klt_tracking.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                           C.c_int, C.c_float, C.c_int, f32p, f32p, u8p, i64p]
+        L.ov2o_klt_tracking_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              C.c_int, C.c_float, C.c_int, f32p, f32p, u8p, f32p, u8p, i32p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Pyramid:
+    """cv::buildOpticalFlowPyramid restatement (padded images + Scharr gradients)."""
+
+    def __init__(self, img, win=9, max_level=3):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        self._h = lib().ov2o_pyramid_build(_p(img, u8p), w, h, w, win, max_level)
+        if not self._h:
+            raise MemoryError("ov2o_pyramid_build failed")
+        self.nlevels = lib().ov2o_pyr_nlevels(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ov2o_pyramid_free(self._h)
+            self._h = None
+
+    def level(self, l):
+        """returns (img[(h+2p),(w+2p)] u8, grad[(h+2p),(w+2p),2] i16, w, h, pad), copies."""
+        w, h, p, s = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().ov2o_pyr_level_info(self._h, l, C.byref(w), C.byref(h), C.byref(p), C.byref(s))
+        w, h, p, s = w.value, h.value, p.value, s.value
+        rows = h + 2 * p
+        img = np.ctypeslib.as_array(lib().ov2o_pyr_image(self._h, l), shape=(rows, s)).copy()
+        grad = np.ctypeslib.as_array(lib().ov2o_pyr_grad(self._h, l), shape=(rows, s, 2)).copy()
+        return img, grad, w, h, p
+
+
+def clahe(img, clip=3.0, tiles_x=15, tiles_y=9):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().ov2o_clahe(_p(img, u8p), w, h, w, clip, tiles_x, tiles_y, _p(out, u8p), w)
+    return out
+
+
+def calc_optical_flow_pyr_lk(prev, nxt, prev_xy, next_xy, win=9, max_level=3, max_iter=30, eps=0.01,
+                             min_eig_thr=1e-4):
+    prev_xy = np.ascontiguousarray(prev_xy, dtype=np.float32)
+    out = np.ascontiguousarray(next_xy, dtype=np.float32).copy()
+    n = prev_xy.shape[0]
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    ml = min(max_level, prev.nlevels - 1, nxt.nlevels - 1)
+    iters = np.zeros((n, ml + 1), np.int32)
+    lib().ov2o_calc_optical_flow_pyr_lk(prev._h, nxt._h, n, _p(prev_xy, f32p), _p(out, f32p), _p(status, u8p),
+                                        _p(err, f32p), win, max_level, max_iter, eps, min_eig_thr,
+                                        _p(iters, i32p))
+    return out, status, err, iters
+
+
+def fb_klt_tracking(prev, cur, kps_xy, priors_xy, win=9, nlevels=3, err_th=30.0, fb_th=0.5, max_iter=30,
+                    eps=0.01):
+    """FeatureTracker::fbKltTracking. returns (priors_out, status, total_lk_iterations)."""
+    kps = np.ascontiguousarray(kps_xy, dtype=np.float32)
+    pri = np.ascontiguousarray(priors_xy, dtype=np.float32).copy()
+    n = kps.shape[0]
+    status = np.zeros(n, np.uint8)
+    total = C.c_int64(0)
+    lib().ov2o_fb_klt_tracking(prev._h, cur._h, win, nlevels, err_th, fb_th, max_iter, eps, n, _p(kps, f32p),
+                               _p(pri, f32p), _p(status, u8p), C.byref(total))
+    return pri, status, total.value
+
+
+def klt_tracking_frame(prev, cur, kps_xy, prior_xy, has_prior, win=9, nlevels=3, err_th=30.0, fb_th=0.5,
+                       max_iter=30, eps=0.01):
+    kps = np.ascontiguousarray(kps_xy, dtype=np.float32)
+    pri = np.ascontiguousarray(prior_xy, dtype=np.float32)
+    hp = np.ascontiguousarray(has_prior, dtype=np.uint8)
+    n = kps.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    p3p = C.c_int(0)
+    lib().ov2o_klt_tracking_frame(prev._h, cur._h, win, nlevels, err_th, fb_th, max_iter, eps, n, _p(kps, f32p),
+                                  _p(pri, f32p), _p(hp, u8p), _p(out, f32p), _p(st, u8p), C.byref(p3p))
+    return out, st, bool(p3p.value)

@@ -1,0 +1,83 @@
+/*
+ * ov2_oracle.h -- CPU restatement ("oracle") of the OV2SLAM front-end + localBA hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker / the reported CPU baseline.  The product path is the HIP library
+ * (ov2slam_amd/csrc -> libov2hip.so) and it never links or calls any of this.
+ *
+ * PARITY STATUS
+ *   - pyramid / Scharr / CLAHE / pyramidal LK / forward-backward wrapper: the arithmetic lives in
+ *     OpenCV (modules/video/src/lkpyramid.cpp, modules/imgproc/src/{pyramids,clahe}.cpp), which is
+ *     NOT vendored in /root/reference and whose version is unpinned (CMakeLists.txt:76-80).  The
+ *     reference holds no test or fixture for it  =>  **parity unpinned** for the KLT arithmetic;
+ *     the restatement follows OpenCV's published algorithm and the
+ *     reference's own call sites (src/feature_tracker.cpp:35-137, src/visual_front_end.cpp:1143-1177).
+ *   - localBA linear algebra: pinned by the known-answer vectors the vendored Ceres 2.0.0 tests hold
+ *     as text (Thirdparty/ceres-solver/internal/ceres/linear_least_squares_problems.cc:66-180, ...),
+ *     see tests/golden/.  The reference's own localBA outputs: **parity unpinned** (no fixtures,
+ *     reference not buildable here: needs OpenCV, Eigen, ROS, PCL, SuiteSparse).
+ */
+#ifndef OV2_ORACLE_H
+#define OV2_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ front-end ---- */
+
+typedef struct ov2o_level {
+    int w, h;        /* level size (unpadded) */
+    int pad;         /* border on every side (= winSize, 9 in every shipped config) */
+    int stride;      /* elements per padded row = w + 2*pad */
+    uint8_t *img;    /* (h+2pad) x stride, REFLECT_101 padded */
+    int16_t *grad;   /* (h+2pad) x stride x 2 (Ix,Iy interleaved), zero padded */
+} ov2o_level;
+
+typedef struct ov2o_pyr {
+    int nlevels;
+    ov2o_level lv[8];
+} ov2o_pyr;
+
+/* cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level) with the defaults the reference
+ * uses (src/visual_front_end.cpp:1172, src/mapper.cpp:81). */
+ov2o_pyr *ov2o_pyramid_build(const uint8_t *img, int w, int h, int stride, int win, int max_level);
+void ov2o_pyramid_free(ov2o_pyr *p);
+int ov2o_pyr_nlevels(const ov2o_pyr *p);
+void ov2o_pyr_level_info(const ov2o_pyr *p, int l, int *w, int *h, int *pad, int *stride);
+const uint8_t *ov2o_pyr_image(const ov2o_pyr *p, int l);
+const int16_t *ov2o_pyr_grad(const ov2o_pyr *p, int l);
+
+/* cv::CLAHE::apply for CV_8UC1 (src/visual_front_end.cpp:1159; tiles from src/ov2slam.cpp:85-89). */
+void ov2o_clahe(const uint8_t *src, int w, int h, int stride, float clip, int tiles_x, int tiles_y,
+                uint8_t *dst, int dst_stride);
+
+/* cv::calcOpticalFlowPyrLK on prebuilt pyramids, flags = USE_INITIAL_FLOW | LK_GET_MIN_EIGENVALS
+ * (src/feature_tracker.cpp:66-69,113-116).  next_xy is in/out.  iters (optional, n*(max_level+1))
+ * receives the executed iteration count per point per level (for the algorithmic-bytes model). */
+void ov2o_calc_optical_flow_pyr_lk(const ov2o_pyr *prev, const ov2o_pyr *next, int n,
+                                   const float *prev_xy, float *next_xy, uint8_t *status, float *err,
+                                   int win, int max_level, int max_iter, float eps,
+                                   float min_eig_thr, int *iters);
+
+/* FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35-137). priors_xy in/out, status out. */
+void ov2o_fb_klt_tracking(const ov2o_pyr *prev, const ov2o_pyr *cur, int win, int nlevels,
+                          float err_th, float fb_th, int max_iter, float eps, int n,
+                          const float *kps_xy, float *priors_xy, uint8_t *status,
+                          int64_t *iter_count /* optional: total LK iterations executed */);
+
+/* VisualFrontEnd::kltTracking batching logic (src/visual_front_end.cpp:132-275) on flat arrays:
+ * stage 1 tracks the has_prior kps on 2 levels, failures are re-queued on the full pyramid,
+ * <33 % good drops all priors.  out_xy (n*2) = tracked position, out_status (n). */
+void ov2o_klt_tracking_frame(const ov2o_pyr *prev, const ov2o_pyr *cur, int win, int nlevels_full,
+                             float err_th, float fb_th, int max_iter, float eps, int n,
+                             const float *kps_xy, const float *prior_xy, const uint8_t *has_prior,
+                             float *out_xy, uint8_t *out_status, int *p3p_req);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,181 @@
+// ctx.hip -- context, device memory, image batches, pooled pyramid buffers of libov2hip.so
+#include "ov2_internal.h"
+
+ov2_status ov2_set_err(ov2_ctx *ctx, ov2_status s, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->err = buf;
+    }
+    return s;
+}
+
+extern "C" const char *ov2_status_string(ov2_status s)
+{
+    switch (s) {
+    case OV2_OK: return "ok";
+    case OV2_ERR_INVALID: return "invalid argument";
+    case OV2_ERR_HIP: return "HIP runtime error";
+    case OV2_ERR_NOMEM: return "out of memory";
+    case OV2_ERR_NODEVICE: return "no gfx950 device";
+    case OV2_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown";
+    }
+}
+
+extern "C" const char *ov2_last_error(const ov2_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" ov2_status ov2_ctx_create(int device, ov2_ctx **out)
+{
+    if (!out) return OV2_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return OV2_ERR_NODEVICE;  // never a CPU fallback
+    if (device < 0 || device >= ndev) return OV2_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return OV2_ERR_HIP;
+    ov2_ctx *c = new ov2_ctx();
+    c->device = device;
+    c->scratch_dev = nullptr;
+    c->scratch_bytes = 0;
+    c->tmp_img = nullptr;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return OV2_ERR_HIP;
+    }
+    *out = c;
+    return OV2_OK;
+}
+
+extern "C" void ov2_ctx_destroy(ov2_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (ov2_pyr_buf *b : c->pool) {
+        (void)hipFree(b->base);
+        if (b->lut) (void)hipFree(b->lut);
+        delete b;
+    }
+    if (c->tmp_img) ov2_images_destroy(c->tmp_img);
+    if (c->scratch_dev) (void)hipFree(c->scratch_dev);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" ov2_status ov2_ctx_synchronize(ov2_ctx *c)
+{
+    if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_timer_start(ov2_ctx *c)
+{
+    if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_timer_stop(ov2_ctx *c, float *ms)
+{
+    if (!c || !ms) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipEventRecord(c->ev1, c->stream));
+    OV2_HIP(c, hipEventSynchronize(c->ev1));
+    OV2_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_dev_alloc(ov2_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_dev_free(ov2_ctx *c, void *dptr)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (dptr) OV2_HIP(c, hipFree(dptr));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_memcpy_h2d(ov2_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_memcpy_d2h(ov2_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    return OV2_OK;
+}
+
+ov2_status ov2_scratch(ov2_ctx *c, size_t bytes, void **out)
+{
+    if (bytes > c->scratch_bytes) {
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->scratch_dev) OV2_HIP(c, hipFree(c->scratch_dev));
+        c->scratch_dev = nullptr;
+        c->scratch_bytes = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipMalloc(&c->scratch_dev, want);
+        if (e != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "scratch hipMalloc(%zu)", want);
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch_dev;
+    return OV2_OK;
+}
+
+// ---- images ---------------------------------------------------------------------------------------
+
+extern "C" ov2_status ov2_images_create(ov2_ctx *c, int batch, int w, int h, ov2_images **out)
+{
+    if (!c || !out || batch <= 0 || w <= 0 || h <= 0) return OV2_ERR_INVALID;
+    *out = nullptr;
+    OV2_HIP(c, hipSetDevice(c->device));
+    ov2_images *im = new ov2_images();
+    im->ctx = c;
+    im->batch = batch;
+    im->w = w;
+    im->h = h;
+    im->stride = ov2_round_up(w, 64);
+    im->bstride = (size_t)im->stride * h;
+    hipError_t e = hipMalloc((void **)&im->base, im->bstride * batch);
+    if (e != hipSuccess) {
+        delete im;
+        return ov2_set_err(c, OV2_ERR_NOMEM, "images hipMalloc: %s", hipGetErrorString(e));
+    }
+    *out = im;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_images_upload(ov2_ctx *c, ov2_images *im, int b, const uint8_t *host, int stride)
+{
+    if (!c || !im || !host || b < 0 || b >= im->batch || stride < im->w) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipMemcpy2DAsync(im->base + im->bstride * b, im->stride, host, stride, im->w, im->h,
+                                hipMemcpyHostToDevice, c->stream));
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    return OV2_OK;
+}
+
+extern "C" void ov2_images_destroy(ov2_images *im)
+{
+    if (!im) return;
+    (void)hipFree(im->base);
+    delete im;
+}

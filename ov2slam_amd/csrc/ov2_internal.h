@@ -1,0 +1,84 @@
+// ov2_internal.h -- shared state of libov2hip.so (not installed; the public ABI is include/ov2slam_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ov2slam_hip.h"
+
+#define OV2_MAX_LEVELS 8
+// left margin of every padded plane, in pixels: >= win (<= 11) and a multiple of 16 so that the interior
+// of a row starts 16-byte (u8 plane) / 64-byte (s16x2 plane) aligned for vector loads and stores.
+#define OV2_LM 16
+
+struct ov2_level_desc {
+    int w, h;             // unpadded size
+    int istride;          // bytes per row of the u8 plane (multiple of 64)
+    int gstride;          // int16x2 elements per row of the gradient plane (multiple of 16)
+    int rows;             // allocated rows = h + 2*pad (+ slack)
+    size_t img_off;       // byte offset of image plane of batch 0 inside the allocation
+    size_t grad_off;      // byte offset of gradient plane of batch 0
+    size_t img_bstride;   // bytes between consecutive batch entries (image plane)
+    size_t grad_bstride;  // bytes between consecutive batch entries (gradient plane)
+};
+
+// what kernels see (passed by value)
+struct ov2_pyr_view {
+    int nlevels, pad, batch;
+    unsigned char *base;
+    ov2_level_desc lv[OV2_MAX_LEVELS];
+};
+
+struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,batch)
+    int w, h, pad, max_level, batch;
+    size_t bytes;
+    unsigned char *base;
+    unsigned char *lut;  // CLAHE LUTs: batch * tiles * 256 (allocated lazily, max tiles 64x64)
+    ov2_pyr_view view;
+};
+
+struct ov2_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    std::mutex mu;                       // guards pool + err
+    std::vector<ov2_pyr_buf *> pool;     // free pyramid buffers
+    std::string err;
+    // scratch for host-pointer entry points (grown on demand)
+    void *scratch_dev;
+    size_t scratch_bytes;
+    ov2_images *tmp_img;                 // staging image for ov2_pyramid_build(host img)
+};
+
+struct ov2_images {
+    ov2_ctx *ctx;
+    int batch, w, h;
+    int stride;        // bytes per row (multiple of 64)
+    size_t bstride;    // bytes per image
+    unsigned char *base;
+};
+
+struct ov2_pyr {
+    std::atomic<int> refs;
+    ov2_ctx *ctx;
+    ov2_pyr_buf *buf;
+};
+
+ov2_status ov2_set_err(ov2_ctx *ctx, ov2_status s, const char *fmt, ...);
+ov2_status ov2_scratch(ov2_ctx *ctx, size_t bytes, void **out);
+
+#define OV2_HIP(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return ov2_set_err((ctx), OV2_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                                 \
+    } while (0)
+
+static inline int ov2_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -1,0 +1,476 @@
+// pyramid.hip -- CLAHE + optical-flow pyramid (pyrDown 5x5 + Scharr) for gfx950.
+//
+// Replaces (reference, /root/reference): VisualFrontEnd::preprocessImage src/visual_front_end.cpp:1143-1177
+// = cv::CLAHE::apply + cv::buildOpticalFlowPyramid(img, pyr, Size(9,9), 3); right image src/mapper.cpp:76-81.
+// Arithmetic = OpenCV semantics restated in oracle/ov2_oracle_fe.c (integer exact; CLAHE interpolation in
+// fp32 with contraction off, v_rndne for cvRound) -- results are bit-identical to the oracle.
+//
+// HBM layout (one allocation per pyramid batch, see ov2_level_desc): per level a u8 plane and an int16x2
+// (Ix,Iy) plane, each padded by `pad` (=win) pixels; the interior of every row starts at column OV2_LM=16
+// so that 4-pixel groups are dword (u8) / 16-byte (gradient) aligned.  u8 padding = REFLECT_101, gradient
+// padding = 0 (zeroed once when the pooled buffer is created; kernels never write it).
+//
+// Kernels (all HBM-streaming, byte/int16 work -- no MFMA on purpose):
+//   clahe_lut_kernel      one workgroup per (tile, image): LDS histogram -> clip/redistribute -> scan -> LUT
+//   level0_kernel         CLAHE bilinear LUT interpolation (or plain copy) -> padded level-0 plane
+//   level_kernel          one pass over level l staged in LDS (64x16 tile + 2-px halo):
+//                         writes Scharr(l) as 16-byte stores and pyrDown(l) -> level l+1 (+ its reflect border)
+#include "ov2_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    // one reflection is enough for |overshoot| < n (callers guarantee it)
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ unsigned char sat_u8_rn(float v)
+{
+    int r = (int)__builtin_rintf(v);  // v_rndne_f32: round half to even == cvRound
+    return (unsigned char)min(max(r, 0), 255);
+}
+
+// write one u8 pixel of a padded plane together with every REFLECT_101 copy of it in the border.
+__device__ __forceinline__ void store_reflections(unsigned char *plane, int istride, int pad, int W, int H, int x,
+                                                  int y, unsigned char v, bool write_self)
+{
+    int xs[3], ys[3], nx = 0, ny = 0;
+    xs[nx++] = x;
+    if (x >= 1 && x <= pad) xs[nx++] = -x;
+    if (x >= W - 1 - pad && x <= W - 2) xs[nx++] = 2 * (W - 1) - x;
+    ys[ny++] = y;
+    if (y >= 1 && y <= pad) ys[ny++] = -y;
+    if (y >= H - 1 - pad && y <= H - 2) ys[ny++] = 2 * (H - 1) - y;
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            if (i == 0 && j == 0 && !write_self) continue;
+            plane[(size_t)(ys[j] + pad) * istride + OV2_LM + xs[i]] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CLAHE LUT: grid (tiles_x*tiles_y, batch), 256 threads.
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__restrict__ src, int w, int h,
+                                                        int sstride, size_t sbstride, int tiles_x, int tiles_y,
+                                                        int tw, int th, int clip_limit, float lut_scale,
+                                                        unsigned char *__restrict__ lut)
+{
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const unsigned char *img = src + sbstride * b;
+    hist[tid] = 0;
+    __syncthreads();
+    const int npx = tw * th;
+    for (int i = tid; i < npx; i += 256) {
+        const int yy = i / tw, xx = i - yy * tw;
+        const int y = reflect101(ty * th + yy, h), x = reflect101(tx * tw + xx, w);
+        atomicAdd(&hist[img[(size_t)y * sstride + x]], 1);
+    }
+    __syncthreads();
+    int hv = hist[tid];
+    if (clip_limit > 0) {
+        int over = hv > clip_limit ? hv - clip_limit : 0;
+        if (over) hv = clip_limit;
+        // block sum of `over`
+        int s = over;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((tid & 63) == 0) wsum[tid >> 6] = s;
+        __syncthreads();
+        const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const int batch = clipped / 256;
+        const int residual = clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            int step = 256 / residual;
+            if (step < 1) step = 1;
+            if (tid % step == 0 && tid / step < residual) hv += 1;
+        }
+    }
+    // inclusive scan over 256 bins
+    scan[tid] = hv;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int v = scan[tid];
+        if (tid >= o) v += scan[tid - o];
+        __syncthreads();
+        scan[tid] = v;
+        __syncthreads();
+    }
+    lut[((size_t)b * tiles_x * tiles_y + tile) * 256 + tid] = sat_u8_rn((float)scan[tid] * lut_scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// level 0: CLAHE interpolation (use_clahe) or copy, 4 px per thread, into the padded plane + reflect border.
+// grid (ceil(w/256), h, batch), 64 threads.
+__global__ __launch_bounds__(64) void level0_kernel(const unsigned char *__restrict__ src, int w, int h, int sstride,
+                                                    size_t sbstride, int use_clahe,
+                                                    const unsigned char *__restrict__ lut, int tiles_x, int tiles_y,
+                                                    float inv_tw, float inv_th, ov2_pyr_view pv)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= w) return;
+    const ov2_level_desc L = pv.lv[0];
+    unsigned char *plane = pv.base + L.img_off + L.img_bstride * b;
+    const unsigned char *srow = src + sbstride * b + (size_t)y * sstride;
+    unsigned char out[4];
+    const int nvalid = min(4, w - x0);
+    unsigned int raw = 0;
+    if (nvalid == 4) raw = *reinterpret_cast<const unsigned int *>(srow + x0);  // sstride, x0 multiples of 4
+    else for (int i = 0; i < nvalid; ++i) raw |= (unsigned int)srow[x0 + i] << (8 * i);
+
+    if (use_clahe) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1;
+        const float ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, tiles_y - 1);
+        const unsigned char *p1 = lut + ((size_t)b * tiles_y + ty1) * tiles_x * 256;
+        const unsigned char *p2 = lut + ((size_t)b * tiles_y + ty2) * tiles_x * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + i;
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf);
+            int tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1;
+            const float xa1 = 1.0f - xa;
+            tx1 = max(tx1, 0);
+            tx2 = min(tx2, tiles_x - 1);
+            const int v = (raw >> (8 * i)) & 255;
+            const int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+            const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 +
+                              ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
+            out[i] = sat_u8_rn(res);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = (unsigned char)((raw >> (8 * i)) & 255);
+    }
+    unsigned char *drow = plane + (size_t)(y + pv.pad) * L.istride + OV2_LM;
+    if (nvalid == 4) {
+        *reinterpret_cast<unsigned int *>(drow + x0) =
+            (unsigned int)out[0] | ((unsigned int)out[1] << 8) | ((unsigned int)out[2] << 16) | ((unsigned int)out[3] << 24);
+    } else {
+        for (int i = 0; i < nvalid; ++i) drow[x0 + i] = out[i];
+    }
+    const bool yedge = (y <= pv.pad) || (y >= h - 1 - pv.pad);
+    const bool xedge = (x0 <= pv.pad) || (x0 + 3 >= w - 1 - pv.pad);
+    if (yedge || xedge)
+        for (int i = 0; i < nvalid; ++i) store_reflections(plane, L.istride, pv.pad, w, h, x0 + i, y, out[i], false);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// level l -> Scharr(l) [+ pyrDown -> level l+1].  Tile 64x16 px of level l, 256 threads.
+// grid (ceil(w/64), ceil(h/16), batch).
+#define TILE_W 64
+#define TILE_H 16
+#define LDS_ROWS (TILE_H + 4)  // rows y0-2 .. y0+17
+#define LDS_DW 18              // dwords per row: cols x0-4 .. x0+67
+
+__global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int has_next)
+{
+    __shared__ unsigned int tile[LDS_ROWS][LDS_DW];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    const ov2_level_desc L = pv.lv[l];
+    const int pad = pv.pad;
+    const unsigned char *img = pv.base + L.img_off + L.img_bstride * b;
+
+    // stage: dword loads from the padded plane (border already holds REFLECT_101, so no index logic)
+    for (int i = tid; i < LDS_ROWS * LDS_DW; i += 256) {
+        const int r = i / LDS_DW, c = i - r * LDS_DW;
+        int row = y0 - 2 + r + pad;                       // padded row index
+        row = min(row, L.h + 2 * pad - 1);                // tiles hanging over the bottom edge
+        int dw = (OV2_LM + x0 - 4) / 4 + c;               // dword column
+        dw = min(dw, L.istride / 4 - 1);                  // tiles hanging over the right edge
+        tile[r][c] = *reinterpret_cast<const unsigned int *>(img + (size_t)row * L.istride + 4 * dw);
+    }
+    __syncthreads();
+
+    // ---- Scharr: 4 px per thread ------------------------------------------------------------------
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+        const int x = x0 + 4 * tx, y = y0 + ty;
+        if (y < L.h && x < L.w) {
+            // bytes x-4 .. x+7 of rows y-1,y,y+1  ->  need cols x-1 .. x+4
+            int t0[6], t1[6];
+            unsigned int ra[3], rb[3], rc[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ra[k] = tile[ty + 1][tx + k];
+                rb[k] = tile[ty + 2][tx + k];
+                rc[k] = tile[ty + 3][tx + k];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int byte = 3 + c;  // col x-1 is byte 3 of the 12 loaded
+                const int a = (ra[byte >> 2] >> (8 * (byte & 3))) & 255;
+                const int m = (rb[byte >> 2] >> (8 * (byte & 3))) & 255;
+                const int d = (rc[byte >> 2] >> (8 * (byte & 3))) & 255;
+                t0[c] = (a + d) * 3 + m * 10;
+                t1[c] = d - a;
+            }
+            short g[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[2 * i] = (short)(t0[i + 2] - t0[i]);
+                g[2 * i + 1] = (short)((t1[i] + t1[i + 2]) * 3 + t1[i + 1] * 10);
+            }
+            short *grow = reinterpret_cast<short *>(pv.base + L.grad_off + L.grad_bstride * b) +
+                          ((size_t)(y + pad) * L.gstride + OV2_LM + x) * 2;
+            if (x + 3 < L.w) {
+                uint4 v;
+                v.x = (unsigned short)g[0] | ((unsigned int)(unsigned short)g[1] << 16);
+                v.y = (unsigned short)g[2] | ((unsigned int)(unsigned short)g[3] << 16);
+                v.z = (unsigned short)g[4] | ((unsigned int)(unsigned short)g[5] << 16);
+                v.w = (unsigned short)g[6] | ((unsigned int)(unsigned short)g[7] << 16);
+                *reinterpret_cast<uint4 *>(grow) = v;
+            } else {
+                for (int i = 0; i < L.w - x; ++i) { grow[2 * i] = g[2 * i]; grow[2 * i + 1] = g[2 * i + 1]; }
+            }
+        }
+    }
+
+    // ---- pyrDown: one output px per thread (32x8 outputs per tile) -----------------------------------
+    if (has_next) {
+        const ov2_level_desc N = pv.lv[l + 1];
+        const int lx = tid & 31, ly = tid >> 5;
+        const int xo = (x0 >> 1) + lx, yo = (y0 >> 1) + ly;
+        const int c0 = 2 + 2 * lx;  // first byte (col 2xo-2) inside the LDS row
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const unsigned int d0 = tile[2 * ly + j][c0 >> 2], d1 = tile[2 * ly + j][(c0 >> 2) + 1];
+            const unsigned long long v = (((unsigned long long)d1 << 32) | d0) >> (8 * (c0 & 3));
+            const int p0 = (int)(v & 255), p1 = (int)((v >> 8) & 255), p2 = (int)((v >> 16) & 255),
+                      p3 = (int)((v >> 24) & 255), p4 = (int)((v >> 32) & 255);
+            const int r = p0 + p4 + 4 * (p1 + p3) + 6 * p2;
+            const int kj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+            acc += kj * r;
+        }
+        const unsigned int val = (unsigned int)((acc + 128) >> 8);
+        // pack 4 neighbouring outputs into one dword store where the group is complete
+        const unsigned int v1 = __shfl_down(val, 1), v2 = __shfl_down(val, 2), v3 = __shfl_down(val, 3);
+        unsigned char *nplane = pv.base + N.img_off + N.img_bstride * b;
+        const bool valid = xo < N.w && yo < N.h;
+        const int gx = xo & ~3;  // group origin
+        const bool full = (gx + 3 < N.w) && yo < N.h;
+        if (full) {
+            if ((lx & 3) == 0)
+                *reinterpret_cast<unsigned int *>(nplane + (size_t)(yo + pad) * N.istride + OV2_LM + xo) =
+                    val | (v1 << 8) | (v2 << 16) | (v3 << 24);
+        } else if (valid) {
+            nplane[(size_t)(yo + pad) * N.istride + OV2_LM + xo] = (unsigned char)val;
+        }
+        if (valid) {
+            const bool edge = (xo <= pad) || (xo >= N.w - 1 - pad) || (yo <= pad) || (yo >= N.h - 1 - pad);
+            if (edge) store_reflections(nplane, N.istride, pad, N.w, N.h, xo, yo, (unsigned char)val, false);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+
+ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int batch, ov2_pyr_buf **out)
+{
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        for (size_t i = 0; i < c->pool.size(); ++i) {
+            ov2_pyr_buf *b = c->pool[i];
+            if (b->w == w && b->h == h && b->pad == pad && b->max_level == max_level && b->batch == batch) {
+                c->pool.erase(c->pool.begin() + i);
+                *out = b;
+                return OV2_OK;
+            }
+        }
+    }
+    ov2_pyr_buf *b = new ov2_pyr_buf();
+    b->w = w; b->h = h; b->pad = pad; b->max_level = max_level; b->batch = batch;
+    b->lut = nullptr;
+    ov2_pyr_view &v = b->view;
+    memset(&v, 0, sizeof(v));
+    v.pad = pad;
+    v.batch = batch;
+    size_t off = 0;
+    int cw = w, ch = h, nl = 0;
+    for (int l = 0; l <= max_level && l < OV2_MAX_LEVELS; ++l) {
+        ov2_level_desc &L = v.lv[l];
+        L.w = cw; L.h = ch;
+        L.istride = ov2_round_up(OV2_LM + cw + pad, 64);
+        L.gstride = ov2_round_up(OV2_LM + cw + pad, 16);
+        L.rows = ch + 2 * pad;
+        L.img_bstride = ((size_t)L.istride * L.rows + 255) / 256 * 256;
+        L.grad_bstride = ((size_t)L.gstride * 4 * L.rows + 255) / 256 * 256;
+        L.img_off = off; off += L.img_bstride * batch;
+        L.grad_off = off; off += L.grad_bstride * batch;
+        nl = l + 1;
+        cw = (cw + 1) / 2; ch = (ch + 1) / 2;
+        if (cw <= pad || ch <= pad) break;  // buildOpticalFlowPyramid early stop (next level <= winSize)
+    }
+    v.nlevels = nl;
+    b->bytes = off + 4096;
+    hipError_t e = hipMalloc((void **)&b->base, b->bytes);
+    if (e != hipSuccess) {
+        delete b;
+        return ov2_set_err(c, OV2_ERR_NOMEM, "pyramid hipMalloc(%zu): %s", off, hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(b->base, 0, b->bytes, c->stream);  // gradient padding = 0 for the lifetime of the buffer
+    if (e != hipSuccess) {
+        (void)hipFree(b->base);
+        delete b;
+        return ov2_set_err(c, OV2_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    v.base = b->base;
+    *out = b;
+    return OV2_OK;
+}
+
+}  // namespace
+
+extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im, int win, int max_level,
+                                               int use_clahe, float clip, int tiles_x, int tiles_y, ov2_pyr **out)
+{
+    if (!c || !im || !out) return OV2_ERR_INVALID;
+    *out = nullptr;
+    if (win < 3 || win > OV2_LM || max_level < 0 || max_level >= OV2_MAX_LEVELS)
+        return ov2_set_err(c, OV2_ERR_INVALID, "win=%d (3..%d) max_level=%d (0..%d)", win, OV2_LM, max_level,
+                           OV2_MAX_LEVELS - 1);
+    if (im->w <= win || im->h <= win) return ov2_set_err(c, OV2_ERR_INVALID, "image smaller than window");
+    if (use_clahe && (tiles_x < 1 || tiles_y < 1 || tiles_x > 64 || tiles_y > 64 || tiles_x > im->w || tiles_y > im->h))
+        return ov2_set_err(c, OV2_ERR_INVALID, "CLAHE tiles %dx%d", tiles_x, tiles_y);
+    OV2_HIP(c, hipSetDevice(c->device));
+    ov2_pyr_buf *buf = nullptr;
+    ov2_status s = acquire_buf(c, im->w, im->h, win, max_level, im->batch, &buf);
+    if (s != OV2_OK) return s;
+    const ov2_pyr_view &v = buf->view;
+    const int B = im->batch;
+
+    float inv_tw = 0.f, inv_th = 0.f;
+    if (use_clahe) {
+        if (!buf->lut) {
+            hipError_t e = hipMalloc((void **)&buf->lut, (size_t)B * 64 * 64 * 256);
+            if (e != hipSuccess) {
+                std::lock_guard<std::mutex> g(c->mu);
+                c->pool.push_back(buf);
+                return ov2_set_err(c, OV2_ERR_NOMEM, "CLAHE LUT hipMalloc");
+            }
+        }
+        int ew = im->w, eh = im->h;
+        if (im->w % tiles_x != 0 || im->h % tiles_y != 0) {  // CLAHE_Impl::apply: extend right/bottom
+            ew = im->w + (tiles_x - im->w % tiles_x);
+            eh = im->h + (tiles_y - im->h % tiles_y);
+        }
+        const int tw = ew / tiles_x, th = eh / tiles_y;
+        const int total = tw * th;
+        const float lut_scale = 255.0f / (float)total;
+        int clip_limit = 0;
+        if ((double)clip > 0.0) {
+            clip_limit = (int)((double)clip * total / 256);
+            if (clip_limit < 1) clip_limit = 1;
+        }
+        inv_tw = 1.0f / (float)tw;
+        inv_th = 1.0f / (float)th;
+        hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, c->stream, im->base, im->w,
+                           im->h, im->stride, im->bstride, tiles_x, tiles_y, tw, th, clip_limit, lut_scale, buf->lut);
+    }
+    hipLaunchKernelGGL(level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, c->stream, im->base, im->w,
+                       im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
+    for (int l = 0; l < v.nlevels; ++l) {
+        const ov2_level_desc &L = v.lv[l];
+        hipLaunchKernelGGL(level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
+                           0, c->stream, v, l, (l + 1 < v.nlevels) ? 1 : 0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->pool.push_back(buf);
+        return ov2_set_err(c, OV2_ERR_HIP, "pyramid launch: %s", hipGetErrorString(e));
+    }
+    ov2_pyr *p = new ov2_pyr();
+    p->refs.store(1);
+    p->ctx = c;
+    p->buf = buf;
+    *out = p;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_pyramid_build(ov2_ctx *c, const uint8_t *img, int w, int h, int stride, int win,
+                                        int max_level, int use_clahe, float clip, int tiles_x, int tiles_y,
+                                        ov2_pyr **out)
+{
+    if (!c || !img || !out || w <= 0 || h <= 0 || stride < w) return OV2_ERR_INVALID;
+    if (c->tmp_img && (c->tmp_img->w != w || c->tmp_img->h != h)) {
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
+        ov2_images_destroy(c->tmp_img);
+        c->tmp_img = nullptr;
+    }
+    if (!c->tmp_img) {
+        ov2_status s = ov2_images_create(c, 1, w, h, &c->tmp_img);
+        if (s != OV2_OK) return s;
+    }
+    ov2_status s = ov2_images_upload(c, c->tmp_img, 0, img, stride);
+    if (s != OV2_OK) return s;
+    s = ov2_pyramid_build_images(c, c->tmp_img, win, max_level, use_clahe, clip, tiles_x, tiles_y, out);
+    if (s != OV2_OK) return s;
+    OV2_HIP(c, hipStreamSynchronize(c->stream));  // the staging image may be overwritten by the next call
+    return OV2_OK;
+}
+
+extern "C" void ov2_pyr_retain(ov2_pyr *p)
+{
+    if (p) p->refs.fetch_add(1);
+}
+
+extern "C" void ov2_pyr_release(ov2_pyr *p)
+{
+    if (!p) return;
+    if (p->refs.fetch_sub(1) == 1) {
+        // stream-ordered reuse: later builds on the same ctx stream run after every kernel that reads this buffer
+        // when those readers were enqueued on the same ctx.  Cross-ctx readers must synchronise before release.
+        std::lock_guard<std::mutex> g(p->ctx->mu);
+        p->ctx->pool.push_back(p->buf);
+        delete p;
+    }
+}
+
+extern "C" int ov2_pyr_batch(const ov2_pyr *p) { return p ? p->buf->batch : 0; }
+extern "C" int ov2_pyr_nlevels(const ov2_pyr *p) { return p ? p->buf->view.nlevels : 0; }
+
+extern "C" ov2_status ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h, int *pad)
+{
+    if (!p || level < 0 || level >= p->buf->view.nlevels) return OV2_ERR_INVALID;
+    if (w) *w = p->buf->view.lv[level].w;
+    if (h) *h = p->buf->view.lv[level].h;
+    if (pad) *pad = p->buf->view.pad;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_pyr_download_level(ov2_ctx *c, const ov2_pyr *p, int b, int level, uint8_t *img,
+                                             int16_t *grad)
+{
+    if (!c || !p || b < 0 || b >= p->buf->batch || level < 0 || level >= p->buf->view.nlevels) return OV2_ERR_INVALID;
+    const ov2_pyr_view &v = p->buf->view;
+    const ov2_level_desc &L = v.lv[level];
+    const int pw = L.w + 2 * v.pad, ph = L.h + 2 * v.pad;
+    const int x_off = OV2_LM - v.pad;
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    if (img)
+        OV2_HIP(c, hipMemcpy2D(img, pw, v.base + L.img_off + L.img_bstride * b + x_off, L.istride, pw, ph,
+                               hipMemcpyDeviceToHost));
+    if (grad)
+        OV2_HIP(c, hipMemcpy2D(grad, (size_t)pw * 4, v.base + L.grad_off + L.grad_bstride * b + (size_t)x_off * 4,
+                               (size_t)L.gstride * 4, (size_t)pw * 4, ph, hipMemcpyDeviceToHost));
+    return OV2_OK;
+}

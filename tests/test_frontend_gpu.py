@@ -1,0 +1,156 @@
+"""GPU parity tests (through the C ABI) of CLAHE + pyramid + forward-backward KLT against the CPU oracle.
+Bar: bit-exact -- pyramid bytes, KLT status flags, and tracked positions (float32 bit patterns, which is
+stronger than the integer-pixel bar north_star asks for)."""
+import numpy as np
+import pytest
+
+from ov2slam_amd import frontend as fe, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_pyr_equal(gp, op, b=0):
+    assert gp.nlevels == op.nlevels
+    for l in range(op.nlevels):
+        gi, gg, w, h, p = gp.level(l, b)
+        oi, og, ow, oh, opad = op.level(l)
+        assert (w, h, p) == (ow, oh, opad)
+        assert np.array_equal(gi, oi), f"level {l} image differs at {np.argwhere(gi != oi)[:5]}"
+        assert np.array_equal(gg, og), f"level {l} gradient differs at {np.argwhere(gg != og)[:5]}"
+
+
+@pytest.mark.parametrize("use_clahe", [False, True])
+def test_pyramid_752x480_bit_exact(ctx, oracle, stream, use_clahe):
+    img = stream.left(3)
+    gp = fe.preprocess_image(ctx, img, use_clahe=use_clahe)
+    src = oracle.clahe(img, 3.0, 15, 9) if use_clahe else img
+    _assert_pyr_equal(gp, oracle.Pyramid(src, 9, 3))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (101, 67), (333, 257), (1241, 376), (20, 20), (19, 23)])
+def test_pyramid_odd_sizes(ctx, oracle, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    gp = fe.preprocess_image(ctx, img, use_clahe=False)
+    _assert_pyr_equal(gp, oracle.Pyramid(img, 9, 3))
+
+
+@pytest.mark.parametrize("w,h,tiles,clip", [(752, 480, (15, 9), 3.0), (640, 480, (12, 9), 3.0), (1241, 376, (24, 7), 3.0),
+                                            (320, 240, (8, 8), 2.0), (97, 61, (3, 2), 40.0), (128, 128, (4, 4), 0.5)])
+def test_clahe_bit_exact(ctx, oracle, w, h, tiles, clip):
+    rng = np.random.default_rng(w + h)
+    # mix of smooth ramp and noise so that clipping and the residual redistribution are both exercised
+    img = (np.linspace(0, 255, w)[None, :] * 0.6 + rng.integers(0, 100, size=(h, w))).clip(0, 255).astype(np.uint8)
+    gp = fe.preprocess_image(ctx, img, use_clahe=True, fclahe_val=clip, tiles=tiles, nklt_pyr_lvl=0)
+    gi, _, gw, gh, p = gp.level(0)
+    ref = oracle.clahe(img, clip, tiles[0], tiles[1])
+    assert np.array_equal(gi[p:p + gh, p:p + gw], ref)
+
+
+def test_pyramid_batched_matches_single(ctx, oracle, stream):
+    B = 3
+    imgs = fe.Images(ctx, B, 752, 480)
+    raw = [stream.left(t) for t in (0, 5, 9)]
+    for b in range(B):
+        imgs.upload(b, raw[b])
+    gp = fe.preprocess_images(ctx, imgs)
+    ctx.synchronize()
+    assert gp.batch == B
+    for b in range(B):
+        _assert_pyr_equal(gp, oracle.Pyramid(oracle.clahe(raw[b]), 9, 3), b)
+
+
+def _pyrs(ctx, oracle, stream, t0, t1, clahe=True):
+    I0, I1 = stream.left(t0), stream.left(t1)
+    g0, g1 = fe.preprocess_image(ctx, I0, use_clahe=clahe), fe.preprocess_image(ctx, I1, use_clahe=clahe)
+    if clahe:
+        I0, I1 = oracle.clahe(I0), oracle.clahe(I1)
+    return g0, g1, oracle.Pyramid(I0), oracle.Pyramid(I1)
+
+
+@pytest.mark.parametrize("nlevels", [0, 1, 3])
+@pytest.mark.parametrize("t1", [1, 12])
+def test_fb_klt_bit_exact(ctx, oracle, stream, nlevels, t1):
+    g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, t1)
+    kps = synth.grid_keypoints(1000)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    out, st = trk.fbKltTracking(g0, g1, 9, nlevels, 30.0, 0.5, kps, kps)
+    eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, kps, 9, nlevels, 30.0, 0.5, 30, 0.01)
+    assert np.array_equal(st, est.astype(bool))
+    assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+    assert np.array_equal(np.rint(out).astype(np.int32), np.rint(eout).astype(np.int32))  # north_star's bar
+    if nlevels == 3:
+        gt = stream.flow(0, t1, kps)
+        assert st.mean() > 0.95
+        assert np.median(np.linalg.norm(out[st] - gt[st], axis=1)) < 0.2
+
+
+def test_fb_klt_edge_cases(ctx, oracle, stream):
+    """points on/over the border, in flat (min-eig reject) regions, priors far outside, empty input."""
+    I0 = stream.left(0).copy()
+    I1 = stream.left(4).copy()
+    I0[100:200, 100:300] = 128   # textureless block -> minEig < 1e-4 -> status 0
+    I1[100:200, 100:300] = 128
+    g0, g1 = fe.preprocess_image(ctx, I0, use_clahe=False), fe.preprocess_image(ctx, I1, use_clahe=False)
+    o0, o1 = oracle.Pyramid(I0), oracle.Pyramid(I1)
+    kps = np.array([[0, 0], [751, 479], [0.4, 479.6], [-3.0, 10.0], [760.0, 100.0], [150.0, 150.0], [200.0, 150.0],
+                    [1.0, 1.0], [750.0, 478.0], [375.5, 239.5], [5.2, 300.7], [746.9, 5.1]], np.float32)
+    pri = kps.copy()
+    pri[9] = [900.0, -50.0]   # prior far outside the image -> out-of-range break in the iteration
+    pri[10] = [-8.0, 300.0]
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for nl in (0, 1, 3):
+        out, st = trk.fbKltTracking(g0, g1, 9, nl, 30.0, 0.5, kps, pri)
+        eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, pri, 9, nl, 30.0, 0.5, 30, 0.01)
+        assert np.array_equal(st, est.astype(bool)), nl
+        assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), nl
+        assert not st[5]      # flat region
+    out, st = trk.fbKltTracking(g0, g1, 9, 3, 30.0, 0.5, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))
+    assert out.shape == (0, 2) and st.shape == (0,)
+
+
+@pytest.mark.parametrize("win,max_iter,eps,fb", [(7, 30, 0.01, 0.5), (11, 10, 0.03, 1.0), (5, 3, 0.01, 0.25), (9, 0, 0.01, 0.5)])
+def test_fb_klt_other_parameters(ctx, oracle, stream, win, max_iter, eps, fb):
+    I0, I1 = stream.left(2), stream.left(9)
+    g0 = fe.preprocess_image(ctx, I0, use_clahe=False, klt_win_size=11)
+    g1 = fe.preprocess_image(ctx, I1, use_clahe=False, klt_win_size=11)
+    o0, o1 = oracle.Pyramid(I0, 11, 3), oracle.Pyramid(I1, 11, 3)
+    kps = synth.grid_keypoints(500, seed=5)
+    trk = fe.FeatureTracker(ctx, max_iter, eps)
+    out, st = trk.fbKltTracking(g0, g1, win, 2, 30.0, fb, kps, kps)
+    eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, kps, win, 2, 30.0, fb, max_iter, eps)
+    assert np.array_equal(st, est.astype(bool))
+    assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+
+
+def test_klt_tracking_frame_two_stage(ctx, oracle, stream):
+    """VisualFrontEnd::kltTracking batching: priors on 2 levels, failures re-queued on the full pyramid."""
+    g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, 10)
+    kps = synth.grid_keypoints(2000)
+    gt = stream.flow(0, 10, kps)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for sigma, expect_p3p in ((1.0, False), (25.0, True)):   # bad motion model -> <33 % good -> priors dropped
+        pri, has = synth.make_priors(kps, gt, sigma=sigma)
+        out, st, p3p = trk.kltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, pri, has)
+        eout, est, ep3p = oracle.klt_tracking_frame(o0, o1, kps, pri, has)
+        assert p3p == ep3p == expect_p3p
+        assert np.array_equal(st, est.astype(bool))
+        assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+
+
+def test_fb_klt_full_size_properties(ctx, stream):
+    """config-4 size (4000 kps): size-independent properties -- tracks land on the analytic flow, identity
+    pair returns the keypoints themselves, batched call == per-image calls."""
+    I0, I1 = stream.left(0), stream.left(8)
+    g0, g1 = fe.preprocess_image(ctx, I0), fe.preprocess_image(ctx, I1)
+    kps = synth.grid_keypoints(4000)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    out, st = trk.fbKltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, kps)
+    gt = stream.flow(0, 8, kps)
+    e = np.linalg.norm(out[st] - gt[st], axis=1)
+    assert st.mean() > 0.95 and np.median(e) < 0.2 and np.percentile(e, 99) < 1.0
+    same, st2 = trk.fbKltTracking(g0, g0, 9, 3, 30.0, 0.5, kps, kps)
+    assert st2.all() and np.abs(same - kps).max() < 1e-3
+    # idempotence of the call itself (deterministic reductions)
+    out3, st3 = trk.fbKltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, kps)
+    assert np.array_equal(out3.view(np.uint32), out.view(np.uint32)) and np.array_equal(st3, st)
