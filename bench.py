@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- tracked frames/s (+ localBA iterations/s) of the MI355X front-end + local-BA hot path.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched with torch.distributed.run,
+one rank per GPU.  W untimed steps, then EXACTLY K timed steps bracketed by barrier + synchronize, MAX over
+ranks, rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json north_star; synthetic because no EuRoC data exists here or on the GPU box):
+  synthetic 752x480 stereo streams, `--kps` (2048) keypoints per frame, `--seqs` independent sequences per GPU
+  processed in lock-step (one "step" = one new stereo frame of every sequence):
+    per frame     : CLAHE + 4-level pyramid + Scharr of the left image  (VisualFrontEnd::preprocessImage)
+                    two-stage forward-backward KLT prev->cur            (VisualFrontEnd::kltTracking)
+    every KF-th   : right image CLAHE + pyramid, stereo KLT left->right (Mapper::run / MapManager::stereoMatching)
+                    [localBA on the keyframe window when the BA path is built: Optimizer::localBA]
+  inputs (images, keypoints, priors) are resident in HBM before the timed region; nothing crosses PCIe inside it.
+Sequences are independent, so N GPUs = N x seqs sequences, no data-path collective ("scaling": "weak");
+RCCL is used only for the end-of-run reduction of {frames, seconds}.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, WIN, NLVL = 752, 480, 9, 3
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seqs", type=int, default=16, help="independent sequences per GPU (batched per launch)")
+    ap.add_argument("--kps", type=int, default=2048, help="keypoints per frame (north_star: ~2k)")
+    ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per stream (ping-pong cycle)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------------
+def lk_bytes(work_words):
+    """one level pass = 500 B template fetch, one LK iteration = 100 B of J."""
+    w = np.asarray(work_words, np.uint32)
+    return 500.0 * float((w >> 16).sum()) + 100.0 * float((w & 0xffff).sum())
+
+
+def pyr_level_bytes(w, h, nlevels):
+    """per level_kernel launch: read level l (u8), write Scharr (4 B/px) + level l+1 (u8)."""
+    out, cw, ch = [], w, h
+    for l in range(nlevels):
+        nw, nh = (cw + 1) // 2, (ch + 1) // 2
+        out.append(cw * ch * 5 + (nw * nh if l + 1 < nlevels else 0))
+        cw, ch = nw, nh
+    return out
+
+
+class Workload:
+    """everything resident in HBM: per cycle position c, the left/right image batches, keypoints, priors."""
+
+    def __init__(self, ctx, fe, synth, seqs, kps, nframes, seed):
+        self.ctx, self.fe, self.B, self.N = ctx, fe, seqs, kps
+        S = synth.StereoStream(seed=seed)
+        F = nframes
+        left = [S.left(3 * t) for t in range(F)]    # 3 stream-frames apart: flow of 1-2 px per step
+        right = [S.right(3 * t) for t in range(F)]
+        order = list(range(F)) + list(range(F - 2, 0, -1))   # ping-pong so consecutive frames are adjacent
+        self.L = L = len(order)
+        self.trk = fe.FeatureTracker(ctx, 30, 0.01)
+        base = synth.grid_keypoints(kps, seed=seed + 7)
+        self.left, self.right, self.kps, self.pri, self.has = [], [], [], [], []
+        self.st_pri, self.st_has = [], []
+        for c in range(L):
+            il, ir = fe.Images(ctx, seqs, W, H), fe.Images(ctx, seqs, W, H)
+            k_all, p_all, h_all, sp_all, sh_all = [], [], [], [], []
+            for b in range(seqs):
+                cur = order[(c + 3 * b) % L]
+                prv = order[(c - 1 + 3 * b) % L]
+                il.upload(b, left[cur])
+                ir.upload(b, right[cur])
+                # keypoints live in the PREVIOUS frame; the prior is the motion-model prediction in the current one
+                gt = S.flow(3 * prv, 3 * cur, base)
+                pri, has = synth.make_priors(base, gt, seed=seed + 11 + 31 * c + b)
+                spri, shas = synth.make_priors(base, S.stereo_gt(base), seed=seed + 13 + 31 * c + b)
+                k_all.append(base); p_all.append(pri); h_all.append(has); sp_all.append(spri); sh_all.append(shas)
+            self.left.append(il); self.right.append(ir)
+            self.kps.append(ctx.to_device(np.concatenate(k_all)))
+            self.pri.append(ctx.to_device(np.concatenate(p_all)))
+            self.has.append(ctx.to_device(np.concatenate(h_all)))
+            self.st_pri.append(ctx.to_device(np.concatenate(sp_all)))
+            self.st_has.append(ctx.to_device(np.concatenate(sh_all)))
+        n = seqs * kps
+        self.n = n
+        self.img_idx = ctx.to_device(np.repeat(np.arange(seqs, dtype=np.int32), kps))
+        self.out_xy = ctx.empty((n, 2), np.float32)
+        self.out_st = ctx.empty((n,), np.uint8)
+        self.p3p = ctx.empty((seqs,), np.int32)
+        self.work = ctx.empty((2 * n,), np.uint32)
+        self.prev = None
+        self.step_no = 0
+        self.host_frames = (left, right, order, base, S)
+
+    def step(self, kf_every, want_work=False):
+        fe, ctx, c = self.fe, self.ctx, self.step_no % self.L
+        cur = fe.preprocess_images(ctx, self.left[c], True, 3.0, WIN, NLVL)           # 2.FE_TM_preprocessImage
+        work = self.work if want_work else None
+        if self.prev is not None:                                                    # 2.FE_TM_KLT-Tracking
+            self.trk.kltTracking_dev(self.prev, cur, WIN, NLVL, 30.0, 0.5, self.kps[c], self.pri[c], self.has[c],
+                                     self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, work)
+            self.prev.release()
+        self.prev = cur
+        is_kf = (self.step_no % kf_every) == 0
+        if is_kf:                                                                    # 1.KF_stereoMatching
+            rp = fe.preprocess_images(ctx, self.right[c], True, 3.0, WIN, NLVL)
+            self.trk.kltTracking_dev(cur, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
+                                     self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, None)
+            rp.release()
+        self.step_no += 1
+        return is_kf
+
+
+def cpu_baseline(workload, kf_every, budget_s):
+    """the oracle (a scalar C port of the OpenCV path) timed on this host, 1 thread, on a bounded sample of the
+    SAME workload (one sequence).  Reported beside the GPU number, never the thing measured or shipped."""
+    from oracle import oracle_py as O
+    left, right, order, base, S = workload.host_frames
+    from ov2slam_amd import synth
+    L = len(order)
+    t0 = time.perf_counter()
+    prev, frames, s = None, 0, 0
+    while True:
+        cur_i, prv_i = order[s % L], order[(s - 1) % L]
+        cur = O.Pyramid(O.clahe(left[cur_i], 3.0, 15, 9), WIN, NLVL)
+        if prev is not None:
+            gt = S.flow(3 * prv_i, 3 * cur_i, base)
+            pri, has = synth.make_priors(base, gt, seed=1 + s)
+            O.klt_tracking_frame(prev, cur, base, pri, has, WIN, NLVL, 30.0, 0.5, 30, 0.01)
+        if s % kf_every == 0:
+            rp = O.Pyramid(O.clahe(right[cur_i], 3.0, 15, 9), WIN, NLVL)
+            spri, shas = synth.make_priors(base, S.stereo_gt(base), seed=2 + s)
+            O.klt_tracking_frame(cur, rp, base, spri, shas, WIN, NLVL, 30.0, 0.5, 30, 0.01)
+        prev = cur
+        frames += 1
+        s += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and frames >= 2 * kf_every:
+            break
+    # subtract the host-side prior generation (numpy) by timing it alone is overkill: it is <2 % of a frame
+    return frames / el, frames, el
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from ov2slam_amd import frontend as fe, synth
+    ctx = fe.Context(local)
+    wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank)
+
+    for _ in range(a.warmup):
+        wl.step(a.kf_every)
+    ctx.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    nkf = 0
+    for _ in range(a.steps):
+        nkf += wl.step(a.kf_every)
+    gpu_ms = ctx.timer_stop()     # synchronises the ctx stream
+    barrier()
+    el = time.perf_counter() - t0
+
+    tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+    frames = torch.tensor([float(a.steps * a.seqs)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
+    el_max, frames_all = float(tmax.item()), float(frames.item())
+
+    out = {
+        "metric": "tracked_frames_per_sec", "value": frames_all / el_max, "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el_max / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/s16 fixed-point + f32",
+        "data": "synthetic",
+        "config": {"workload": "synthetic 752x480 stereo streams, CLAHE + 4-level pyramid + 2-stage fwd-bwd KLT "
+                               f"(win 9, 30 it, eps 0.01) on {a.kps} kps/frame, right-image pyramid + stereo KLT every "
+                               f"{a.kf_every}th frame; {a.seqs} sequences per GPU in lock-step",
+                   "sequences_per_gpu": a.seqs, "keypoints_per_frame": a.kps, "kf_every": a.kf_every,
+                   "image": [W, H], "parallelism": f"replicas x{world} (one batch of sequences per GPU)"},
+        "gpu_stream_ms_per_step": gpu_ms / a.steps,
+        "keyframes_per_step": nkf / a.steps,
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # second, instrumented pass over the same steps: every launch bracketed by hipEvents on the ctx stream
+        ctx.kernel_timing(True)
+        ctx.kernel_times()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.step(a.kf_every)
+        ctx.synchronize()
+        el_instr = time.perf_counter() - t1
+        times = ctx.kernel_times()
+        ctx.kernel_timing(False)
+        # algorithmic bytes per launch: KLT from the executed work words of a representative pass over the cycle
+        n = wl.n
+        per_pos = []
+        for _ in range(wl.L):
+            wl.step(10 ** 9, want_work=True)      # no KF => work words belong to the temporal launch
+            ctx.synchronize()
+            w = wl.work.get()
+            per_pos.append((lk_bytes(w[:n]), lk_bytes(w[n:])))
+        b1 = float(np.mean([p[0] for p in per_pos]))
+        b2 = float(np.mean([p[1] for p in per_pos]))
+        lvl_bytes = pyr_level_bytes(W, H, NLVL + 1)
+        alg = {
+            "klt_stage1_kernel": b1, "klt_stage2_kernel": b2,
+            "level_kernel": a.seqs * float(np.mean(lvl_bytes)),
+            "level0_kernel": a.seqs * 2.0 * W * H,
+            "clahe_lut_kernel": a.seqs * 1.0 * W * H,
+        }
+        rl = {}
+        for k, (ms, cnt) in times.items():
+            avg_s = ms * 1e-3 / max(cnt, 1)
+            gbs = alg.get(k, 0.0) / avg_s / 1e9 if avg_s > 0 else 0.0
+            rl[k] = {"avg_us": 1e6 * avg_s, "launches": cnt, "total_ms": ms, "alg_bytes_per_launch": alg.get(k),
+                     "achieved_GBs": gbs}
+        dom = max(times, key=lambda k: times[k][0])
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": rl[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": rl[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                           "avg_launch_us": rl[dom]["avg_us"], "alg_bytes_per_launch": rl[dom]["alg_bytes_per_launch"]}
+        out["kernels"] = rl
+        out["ms_per_step_instrumented"] = 1e3 * el_instr / a.steps
+
+    if rank == 0 and not a.no_cpu_baseline:
+        fps, nfr, sec = cpu_baseline(wl, a.kf_every, a.cpu_seconds)
+        out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{nfr} frames of one sequence of the same workload ({sec:.1f} s), "
+                                         "oracle/ C port of the OpenCV path, 1 thread; host has "
+                                         f"{os.cpu_count()} logical cores"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

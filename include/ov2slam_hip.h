@@ -51,6 +51,12 @@ ov2_status ov2_ctx_synchronize(ov2_ctx *ctx);
 /* hipEvent pair on the ctx stream (used by bench.py: torch.cuda.Event would only see torch's stream) */
 ov2_status ov2_timer_start(ov2_ctx *ctx);
 ov2_status ov2_timer_stop(ov2_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+/* optional per-kernel timing: when enabled every kernel launch of this ctx is bracketed by a hipEvent pair on the
+ * ctx stream; ov2_ktime_report synchronises, returns per-kernel {name, total ms, launches} since the last report
+ * and resets.  Used by bench.py for roofline.achieved; off by default (it perturbs back-to-back launches). */
+ov2_status ov2_ktime_enable(ov2_ctx *ctx, int on);
+ov2_status ov2_ktime_report(ov2_ctx *ctx, int max_kernels, const char **names, double *total_ms,
+                            long long *launches, int *n_out);
 /* raw device memory for callers that keep keypoints resident (C++ hosts without torch) */
 ov2_status ov2_dev_alloc(ov2_ctx *ctx, size_t bytes, void **dptr);
 ov2_status ov2_dev_free(ov2_ctx *ctx, void *dptr);
@@ -99,8 +105,8 @@ ov2_status ov2_klt_track_fb(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cu
                             float *priors_xy, uint8_t *status);
 /* device-resident, asynchronous, batched form.  img_idx (n int32, may be NULL = all 0) selects which pyramid
  * of the batch each keypoint lives in.  d_iters
- * (n uint32, may be NULL) receives per keypoint the number of LK iterations executed, forward levels +
- * backward pass (drives the algorithmic-bytes model of bench.py). */
+ * (n uint32, may be NULL) receives per keypoint a work word: low 16 bits = LK iterations executed (forward
+ * levels + backward pass), high 16 bits = level passes started (template fetches) (drives the algorithmic-bytes model of bench.py). */
 ov2_status ov2_klt_track_fb_dev(ov2_ctx *ctx, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels,
                                 int max_iter, float eps, float err_th, float fb_th, int n, const float *d_kps_xy,
                                 float *d_priors_xy, uint8_t *d_status, const int32_t *d_img_idx,
@@ -115,7 +121,7 @@ ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const o
                                       int nlevels_full, int max_iter, float eps, float err_th, float fb_th, int n,
                                       const float *d_kps_xy, const float *d_prior_xy, const uint8_t *d_has_prior,
                                       const int32_t *d_img_idx, float *d_out_xy, uint8_t *d_out_status,
-                                      int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* n, may be NULL */);
+                                      int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* 2n work words: [0,n) stage 1, [n,2n) stage 2; may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,9 @@ SIGNATURES = {
     "ov2_ctx_synchronize": (C.c_int, [vp]),
     "ov2_timer_start": (C.c_int, [vp]),
     "ov2_timer_stop": (C.c_int, [vp, fp]),
+    "ov2_ktime_enable": (C.c_int, [vp, C.c_int]),
+    "ov2_ktime_report": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_longlong), ip]),
     "ov2_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
     "ov2_dev_free": (C.c_int, [vp, vp]),
     "ov2_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -43,6 +43,7 @@ extern "C" ov2_status ov2_ctx_create(int device, ov2_ctx **out)
     c->scratch_dev = nullptr;
     c->scratch_bytes = 0;
     c->tmp_img = nullptr;
+    c->ktime_on = false;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -63,6 +64,8 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
         delete b;
     }
     if (c->tmp_img) ov2_images_destroy(c->tmp_img);
+    for (auto &r : c->ktime_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c->ktime_free) (void)hipEventDestroy(e);
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -178,4 +181,69 @@ extern "C" void ov2_images_destroy(ov2_images *im)
     if (!im) return;
     (void)hipFree(im->base);
     delete im;
+}
+
+// ---- per-kernel event timing ------------------------------------------------------------------------
+
+const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", "level_kernel", "klt_fb_kernel",
+                                           "klt_stage1_kernel", "klt_stage2_kernel"};
+
+static hipEvent_t ktime_event(ov2_ctx *c)
+{
+    if (!c->ktime_free.empty()) {
+        hipEvent_t e = c->ktime_free.back();
+        c->ktime_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void ov2_ktime_begin(ov2_ctx *c, int id)
+{
+    ov2_ktime_rec r;
+    r.id = id;
+    r.e0 = ktime_event(c);
+    r.e1 = ktime_event(c);
+    (void)hipEventRecord(r.e0, c->stream);
+    c->ktime_recs.push_back(r);
+}
+
+void ov2_ktime_end(ov2_ctx *c) { (void)hipEventRecord(c->ktime_recs.back().e1, c->stream); }
+
+extern "C" ov2_status ov2_ktime_enable(ov2_ctx *c, int on)
+{
+    if (!c) return OV2_ERR_INVALID;
+    c->ktime_on = on != 0;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_ktime_report(ov2_ctx *c, int max_kernels, const char **names, double *total_ms,
+                                       long long *launches, int *n_out)
+{
+    if (!c || !n_out || max_kernels < 0) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    double tot[OV2_K_MAX] = {0};
+    long long cnt[OV2_K_MAX] = {0};
+    for (auto &r : c->ktime_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.id >= 0 && r.id < OV2_K_MAX) {
+            tot[r.id] += ms;
+            cnt[r.id] += 1;
+        }
+        c->ktime_free.push_back(r.e0);
+        c->ktime_free.push_back(r.e1);
+    }
+    c->ktime_recs.clear();
+    int n = 0;
+    for (int i = 0; i < OV2_K_MAX && n < max_kernels; ++i) {
+        if (!cnt[i]) continue;
+        if (names) names[n] = ov2_kernel_names[i] ? ov2_kernel_names[i] : "?";
+        if (total_ms) total_ms[n] = tot[i];
+        if (launches) launches[n] = cnt[i];
+        ++n;
+    }
+    *n_out = n;
+    return OV2_OK;
 }

@@ -204,6 +204,7 @@ __device__ __forceinline__ int fb_track_one(const ov2_pyr_view &pv, const ov2_py
     for (int l = nlevels; l >= 0; --l) {
         const plane_ptrs I = level_planes(pv, l, b), J = level_planes(cv, l, b);
         it += lk_level(I.img, I.grad, J.img, pv.lv[l], cv.lv[l], pv.pad, l, nlevels, kx, ky, fx, fy, status, err, P, lane);
+        it += 1u << 16;  // one level pass (template fetch) -- high half of the work word
     }
     // gates of src/feature_tracker.cpp:79-101
     const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
@@ -215,6 +216,7 @@ __device__ __forceinline__ int fb_track_one(const ov2_pyr_view &pv, const ov2_py
         float e2 = 0.f, bx = kx, by = ky;
         const plane_ptrs I = level_planes(cv, 0, b), J = level_planes(pv, 0, b);
         it += lk_level(I.img, I.grad, J.img, cv.lv[0], pv.lv[0], cv.pad, 0, 0, fx, fy, bx, by, st2, e2, P, lane);
+        it += 1u << 16;
         if (!st2) ok = 0;
         else {
             const float dx = kx - bx, dy = ky - by;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
                                                         const unsigned char *__restrict__ has_prior,
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
                                                         unsigned char *__restrict__ out_status,
-                                                        int *__restrict__ counts /* [batch][2] = {n3d, good} */,
+                                                        unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
                                                         unsigned *__restrict__ iters)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -272,8 +274,9 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
         out_xy[i] = pr;  // tracked position, or the failed forward result that seeds stage 2 (:217-219)
         out_status[i] = (unsigned char)ok;
         if (iters) iters[i] = it;
-        atomicAdd(&counts[2 * b], 1);
-        if (ok) atomicAdd(&counts[2 * b + 1], 1);
+        // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
+        // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
+        atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
     }
 }
 
@@ -283,17 +286,21 @@ __global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr
                                                         const unsigned char *__restrict__ has_prior,
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
                                                         unsigned char *__restrict__ out_status,
-                                                        const int *__restrict__ counts, int *__restrict__ p3p_req,
+                                                        const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
                                                         unsigned *__restrict__ iters)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     const int b = img_idx ? img_idx[i] : 0;
-    const int n3 = counts[2 * b], good = counts[2 * b + 1];
+    const unsigned cw = counts[64 * b + lane];
+    const int n3 = (int)wave_sum_i64((int)(cw & 0xffffu)), good = (int)wave_sum_i64((int)(cw >> 16));
     const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
     if (lane == 0 && p3p_req && drop) p3p_req[b] = 1;
     const bool hp = has_prior[i] != 0;
-    if (hp && out_status[i]) return;  // tracked in stage 1
+    if (hp && out_status[i]) {  // tracked in stage 1
+        if (lane == 0 && iters) iters[n + i] = 0;
+        return;
+    }
     const float2 kp = kps[i];
     float2 pr = (hp && !drop) ? out_xy[i] : kp;
     unsigned it = 0;
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr
     if (lane == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
-        if (iters) iters[i] += it;
+        if (iters) iters[n + i] = it;  // second half of the work-word array = stage 2
     }
 }
 
@@ -345,7 +352,7 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     ov2_status s = make_params(c, prev, cur, win, nlevels, max_iter, eps, err_th, fb_th, &P);
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(klt_fb_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
+    OV2_LAUNCH(c, OV2_K_KLT_FB, klt_fb_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
                        reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_priors), d_status,
                        d_img_idx, d_iters);
     OV2_HIP(c, hipGetLastError());
@@ -392,15 +399,15 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     OV2_HIP(c, hipSetDevice(c->device));
     const int B = prev->buf->batch;
     void *scr = nullptr;
-    s = ov2_scratch(c, (size_t)B * 2 * sizeof(int) + 256, &scr);
+    s = ov2_scratch(c, (size_t)B * 64 * sizeof(unsigned) + 256, &scr);
     if (s != OV2_OK) return s;
-    int *counts = (int *)scr;
-    OV2_HIP(c, hipMemsetAsync(counts, 0, (size_t)B * 2 * sizeof(int), c->stream));
+    unsigned *counts = (unsigned *)scr;
+    OV2_HIP(c, hipMemsetAsync(counts, 0, (size_t)B * 64 * sizeof(unsigned), c->stream));
     if (d_p3p_req) OV2_HIP(c, hipMemsetAsync(d_p3p_req, 0, (size_t)B * sizeof(int), c->stream));
-    hipLaunchKernelGGL(klt_stage1_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
+    OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
                        reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<const float2 *>(d_prior), d_has_prior,
                        d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters);
-    hipLaunchKernelGGL(klt_stage2_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
+    OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
                        reinterpret_cast<const float2 *>(d_kps), d_has_prior, d_img_idx,
                        reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters);
     OV2_HIP(c, hipGetLastError());

@@ -43,6 +43,18 @@ struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,ba
     ov2_pyr_view view;
 };
 
+enum ov2_kernel_id {
+    OV2_K_CLAHE_LUT = 0, OV2_K_LEVEL0, OV2_K_LEVEL, OV2_K_KLT_FB, OV2_K_KLT_STAGE1, OV2_K_KLT_STAGE2,
+    OV2_K_BA_FIRST,  // BA kernels register from here (ba.hip)
+    OV2_K_MAX = 48
+};
+extern const char *ov2_kernel_names[OV2_K_MAX];
+
+struct ov2_ktime_rec {
+    int id;
+    hipEvent_t e0, e1;
+};
+
 struct ov2_ctx {
     int device;
     hipStream_t stream;
@@ -54,6 +66,10 @@ struct ov2_ctx {
     void *scratch_dev;
     size_t scratch_bytes;
     ov2_images *tmp_img;                 // staging image for ov2_pyramid_build(host img)
+    // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
+    bool ktime_on;
+    std::vector<ov2_ktime_rec> ktime_recs;   // recorded (kernel id, event pair) since the last report
+    std::vector<hipEvent_t> ktime_free;      // recycled events
 };
 
 struct ov2_images {
@@ -79,6 +95,16 @@ ov2_status ov2_scratch(ov2_ctx *ctx, size_t bytes, void **out);
         if (e_ != hipSuccess)                                                                       \
             return ov2_set_err((ctx), OV2_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                                __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// bracket a launch with events when kernel timing is enabled
+void ov2_ktime_begin(ov2_ctx *c, int id);
+void ov2_ktime_end(ov2_ctx *c);
+#define OV2_LAUNCH(ctx, id, ...)            \
+    do {                                    \
+        if ((ctx)->ktime_on) ov2_ktime_begin((ctx), (id)); \
+        hipLaunchKernelGGL(__VA_ARGS__);    \
+        if ((ctx)->ktime_on) ov2_ktime_end((ctx)); \
     } while (0)
 
 static inline int ov2_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -382,14 +382,14 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
         }
         inv_tw = 1.0f / (float)tw;
         inv_th = 1.0f / (float)th;
-        hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, c->stream, im->base, im->w,
+        OV2_LAUNCH(c, OV2_K_CLAHE_LUT, clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, c->stream, im->base, im->w,
                            im->h, im->stride, im->bstride, tiles_x, tiles_y, tw, th, clip_limit, lut_scale, buf->lut);
     }
-    hipLaunchKernelGGL(level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, c->stream, im->base, im->w,
+    OV2_LAUNCH(c, OV2_K_LEVEL0, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, c->stream, im->base, im->w,
                        im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
     for (int l = 0; l < v.nlevels; ++l) {
         const ov2_level_desc &L = v.lv[l];
-        hipLaunchKernelGGL(level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
+        OV2_LAUNCH(c, OV2_K_LEVEL, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
                            0, c->stream, v, l, (l + 1 < v.nlevels) ? 1 : 0);
     }
     hipError_t e = hipGetLastError();

@@ -51,6 +51,18 @@ class Context:
         _check(self.h, self.lib.ov2_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
+    def kernel_timing(self, on):
+        _check(self.h, self.lib.ov2_ktime_enable(self.h, int(bool(on))))
+
+    def kernel_times(self):
+        """{kernel name: (total_ms, launches)} since the last call (synchronises)."""
+        names = (C.c_char_p * 48)()
+        tot = (C.c_double * 48)()
+        cnt = (C.c_longlong * 48)()
+        n = C.c_int()
+        _check(self.h, self.lib.ov2_ktime_report(self.h, 48, names, tot, cnt, C.byref(n)))
+        return {names[i].decode(): (tot[i], cnt[i]) for i in range(n.value)}
+
     # -- device arrays ------------------------------------------------------------------------------
     def alloc(self, nbytes):
         p = C.c_void_p()
