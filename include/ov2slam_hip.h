@@ -123,6 +123,93 @@ ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const o
                                       const int32_t *d_img_idx, float *d_out_xy, uint8_t *d_out_status,
                                       int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* 2n work words: [0,n) stage 1, [n,2n) stage 2; may be NULL */);
 
+/* ---- local bundle adjustment ------------------------------------------------------------------- */
+/* Flat, POD restatement of the ceres::Problem that Optimizer::localBA assembles (src/optimizer.cpp:76-392).
+ * The host adapter (ov2slam_amd/host/local_ba_adapter.*) fills it from Frame/MapPoint graphs and applies the
+ * result back with the semantics of src/optimizer.cpp:741-882.
+ * Parameter memory layout follows the reference PODs (include/ceres_parametrization/.../se3_param_block.hpp):
+ *   pose = Twc as [tx ty tz qx qy qz qw]  (Eigen quaternion coefficient order x,y,z,w)
+ *   landmark = world XYZ (inv_depth = 0) or inverse depth in its anchor keyframe (inv_depth = 1)
+ * Residual types = the cost functors of src/ceres_parametrization.cpp: */
+enum {
+    OV2_BA_L_XYZ = 0,      /* ReprojectionErrorKSE3XYZ               :107  {K_l, T_k, X}            */
+    OV2_BA_R_XYZ = 1,      /* ReprojectionErrorRightCamKSE3XYZ       :198  {K_r, T_k, T_rl, X}      */
+    OV2_BA_L_INV = 2,      /* ReprojectionErrorKSE3AnchInvDepth      :361  {K_l, T_anch, T_k, rho}  */
+    OV2_BA_R_INV = 3,      /* ReprojectionErrorRightCamKSE3AnchInvDepth :579 {K_l,K_r,T_anch,T_k,T_rl,rho} */
+    OV2_BA_RANCH_INV = 4   /* ReprojectionErrorRightAnchCamKSE3AnchInvDepth :476 {K_l,K_r,T_rl,rho} */
+};
+
+typedef struct ov2_ba_problem {
+    double calib_l[4], calib_r[4];   /* fx fy cx cy (constant blocks, src/optimizer.cpp:94-113) */
+    double T_rl[7];                  /* right<-left extrinsic, constant (:116-125) */
+    int32_t inv_depth;               /* buse_inv_depth */
+    int32_t n_pose;
+    double *pose;                    /* n_pose x 7, in/out */
+    const uint8_t *pose_const;       /* n_pose: 1 = SetParameterBlockConstant (:181-185, :229-246, :397-407) */
+    int32_t n_lm;
+    double *lm;                      /* n_lm x (inv_depth ? 1 : 3), in/out */
+    const int32_t *lm_anchor_pose;   /* n_lm, inv_depth only: pose index of the anchor keyframe (:258-267) */
+    const double *lm_anchor_uv;      /* n_lm x 2, inv_depth only: undistorted anchor pixel */
+    int32_t n_res;
+    const uint8_t *res_type;         /* n_res: OV2_BA_* */
+    const int32_t *res_pose;         /* n_res: observing keyframe (ignored for RANCH_INV) */
+    const int32_t *res_lm;           /* n_res */
+    const double *res_uv;            /* n_res x 2: unpx_ (left types) or runpx_ (right types) */
+    const double *res_sigma;         /* n_res: sqrt_info = I / sigma, sigma = 2^scale (NULL = all 1) */
+} ov2_ba_problem;
+
+typedef struct ov2_ba_options {
+    double huber_delta;      /* a of ceres::HuberLoss = sqrtf(robust_mono_th) (:49); <= 0 disables the loss */
+    double chi2_th;          /* robust_mono_th: residual flagged when chi2 > chi2_th or depth <= 0 (:500-592) */
+    int32_t max_iters;       /* 5  (:462) */
+    int32_t l2_refine;       /* apply_l2_after_robust: re-solve without the flagged residuals (:603-627) */
+    int32_t l2_max_iters;    /* 10 (:610) */
+    double function_tolerance;     /* 1e-3 (:463) */
+    /* ceres::Solver::Options defaults the reference leaves untouched (include/ceres/solver.h) */
+    double initial_radius;         /* 1e4  */
+    double max_radius;             /* 1e16 */
+    double min_radius;             /* 1e-32 */
+    double min_lm_diagonal;        /* 1e-6 */
+    double max_lm_diagonal;        /* 1e32 */
+    double min_relative_decrease;  /* 1e-3 */
+    double parameter_tolerance;    /* 1e-8 */
+    double gradient_tolerance;     /* 1e-10 */
+    int32_t jacobi_scaling;        /* 1 */
+    int32_t max_consecutive_invalid_steps; /* 5 */
+} ov2_ba_options;
+
+typedef struct ov2_ba_iter {
+    double cost, cost_change, radius, relative_decrease, model_cost_change;
+    int32_t step_is_valid, step_is_successful;
+} ov2_ba_iter;
+
+enum { OV2_BA_TERM_MAX_ITER = 0, OV2_BA_TERM_FTOL = 1, OV2_BA_TERM_PTOL = 2, OV2_BA_TERM_GTOL = 3,
+       OV2_BA_TERM_MIN_RADIUS = 4, OV2_BA_TERM_FAILURE = 5, OV2_BA_TERM_SKIPPED = 6 };
+
+#define OV2_BA_MAX_LOG 40
+typedef struct ov2_ba_result {
+    double *chi2;            /* n_res (caller allocated, may be NULL): ||r||^2 at the state the flag was taken */
+    uint8_t *depth_positive; /* n_res (may be NULL) */
+    uint8_t *outlier;        /* n_res (may be NULL): 0 kept, 1 flagged after the robust solve, 2 after the L2 re-solve */
+    double initial_cost, final_cost;   /* of the robust solve */
+    double l2_initial_cost, l2_final_cost;
+    int32_t n_log;           /* iteration log of both solves (robust first), iteration 0 included */
+    int32_t n_log_robust;
+    int32_t termination, l2_termination, l2_done;
+    int32_t n_outliers_pass1, n_outliers_pass2;
+    ov2_ba_iter log[OV2_BA_MAX_LOG];
+} ov2_ba_result;
+
+/* fills `o` with the values Optimizer::localBA uses (robust_mono_th from the YAML, default 5.9915) */
+void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th);
+
+/* Replaces the ceres::Solve + chi2 flagging + L2 re-solve of Optimizer::localBA(Frame&, bool)
+ * (include/optimizer.hpp:42, src/optimizer.cpp:439-735): Levenberg-Marquardt with Jacobi scaling, Huber loss via the
+ * Ceres corrector, landmark Schur complement, reduced camera system solved on device; time caps are not applied
+ * (the reference's 0.2 s wall-clock truncation makes it non-deterministic).
+ * p->pose / p->lm are HOST pointers, updated in place for the non-constant blocks. */
+ov2_status ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,103 @@ def klt_tracking_frame(prev, cur, kps_xy, prior_xy, has_prior, win=9, nlevels=3,
     lib().ov2o_klt_tracking_frame(prev._h, cur._h, win, nlevels, err_th, fb_th, max_iter, eps, n, _p(kps, f32p),
                                   _p(pri, f32p), _p(hp, u8p), _p(out, f32p), _p(st, u8p), C.byref(p3p))
     return out, st, bool(p3p.value)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BA half of the oracle
+
+class _ResEvalC(C.Structure):
+    _fields_ = [("r", C.c_double * 2), ("Jk", C.c_double * 12), ("Ja", C.c_double * 12), ("Jl", C.c_double * 6),
+                ("chi2", C.c_double), ("depth_positive", C.c_int)]
+
+
+class _BsProblemC(C.Structure):
+    _fields_ = [("R", C.c_int), ("E", C.c_int), ("F", C.c_int), ("maxf", C.c_int), ("n_rows", C.c_int),
+                ("n_e", C.c_int), ("n_f", C.c_int), ("row_e", i32p), ("row_f", i32p), ("Je", f64p), ("Jf", f64p),
+                ("b", f64p), ("D", f64p)]
+
+
+def _ba_lib():
+    L = lib()
+    if not getattr(L, "_ba_bound", False):
+        from ov2slam_amd import ba_types as T
+        L.ov2o_se3_exp.argtypes = [f64p, f64p]
+        L.ov2o_se3_plus.argtypes = [f64p, f64p, f64p]
+        L.ov2o_ba_eval_residual.argtypes = [C.POINTER(T.BaProblemC), f64p, f64p, C.c_int, C.c_int, C.POINTER(_ResEvalC)]
+        L.ov2o_huber.argtypes = [C.c_double, C.c_double, f64p]
+        L.ov2o_schur_solve.argtypes = [C.POINTER(_BsProblemC), f64p, f64p, f64p]
+        L.ov2o_schur_solve.restype = C.c_int
+        L.ov2o_ba_default_options.argtypes = [C.POINTER(T.BaOptionsC), C.c_float]
+        L.ov2o_ba_solve.argtypes = [C.POINTER(T.BaProblemC), C.POINTER(T.BaOptionsC), C.POINTER(T.BaResultC)]
+        L._ba_bound = True
+    return L
+
+
+def se3_exp(d):
+    d = np.ascontiguousarray(d, np.float64)
+    out = np.zeros(7)
+    _ba_lib().ov2o_se3_exp(_p(d, f64p), _p(out, f64p))
+    return out
+
+
+def se3_plus(x, d):
+    x, d = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(d, np.float64)
+    out = np.zeros(7)
+    _ba_lib().ov2o_se3_plus(_p(x, f64p), _p(d, f64p), _p(out, f64p))
+    return out
+
+
+def ba_eval_residual(prob, i, poses=None, lms=None, want_jac=True):
+    """returns dict(r, Jk(2,6), Ja(2,6), Jl(2,e), chi2, depth_positive) of residual i at (poses, lms)."""
+    L = _ba_lib()
+    poses = prob.pose if poses is None else np.ascontiguousarray(poses, np.float64)
+    lms = prob.lm if lms is None else np.ascontiguousarray(lms, np.float64)
+    pc = prob.as_c()
+    ev = _ResEvalC()
+    L.ov2o_ba_eval_residual(C.byref(pc), _p(poses, f64p), _p(lms, f64p), i, int(want_jac), C.byref(ev))
+    e = 1 if prob.inv_depth else 3
+    return dict(r=np.array(ev.r[:]), Jk=np.array(ev.Jk[:]).reshape(2, 6), Ja=np.array(ev.Ja[:]).reshape(2, 6),
+                Jl=np.array(ev.Jl[:2 * e]).reshape(2, e), chi2=ev.chi2, depth_positive=bool(ev.depth_positive))
+
+
+def huber(a, s):
+    rho = np.zeros(3)
+    _ba_lib().ov2o_huber(a, s, _p(rho, f64p))
+    return rho
+
+
+def schur_solve(R, E, F, row_e, row_f, Je, Jf, b, n_e, n_f, D=None):
+    """generic block-sparse Schur least squares; returns (rc, S, rhs, x)."""
+    L = _ba_lib()
+    row_e = np.ascontiguousarray(row_e, np.int32)
+    row_f = np.ascontiguousarray(row_f, np.int32)
+    maxf = row_f.shape[1]
+    Je, Jf, b = (np.ascontiguousarray(a, np.float64) for a in (Je, Jf, b))
+    p = _BsProblemC(R, E, F, maxf, len(row_e), n_e, n_f, _p(row_e, i32p), _p(row_f, i32p), _p(Je, f64p), _p(Jf, f64p),
+                    _p(b, f64p), None)
+    if D is not None:
+        D = np.ascontiguousarray(D, np.float64)
+        p.D = _p(D, f64p)
+    m = n_f * F
+    S, rhs, x = np.zeros((m, m)), np.zeros(m), np.zeros(n_e * E + m)
+    rc = L.ov2o_schur_solve(C.byref(p), _p(S, f64p), _p(rhs, f64p), _p(x, f64p))
+    return rc, S, rhs, x
+
+
+def ba_default_options(robust_mono_th=5.9915):
+    from ov2slam_amd import ba_types as T
+    o = T.BaOptionsC()
+    _ba_lib().ov2o_ba_default_options(C.byref(o), robust_mono_th)
+    return o
+
+
+def ba_solve(prob, options=None):
+    """Optimizer::localBA numerical core on a BaProblem (updated in place). returns BaResult."""
+    from ov2slam_amd import ba_types as T
+    L = _ba_lib()
+    o = options if options is not None else ba_default_options()
+    res = T.BaResult(prob.n_res)
+    pc = prob.as_c()
+    rc = L.ov2o_ba_solve(C.byref(pc), C.byref(o), C.byref(res.c))
+    assert rc == 0
+    return res
