@@ -48,6 +48,8 @@ SIGNATURES = {
                                        C.c_int, vp, vp, vp, vp, vp]),
     "ov2_klt_tracking_frame_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                              C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ov2_ba_default_options": (None, [vp, C.c_float]),
+    "ov2_ba_solve": (C.c_int, [vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -1,0 +1,1309 @@
+// ba.hip -- local bundle adjustment on gfx950: Levenberg-Marquardt + landmark Schur complement, all f64.
+//
+// Replaces (reference, /root/reference): the ceres::Solve + chi2 flagging + L2 re-solve inside
+// Optimizer::localBA src/optimizer.cpp:439-735, with the cost functors of src/ceres_parametrization.cpp:107-709
+// and the Ceres 2.0.0 trust-region/LM/Schur semantics restated in oracle/ov2_oracle_ba.c.
+// The host (this file, bottom) keeps Ceres' control flow -- radius update, accept/reject, tolerances -- and syncs
+// once per LM iteration on a handful of scalars; every O(residuals) / O(landmarks) / O(poses^3) step is a kernel.
+//
+// HBM layout (one workspace per solve, reused across calls through the ctx):
+//   rows (= residual blocks) sorted by (landmark, observing pose), SoA: type / pose / landmark / F-block ids /
+//   measurement; per row storage of the robustified, Jacobi-scaled jacobian: res[2], Je[2e], Jf[2 cells][2x6]
+//   landmark CSR row_ptr[n_e+1]; S (reduced camera system) dense column-major m x m (m = 6 * free poses), lower
+//   triangle authoritative; all reductions that decide accept/reject (cost, model change, norms) are two-stage and
+//   order-fixed => bitwise reproducible; S / rhs / pose column norms are accumulated with f64 atomics after a
+//   per-(landmark,pose) pre-aggregation in registers (order-dependent at the 1e-16 level only).
+//
+// Kernels:  ba_eval (residual + analytic jacobian + Huber corrector + Jacobi scaling)  -> rows
+//           ba_colnorm (per landmark: E column norms/gradient direct, F side aggregated + atomics)
+//           ba_schur (per landmark: E'E, inverse, rhs, F'F and (E'F)'(E'E)^-1(E'F) blocks -> S)
+//           ba_chol (one workgroup, left-looking blocked Cholesky in LDS, rhs carried as an extra row; back solve)
+//           ba_backsub (per landmark: y_e, then J*step and the model cost change)
+//           ba_plus (SE3 left update / additive), ba_flag (chi2 + depth flags), ba_reduce (ordered sums)
+// No MFMA: the dense contractions are 6x6 / 6x1 / 6x3 blocks (latency- and atomics-bound).
+#include "ov2_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace {
+
+enum { K_EVAL = OV2_K_BA_FIRST, K_COLNORM, K_SCALE, K_LMDIAG, K_SINIT, K_SCHUR, K_CHOL, K_BACKSUB, K_PLUS, K_FLAG,
+       K_REDUCE, K_MISC };
+
+struct ba_dev {
+    // problem constants
+    double Kl[4], Kr[4], Rrl[9], trl[3];
+    int e;               // landmark block size 1 | 3
+    int n_rows, n_e, n_f, n_pose, n_lm, m, nc;
+    // rows (sorted)
+    const unsigned char *type;
+    const int *pose, *lm, *anch;   // global pose / landmark / anchor-pose indices (anch = -1 for XYZ)
+    const int *eb, *fk, *fa;       // reduced-program block ids (fk/fa = -1: constant or absent)
+    const double *uv, *inv_sigma, *auv;  // measurement, 1/sigma, anchor pixel per ROW (copied for coalescing)
+    const int *row_ptr;            // n_e + 1
+    const int *lm_of_e, *pose_of_f;
+    // jacobian storage
+    double *res, *Je, *Jf;
+    // vectors over columns (E part first: n_e*e, then F part: n_f*6)
+    double *scale, *sqn, *grad, *diag, *lmd, *step;
+    double *S, *rhs, *iete, *ieg;
+    double *part;        // partial sums (max(n_rows blocks, n_e, n_f + n_e))
+    double *scal;        // scalar slots
+    int *flags;          // [0] cholesky failure
+};
+
+enum { SC_COST = 0, SC_CAND_COST, SC_MODEL, SC_STEP2, SC_XNORM2, SC_GMAX_LM, SC_N };
+
+// ------------------------------------------------------------------------------------------------------
+// SE3 helpers (same formulas as the oracle / Sophus / Eigen)
+
+__host__ __device__ inline void quat_to_R(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__host__ __device__ inline void pose_Rt(const double *p, double R[9], double t[3])
+{
+    double q[4] = {p[3], p[4], p[5], p[6]};
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    quat_to_R(q, R);
+    t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+}
+
+__device__ inline void se3_plus(const double *x, const double *d, double *out)
+{
+    // Sophus::SE3::exp(d) * SE3(q,t)   (se3left_parametrization.hpp:41-60)
+    const double *u = d, *w = d + 3;
+    const double eps = 1e-10;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double theta, imag, real;
+    if (th2 < eps * eps) {
+        theta = 0.0;
+        const double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        theta = sqrt(th2);
+        const double half = 0.5 * theta;
+        imag = sin(half) / theta;
+        real = cos(half);
+    }
+    const double a[4] = {imag * w[0], imag * w[1], imag * w[2], real};
+    double Ra[9], V[9];
+    quat_to_R(a, Ra);
+    if (theta < eps) {
+        for (int i = 0; i < 9; ++i) V[i] = Ra[i];
+    } else {
+        const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double O2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += O[3 * i + k] * O[3 * k + j];
+                O2[3 * i + j] = s;
+            }
+        const double t2 = theta * theta;
+        const double c1 = (1.0 - cos(theta)) / t2, c2 = (theta - sin(theta)) / (t2 * theta);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+    }
+    double b[4] = {x[3], x[4], x[5], x[6]};
+    const double nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
+    b[0] /= nb; b[1] /= nb; b[2] /= nb; b[3] /= nb;
+    double q[4];
+    q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int r = 0; r < 3; ++r)
+        out[r] = (V[3 * r] * u[0] + V[3 * r + 1] * u[1] + V[3 * r + 2] * u[2]) +
+                 (Ra[3 * r] * x[0] + Ra[3 * r + 1] * x[1] + Ra[3 * r + 2] * x[2]);
+    out[3] = q[0] / nq; out[4] = q[1] / nq; out[5] = q[2] / nq; out[6] = q[3] / nq;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// one residual block: r, local jacobians, chi2, depth sign  (src/ceres_parametrization.cpp, 5 functors)
+
+struct row_eval {
+    double r[2], Jk[12], Ja[12], Jl[6], chi2;
+    bool depth_pos;
+};
+
+template <bool JAC>
+__device__ inline void eval_row(const ba_dev &d, const double *__restrict__ poses, const double *__restrict__ lms,
+                                int row, row_eval &o)
+{
+    const int type = d.type[row], l = d.lm[row];
+    const double inv_sigma = d.inv_sigma[row];
+    const bool is_right = (type == OV2_BA_R_XYZ || type == OV2_BA_R_INV || type == OV2_BA_RANCH_INV);
+    const bool inv = (type >= OV2_BA_L_INV);
+    const double *K = is_right ? d.Kr : d.Kl;
+    double wpt[3] = {0, 0, 0}, anchpt[3] = {0, 0, 0}, Rwa[9], zanch = 0.0;
+    if (inv) {
+        zanch = 1.0 / lms[l];
+        anchpt[0] = zanch * ((d.auv[2 * row] - d.Kl[2]) / d.Kl[0]);
+        anchpt[1] = zanch * ((d.auv[2 * row + 1] - d.Kl[3]) / d.Kl[1]);
+        anchpt[2] = zanch;
+        if (type != OV2_BA_RANCH_INV) {
+            double twa[3];
+            pose_Rt(poses + 7 * d.anch[row], Rwa, twa);
+            for (int r = 0; r < 3; ++r)
+                wpt[r] = (Rwa[3 * r] * anchpt[0] + Rwa[3 * r + 1] * anchpt[1] + Rwa[3 * r + 2] * anchpt[2]) + twa[r];
+        }
+    } else {
+        wpt[0] = lms[3 * l]; wpt[1] = lms[3 * l + 1]; wpt[2] = lms[3 * l + 2];
+    }
+    double cam[3], M[9];
+    if (type == OV2_BA_RANCH_INV) {
+        for (int r = 0; r < 3; ++r)
+            cam[r] = (d.Rrl[3 * r] * anchpt[0] + d.Rrl[3 * r + 1] * anchpt[1] + d.Rrl[3 * r + 2] * anchpt[2]) + d.trl[r];
+        for (int i = 0; i < 9; ++i) M[i] = d.Rrl[i];
+    } else {
+        double Rwc[9], twc[3], lcam[3];
+        pose_Rt(poses + 7 * d.pose[row], Rwc, twc);
+        const double dd[3] = {wpt[0] - twc[0], wpt[1] - twc[1], wpt[2] - twc[2]};
+        for (int r = 0; r < 3; ++r) lcam[r] = Rwc[r] * dd[0] + Rwc[3 + r] * dd[1] + Rwc[6 + r] * dd[2];
+        if (is_right) {
+            for (int r = 0; r < 3; ++r)
+                cam[r] = (d.Rrl[3 * r] * lcam[0] + d.Rrl[3 * r + 1] * lcam[1] + d.Rrl[3 * r + 2] * lcam[2]) + d.trl[r];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    double s = 0;
+                    for (int k = 0; k < 3; ++k) s += d.Rrl[3 * r + k] * Rwc[3 * c + k];
+                    M[3 * r + c] = s;
+                }
+        } else {
+            cam[0] = lcam[0]; cam[1] = lcam[1]; cam[2] = lcam[2];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) M[3 * r + c] = Rwc[3 * c + r];
+        }
+    }
+    const double invz = 1.0 / cam[2];
+    o.r[0] = inv_sigma * ((K[0] * cam[0] * invz + K[2]) - d.uv[2 * row]);
+    o.r[1] = inv_sigma * ((K[1] * cam[1] * invz + K[3]) - d.uv[2 * row + 1]);
+    o.chi2 = o.r[0] * o.r[0] + o.r[1] * o.r[1];
+    o.depth_pos = cam[2] > 0.0;
+    if (!JAC) return;
+    const double invz2 = invz * invz;
+    const double Jc[6] = {invz * K[0], 0.0, -cam[0] * invz2 * K[0], 0.0, invz * K[1], -cam[1] * invz2 * K[1]};
+    double JR[6];
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c) JR[3 * r + c] = Jc[3 * r] * M[c] + Jc[3 * r + 1] * M[3 + c] + Jc[3 * r + 2] * M[6 + c];
+    for (int i = 0; i < 12; ++i) { o.Jk[i] = 0.0; o.Ja[i] = 0.0; }
+    for (int i = 0; i < 6; ++i) o.Jl[i] = 0.0;
+    if (type != OV2_BA_RANCH_INV) {
+        for (int r = 0; r < 2; ++r) {
+            const double a = JR[3 * r], b = JR[3 * r + 1], c = JR[3 * r + 2];
+            const double h0 = b * wpt[2] - c * wpt[1], h1 = c * wpt[0] - a * wpt[2], h2 = a * wpt[1] - b * wpt[0];
+            o.Jk[6 * r + 0] = -inv_sigma * a; o.Jk[6 * r + 1] = -inv_sigma * b; o.Jk[6 * r + 2] = -inv_sigma * c;
+            o.Jk[6 * r + 3] = inv_sigma * h0; o.Jk[6 * r + 4] = inv_sigma * h1; o.Jk[6 * r + 5] = inv_sigma * h2;
+            if (inv) {
+                o.Ja[6 * r + 0] = inv_sigma * a; o.Ja[6 * r + 1] = inv_sigma * b; o.Ja[6 * r + 2] = inv_sigma * c;
+                o.Ja[6 * r + 3] = -inv_sigma * h0; o.Ja[6 * r + 4] = -inv_sigma * h1; o.Ja[6 * r + 5] = -inv_sigma * h2;
+            }
+        }
+    }
+    if (inv) {
+        double jl[3];
+        if (type == OV2_BA_RANCH_INV) {
+            jl[0] = -zanch * anchpt[0]; jl[1] = -zanch * anchpt[1]; jl[2] = -zanch * anchpt[2];
+        } else {
+            for (int r = 0; r < 3; ++r)
+                jl[r] = -zanch * (Rwa[3 * r] * anchpt[0] + Rwa[3 * r + 1] * anchpt[1] + Rwa[3 * r + 2] * anchpt[2]);
+        }
+        for (int r = 0; r < 2; ++r) o.Jl[r] = inv_sigma * (JR[3 * r] * jl[0] + JR[3 * r + 1] * jl[1] + JR[3 * r + 2] * jl[2]);
+    } else {
+        for (int i = 0; i < 6; ++i) o.Jl[i] = inv_sigma * JR[i];
+    }
+}
+
+__device__ inline void huber(double a, double s, double rho[3])
+{
+    const double b = a * a;
+    if (s > b) {
+        const double r = sqrt(s);
+        rho[0] = 2.0 * a * r - b;
+        rho[1] = fmax(2.2250738585072014e-308, a / r);
+        rho[2] = -rho[1] / (2.0 * s);
+    } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+}
+
+// block-wide ordered sum of one double per thread (blockDim = 256) -> lane 0 of the block returns the total
+__device__ inline double block_sum_256(double v, double *sh)
+{
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_EVAL: residual (+ jacobian), loss, corrector, Jacobi scaling; cost partial per workgroup
+
+template <bool JAC>
+__global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
+                                                      const double *__restrict__ lms, int use_loss, double huber_a,
+                                                      int apply_scale, double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double c = 0.0;
+    if (row < d.n_rows) {
+        row_eval ev;
+        eval_row<JAC>(d, poses, lms, row, ev);
+        double rho[3] = {ev.chi2, 1.0, 0.0};
+        if (use_loss) huber(huber_a, ev.chi2, rho);
+        c = 0.5 * rho[0];
+        if (JAC) {
+            // Corrector (corrector.cc:42-157); for Huber rho'' <= 0 always -> plain sqrt(rho') scaling, the general
+            // branch is kept for completeness
+            const double sqrt_rho1 = sqrt(rho[1]);
+            double rs = sqrt_rho1, asn = 0.0;
+            if (use_loss && !(ev.chi2 == 0.0 || rho[2] <= 0.0)) {
+                const double D = 1.0 + 2.0 * ev.chi2 * rho[2] / rho[1];
+                const double alpha = 1.0 - sqrt(D);
+                rs = sqrt_rho1 / (1 - alpha);
+                asn = alpha / ev.chi2;
+            }
+            const int e = d.e;
+            if (use_loss) {
+                if (asn == 0.0) {
+                    for (int i = 0; i < 12; ++i) { ev.Jk[i] *= sqrt_rho1; ev.Ja[i] *= sqrt_rho1; }
+                    for (int i = 0; i < 2 * e; ++i) ev.Jl[i] *= sqrt_rho1;
+                } else {
+                    for (int cc = 0; cc < 6; ++cc) {
+                        double rtj = ev.Jk[cc] * ev.r[0] + ev.Jk[6 + cc] * ev.r[1];
+                        ev.Jk[cc] = sqrt_rho1 * (ev.Jk[cc] - asn * ev.r[0] * rtj);
+                        ev.Jk[6 + cc] = sqrt_rho1 * (ev.Jk[6 + cc] - asn * ev.r[1] * rtj);
+                        rtj = ev.Ja[cc] * ev.r[0] + ev.Ja[6 + cc] * ev.r[1];
+                        ev.Ja[cc] = sqrt_rho1 * (ev.Ja[cc] - asn * ev.r[0] * rtj);
+                        ev.Ja[6 + cc] = sqrt_rho1 * (ev.Ja[6 + cc] - asn * ev.r[1] * rtj);
+                    }
+                    for (int cc = 0; cc < e; ++cc) {
+                        const double rtj = ev.Jl[cc] * ev.r[0] + ev.Jl[e + cc] * ev.r[1];
+                        ev.Jl[cc] = sqrt_rho1 * (ev.Jl[cc] - asn * ev.r[0] * rtj);
+                        ev.Jl[e + cc] = sqrt_rho1 * (ev.Jl[e + cc] - asn * ev.r[1] * rtj);
+                    }
+                }
+                ev.r[0] *= rs; ev.r[1] *= rs;
+            }
+            d.res[2 * row] = ev.r[0];
+            d.res[2 * row + 1] = ev.r[1];
+            const int eb = d.eb[row], fk = d.fk[row], fa = d.fa[row];
+            const int ne = d.n_e * e;
+            for (int cc = 0; cc < e; ++cc) {
+                const double s = apply_scale ? d.scale[eb * e + cc] : 1.0;
+                d.Je[(size_t)row * 2 * e + cc] = ev.Jl[cc] * s;
+                d.Je[(size_t)row * 2 * e + e + cc] = ev.Jl[e + cc] * s;
+            }
+            double *Jf = d.Jf + (size_t)row * 24;
+            for (int cc = 0; cc < 6; ++cc) {
+                const double sk = (apply_scale && fk >= 0) ? d.scale[ne + fk * 6 + cc] : 1.0;
+                const double sa = (apply_scale && fa >= 0) ? d.scale[ne + fa * 6 + cc] : 1.0;
+                Jf[cc] = ev.Jk[cc] * sk; Jf[6 + cc] = ev.Jk[6 + cc] * sk;
+                Jf[12 + cc] = ev.Ja[cc] * sa; Jf[18 + cc] = ev.Ja[6 + cc] * sa;
+            }
+        }
+    }
+    const double tot = block_sum_256(c, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ordered sum of n doubles by ONE workgroup of 256 threads -> out[0] (sign * sum)
+__global__ __launch_bounds__(256) void ba_reduce_kernel(const double *__restrict__ in, int n, double *__restrict__ out,
+                                                        double sign)
+{
+    __shared__ double sh[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += in[i];
+    const double tot = block_sum_256(v, sh);
+    if (threadIdx.x == 0) out[0] = sign * tot;
+}
+
+__global__ __launch_bounds__(256) void ba_max_kernel(const double *__restrict__ in, int n, double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v = fmax(v, fabs(in[i]));
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_COLNORM: squared column norms and J'r.  One thread per landmark; F side aggregated over runs of equal pose.
+
+__device__ inline void flush_cols(double *sqn, double *grad, int base, const double *s, const double *g)
+{
+    for (int c = 0; c < 6; ++c) {
+        atomicAdd(&sqn[base + c], s[c]);
+        atomicAdd(&grad[base + c], g[c]);
+    }
+}
+
+__global__ __launch_bounds__(64) void ba_colnorm_kernel(ba_dev d)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.n_e) return;
+    const int e = d.e, ne = d.n_e * e;
+    double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
+    double sk[6], gk[6], sa[6] = {0, 0, 0, 0, 0, 0}, ga[6] = {0, 0, 0, 0, 0, 0};
+    int cur = -1, fa_seen = -1;
+    for (int c = 0; c < 6; ++c) { sk[c] = 0; gk[c] = 0; }
+    for (int r = d.row_ptr[l]; r < d.row_ptr[l + 1]; ++r) {
+        const double *Je = d.Je + (size_t)r * 2 * e, *Jf = d.Jf + (size_t)r * 24;
+        const double r0 = d.res[2 * r], r1 = d.res[2 * r + 1];
+        for (int c = 0; c < e; ++c) {
+            se[c] += Je[c] * Je[c] + Je[e + c] * Je[e + c];
+            ge[c] += Je[c] * r0 + Je[e + c] * r1;
+        }
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fk >= 0) {
+            if (fk != cur) {
+                if (cur >= 0) flush_cols(d.sqn, d.grad, ne + cur * 6, sk, gk);
+                for (int c = 0; c < 6; ++c) { sk[c] = 0; gk[c] = 0; }
+                cur = fk;
+            }
+            for (int c = 0; c < 6; ++c) {
+                sk[c] += Jf[c] * Jf[c] + Jf[6 + c] * Jf[6 + c];
+                gk[c] += Jf[c] * r0 + Jf[6 + c] * r1;
+            }
+        }
+        if (fa >= 0) {
+            fa_seen = fa;
+            for (int c = 0; c < 6; ++c) {
+                sa[c] += Jf[12 + c] * Jf[12 + c] + Jf[18 + c] * Jf[18 + c];
+                ga[c] += Jf[12 + c] * r0 + Jf[18 + c] * r1;
+            }
+        }
+    }
+    if (cur >= 0) flush_cols(d.sqn, d.grad, ne + cur * 6, sk, gk);
+    if (fa_seen >= 0) flush_cols(d.sqn, d.grad, ne + fa_seen * 6, sa, ga);
+    for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
+}
+
+// iteration 0: scale = 1/(1+sqrt(|col|^2)) (trust_region_minimizer.cc:261-276), keep the unscaled gradient
+__global__ void ba_make_scale_kernel(ba_dev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.nc) d.scale[i] = 1.0 / (1.0 + sqrt(d.sqn[i]));
+}
+
+__global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= d.n_rows) return;
+    const int e = d.e, ne = d.n_e * e, eb = d.eb[row], fk = d.fk[row], fa = d.fa[row];
+    for (int c = 0; c < e; ++c) {
+        const double s = d.scale[eb * e + c];
+        d.Je[(size_t)row * 2 * e + c] *= s;
+        d.Je[(size_t)row * 2 * e + e + c] *= s;
+    }
+    double *Jf = d.Jf + (size_t)row * 24;
+    if (fk >= 0) for (int c = 0; c < 6; ++c) { const double s = d.scale[ne + fk * 6 + c]; Jf[c] *= s; Jf[6 + c] *= s; }
+    if (fa >= 0) for (int c = 0; c < 6; ++c) { const double s = d.scale[ne + fa * 6 + c]; Jf[12 + c] *= s; Jf[18 + c] *= s; }
+}
+
+// LevenbergMarquardtStrategy::ComputeStep :76-89
+__global__ void ba_lmdiag_kernel(ba_dev d, int refresh_diag, double min_d, double max_d, double radius)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.nc) return;
+    if (refresh_diag) d.diag[i] = fmin(fmax(d.sqn[i], min_d), max_d);
+    d.lmd[i] = sqrt(d.diag[i] / radius);
+}
+
+// S = diag(D_f^2), rhs = 0
+__global__ void ba_sinit_kernel(ba_dev d)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t mm = (size_t)d.m * d.m;
+    if (i < mm) {
+        const int r = (int)(i % d.m), c = (int)(i / d.m);
+        const double dv = d.lmd[d.n_e * d.e + r];
+        d.S[i] = (r == c) ? dv * dv : 0.0;
+    }
+    if (i < (size_t)d.m) d.rhs[i] = 0.0;
+    if (i == 0) d.flags[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_SCHUR: SchurEliminator::Eliminate per landmark chunk (schur_eliminator_impl.h:179-308)
+
+// add a 6x6 block B[i*6+j] = d2/(p_i, q_j) into column-major S at block (fp, fq); only the lower triangle of S is
+// read by the factorisation, so off-diagonal blocks go to (max, min) with the matching transpose.
+__device__ inline void add_block(double *S, int m, int fp, int fq, const double *B, double sign)
+{
+    if (fp >= fq) {
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                if (fp == fq && i < j) continue;
+                atomicAdd(&S[(size_t)(fq * 6 + j) * m + fp * 6 + i], sign * B[i * 6 + j]);
+            }
+    } else {
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) atomicAdd(&S[(size_t)(fp * 6 + i) * m + fq * 6 + j], sign * B[i * 6 + j]);
+    }
+}
+
+#define BA_MAX_RUNS 40   // distinct free observing poses per landmark handled in registers/scratch per thread
+
+template <int E>
+__global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restrict__ Wbuf /* n_e x (RUNS+1) x 6E */,
+                                                      int *__restrict__ Wf /* n_e x (RUNS+1) */)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.n_e) return;
+    const int r0 = d.row_ptr[l], r1 = d.row_ptr[l + 1];
+    double ete[E * E], g[E];
+    for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
+    for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] = dv * dv; g[i] = 0.0; }
+    for (int r = r0; r < r1; ++r) {
+        const double *Je = d.Je + (size_t)r * 2 * E;
+        const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+        for (int i = 0; i < E; ++i) {
+            for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
+            g[i] += Je[i] * b0 + Je[E + i] * b1;
+        }
+    }
+    // inverse of the SPD E'E (closed form; invert_psd_matrix.h uses an LLT solve -- same matrix)
+    double ie[E * E], ieg[E];
+    if (E == 1) {
+        ie[0] = 1.0 / ete[0];
+    } else {
+        const double a = ete[0], b = ete[1], c = ete[2], dd = ete[4], ee = ete[5], f = ete[8];
+        const double A = dd * f - ee * ee, B = c * ee - b * f, C = b * ee - c * dd;
+        const double det = a * A + b * B + c * C;
+        const double id = 1.0 / det;
+        ie[0] = A * id; ie[1] = B * id; ie[2] = C * id;
+        ie[3] = B * id; ie[4] = (a * f - c * c) * id; ie[5] = (b * c - a * ee) * id;
+        ie[6] = C * id; ie[7] = ie[5]; ie[8] = (a * dd - b * b) * id;
+    }
+    for (int i = 0; i < E; ++i) {
+        double s = 0;
+        for (int j = 0; j < E; ++j) s += ie[i * E + j] * g[j];
+        ieg[i] = s;
+    }
+    for (int i = 0; i < E * E; ++i) d.iete[(size_t)l * E * E + i] = ie[i];
+    for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
+
+    // second pass: per (landmark, pose) run aggregation, then the outer products
+    double *W = Wbuf + (size_t)l * (BA_MAX_RUNS + 1) * 6 * E;
+    int *wf = Wf + (size_t)l * (BA_MAX_RUNS + 1);
+    int nruns = 0, cur = -1, fa_seen = -1;
+    double Wk[6 * E], vk[6], FkFk[36], FkFa[36];
+    double Wa[6 * E], va[6], FaFa[36];
+    for (int i = 0; i < 6 * E; ++i) { Wk[i] = 0; Wa[i] = 0; }
+    for (int i = 0; i < 6; ++i) { vk[i] = 0; va[i] = 0; }
+    for (int i = 0; i < 36; ++i) { FkFk[i] = 0; FkFa[i] = 0; FaFa[i] = 0; }
+    auto flush_run = [&](int f) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&d.rhs[f * 6 + i], vk[i]);
+        add_block(d.S, d.m, f, f, FkFk, 1.0);
+        if (fa_seen >= 0) add_block(d.S, d.m, f, fa_seen, FkFa, 1.0);
+        if (nruns < BA_MAX_RUNS) {
+            for (int i = 0; i < 6 * E; ++i) W[nruns * 6 * E + i] = Wk[i];
+            wf[nruns] = f;
+            ++nruns;
+        }
+        for (int i = 0; i < 6 * E; ++i) Wk[i] = 0;
+        for (int i = 0; i < 6; ++i) vk[i] = 0;
+        for (int i = 0; i < 36; ++i) { FkFk[i] = 0; FkFa[i] = 0; }
+    };
+    for (int r = r0; r < r1; ++r) {
+        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+        double sj[2] = {d.res[2 * r], d.res[2 * r + 1]};
+        for (int i = 0; i < E; ++i) { sj[0] -= Je[i] * ieg[i]; sj[1] -= Je[E + i] * ieg[i]; }
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fa >= 0) fa_seen = fa;
+        if (fk >= 0) {
+            if (fk != cur) {
+                if (cur >= 0) flush_run(cur);
+                cur = fk;
+            }
+            for (int i = 0; i < 6; ++i) {
+                for (int c = 0; c < E; ++c) Wk[i * E + c] += Jf[i] * Je[c] + Jf[6 + i] * Je[E + c];
+                vk[i] += Jf[i] * sj[0] + Jf[6 + i] * sj[1];
+                for (int j = 0; j < 6; ++j) FkFk[i * 6 + j] += Jf[i] * Jf[j] + Jf[6 + i] * Jf[6 + j];
+                if (fa >= 0)
+                    for (int j = 0; j < 6; ++j) FkFa[i * 6 + j] += Jf[i] * Jf[12 + j] + Jf[6 + i] * Jf[18 + j];
+            }
+        }
+        if (fa >= 0) {
+            for (int i = 0; i < 6; ++i) {
+                for (int c = 0; c < E; ++c) Wa[i * E + c] += Jf[12 + i] * Je[c] + Jf[18 + i] * Je[E + c];
+                va[i] += Jf[12 + i] * sj[0] + Jf[18 + i] * sj[1];
+                for (int j = 0; j < 6; ++j) FaFa[i * 6 + j] += Jf[12 + i] * Jf[12 + j] + Jf[18 + i] * Jf[18 + j];
+            }
+        }
+    }
+    if (cur >= 0) flush_run(cur);
+    if (fa_seen >= 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&d.rhs[fa_seen * 6 + i], va[i]);
+        add_block(d.S, d.m, fa_seen, fa_seen, FaFa, 1.0);
+        for (int i = 0; i < 6 * E; ++i) W[nruns * 6 * E + i] = Wa[i];
+        wf[nruns] = fa_seen;
+        ++nruns;
+    }
+    // S -= (E'F)' (E'E)^-1 (E'F) over all pairs of this landmark's pose blocks (ChunkOuterProduct)
+    for (int p = 0; p < nruns; ++p) {
+        double T[6 * E];  // W_p * ie  (6 x E)
+        for (int i = 0; i < 6; ++i)
+            for (int c = 0; c < E; ++c) {
+                double s = 0;
+                for (int k = 0; k < E; ++k) s += W[p * 6 * E + i * E + k] * ie[k * E + c];
+                T[i * E + c] = s;
+            }
+        for (int q = p; q < nruns; ++q) {
+            double B[36];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    double s = 0;
+                    for (int c = 0; c < E; ++c) s += T[i * E + c] * W[q * 6 * E + j * E + c];
+                    B[i * 6 + j] = s;
+                }
+            add_block(d.S, d.m, wf[p], wf[q], B, -1.0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_CHOL: dense Cholesky of the reduced camera system by one workgroup (schur_complement_solver.cc:217-229 does an
+// Eigen LLT; :319-355 a sparse one -- same factor).  Column-major, lower triangle.  Left-looking, panels of NB
+// columns held in LDS; the right-hand side rides along as row m, so the forward substitution is free; the backward
+// substitution is done panel by panel afterwards.  z (solution) overwrites rhs.
+
+template <int NB>
+__global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, double *__restrict__ rhs, int m,
+                                                       int *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // the only LDS object of this kernel
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int M1 = m + 1;               // augmented row count (row m = right-hand side)
+    constexpr int PS = NB + 1;          // panel row stride (bank spread)
+    constexpr int KC = 32, HALF = NB / 2;
+    double *P = lds;                    // panel: rows x NB
+    double *Lj = lds + (size_t)M1 * PS; // NB x KC chunk of the previous columns of rows j0..j0+nb
+    volatile int *failp = reinterpret_cast<volatile int *>(Lj + NB * KC);
+    if (tid == 0) *failp = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < m; j0 += NB) {
+        const int nb = min(NB, m - j0);
+        const int rows = M1 - j0;       // panel rows j0 .. m
+        for (int idx = tid; idx < rows * nb; idx += nth) {
+            const int c = idx / rows, i = idx - c * rows;
+            const int gi = j0 + i;
+            P[i * PS + c] = (gi < m) ? A[(size_t)(j0 + c) * m + gi] : rhs[j0 + c];
+        }
+        __syncthreads();
+        // P -= L[j0.., 0..j0) * L[j0..j0+nb, 0..j0)^T ; thread = (row, half of the panel columns)
+        const int groups = (rows * 2 <= nth) ? 2 : 1;
+        for (int k0 = 0; k0 < j0; k0 += KC) {
+            const int kc = min(KC, j0 - k0);
+            for (int idx = tid; idx < nb * kc; idx += nth) {
+                const int kk = idx / nb, c = idx - kk * nb;
+                Lj[c * KC + kk] = A[(size_t)(k0 + kk) * m + j0 + c];
+            }
+            __syncthreads();
+            for (int w = tid; w < rows * groups; w += nth) {
+                const int i = w % rows, g = w / rows;
+                const int gi = j0 + i;
+                for (int h = g; h < 2; h += groups) {
+                    const int c0 = h * HALF;
+                    double acc[HALF];
+#pragma unroll
+                    for (int c = 0; c < HALF; ++c) acc[c] = 0.0;
+                    for (int kk = 0; kk < kc; ++kk) {
+                        // row m (rhs) of previous columns lives in rhs[] after their panel was written back
+                        const double lik = (gi < m) ? A[(size_t)(k0 + kk) * m + gi] : rhs[k0 + kk];
+#pragma unroll
+                        for (int c = 0; c < HALF; ++c) acc[c] += lik * Lj[(c0 + c) * KC + kk];
+                    }
+#pragma unroll
+                    for (int c = 0; c < HALF; ++c)
+                        if (c0 + c < nb) P[i * PS + c0 + c] -= acc[c];
+                }
+            }
+            __syncthreads();
+        }
+        // factor the panel (right-looking inside the panel)
+        for (int c = 0; c < nb; ++c) {
+            const double dkk = P[c * PS + c];
+            if (!(dkk > 0.0) && tid == 0) *failp = 1;
+            __syncthreads();
+            if (*failp) break;
+            const double dsq = sqrt(dkk);
+            for (int i = tid; i < rows; i += nth) {
+                if (i == c) P[i * PS + c] = dsq;
+                else if (i > c) P[i * PS + c] /= dsq;
+            }
+            __syncthreads();
+            const int wc = nb - c - 1;
+            for (int idx = tid; idx < (rows - c - 1) * wc; idx += nth) {
+                const int i = c + 1 + idx / wc, c2 = c + 1 + idx % wc;
+                if (i >= c2) P[i * PS + c2] -= P[i * PS + c] * P[c2 * PS + c];
+            }
+            __syncthreads();
+        }
+        if (*failp) break;
+        for (int idx = tid; idx < rows * nb; idx += nth) {
+            const int c = idx / rows, i = idx - c * rows;
+            const int gi = j0 + i;
+            if (gi < m) { if (i >= c) A[(size_t)(j0 + c) * m + gi] = P[i * PS + c]; }
+            else rhs[j0 + c] = P[i * PS + c];   // y = L^-1 b rides along as row m
+        }
+        __syncthreads();
+    }
+    if (*failp) {
+        if (tid == 0) flags[0] = 1;
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // backward substitution L^T z = y by ONE wave (wave-synchronous, no workgroup barriers): z kept in LDS
+    if (tid < 64) {
+        volatile double *zb = lds;
+        for (int i = tid; i < m; i += 64) zb[i] = rhs[i];
+        for (int j = m - 1; j >= 0; --j) {
+            double s = 0.0;
+            for (int i = j + 1 + tid; i < m; i += 64) s += A[(size_t)j * m + i] * zb[i];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (tid == 0) zb[j] = (zb[j] - s) / A[(size_t)j * m + j];
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = tid; i < m; i += 64) rhs[i] = zb[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K_BACKSUB: y_e per landmark (schur_eliminator_impl.h:311-377), step = -[y; z], model cost change partials
+
+template <int E>
+__global__ __launch_bounds__(64) void ba_backsub_kernel(ba_dev d, double *__restrict__ part)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.n_e) return;
+    const int ne = d.n_e * E;
+    const int r0 = d.row_ptr[l], r1 = d.row_ptr[l + 1];
+    double acc[E];
+    for (int i = 0; i < E; ++i) acc[i] = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+        double sj[2] = {d.res[2 * r], d.res[2 * r + 1]};
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; sj[0] -= Jf[c] * z; sj[1] -= Jf[6 + c] * z; }
+        if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; sj[0] -= Jf[12 + c] * z; sj[1] -= Jf[18 + c] * z; }
+        for (int i = 0; i < E; ++i) acc[i] += Je[i] * sj[0] + Je[E + i] * sj[1];
+    }
+    double y[E];
+    for (int i = 0; i < E; ++i) {
+        double s = 0;
+        for (int j = 0; j < E; ++j) s += d.iete[(size_t)l * E * E + i * E + j] * acc[j];
+        y[i] = s;
+        d.step[l * E + i] = -s;
+    }
+    // model_cost_change = -sum m.(r + m/2), m = J step = -(E y + F z)
+    double mc = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+        double m0 = 0.0, m1 = 0.0;
+        for (int i = 0; i < E; ++i) { m0 -= Je[i] * y[i]; m1 -= Je[E + i] * y[i]; }
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; m0 -= Jf[c] * z; m1 -= Jf[6 + c] * z; }
+        if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; m0 -= Jf[12 + c] * z; m1 -= Jf[18 + c] * z; }
+        mc += m0 * (d.res[2 * r] + m0 / 2.0) + m1 * (d.res[2 * r + 1] + m1 / 2.0);
+    }
+    part[l] = mc;
+    (void)ne;
+}
+
+__global__ void ba_zstep_kernel(ba_dev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.m) d.step[d.n_e * d.e + i] = -d.rhs[i];
+}
+
+// K_PLUS: candidate = Plus(x, step .* scale); partials: |x - cand|^2 and |cand|^2 over the free blocks (global size)
+__global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__restrict__ xp, const double *__restrict__ xl,
+                                                     double *__restrict__ cp, double *__restrict__ cl,
+                                                     const double *__restrict__ delta_vec, int use_scale,
+                                                     double *__restrict__ part_step, double *__restrict__ part_norm)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int e = d.e, ne = d.n_e * e;
+    if (i < d.n_e) {
+        const int l = d.lm_of_e[i];
+        double s2 = 0, n2 = 0;
+        for (int c = 0; c < e; ++c) {
+            const double dl = delta_vec[i * e + c] * (use_scale ? d.scale[i * e + c] : 1.0);
+            const double v = xl[l * e + c] + dl;
+            cl[l * e + c] = v;
+            s2 += (xl[l * e + c] - v) * (xl[l * e + c] - v);
+            n2 += v * v;
+        }
+        part_step[i] = s2; part_norm[i] = n2;
+    } else if (i < d.n_e + d.n_f) {
+        const int f = i - d.n_e, p = d.pose_of_f[f];
+        double dl[6], out[7];
+        for (int c = 0; c < 6; ++c) dl[c] = delta_vec[ne + f * 6 + c] * (use_scale ? d.scale[ne + f * 6 + c] : 1.0);
+        se3_plus(xp + 7 * p, dl, out);
+        double s2 = 0, n2 = 0;
+        for (int c = 0; c < 7; ++c) {
+            s2 += (xp[7 * p + c] - out[c]) * (xp[7 * p + c] - out[c]);
+            n2 += out[c] * out[c];
+            cp[7 * p + c] = out[c];
+        }
+        part_step[i] = s2; part_norm[i] = n2;
+    }
+}
+
+// K_FLAG: chi2 / depth at the given state, in SORTED row order
+__global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__restrict__ poses,
+                                                      const double *__restrict__ lms, double *__restrict__ chi2,
+                                                      unsigned char *__restrict__ depth)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= d.n_rows) return;
+    row_eval ev;
+    eval_row<false>(d, poses, lms, row, ev);
+    chi2[row] = ev.chi2;
+    depth[row] = ev.depth_pos ? 1 : 0;
+}
+
+__global__ void ba_unscale_grad_kernel(ba_dev d, int scaled)
+{
+    // gradient of the UNSCALED problem (tolerance test only): g = g_scaled / scale
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.nc && scaled) d.grad[i] = d.grad[i] / d.scale[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+
+struct dev_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ba_workspace {
+    std::vector<dev_buf> bufs;
+    size_t next = 0;
+};
+
+template <typename T>
+ov2_status dalloc(ov2_ctx *c, std::vector<void *> &owned, T **out, size_t n)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA hipMalloc(%zu)", n * sizeof(T));
+    owned.push_back(p);
+    *out = (T *)p;
+    return OV2_OK;
+}
+
+template <typename T>
+ov2_status dupload(ov2_ctx *c, std::vector<void *> &owned, const T **out, const std::vector<T> &v)
+{
+    T *p = nullptr;
+    ov2_status s = dalloc(c, owned, &p, v.size());
+    if (s != OV2_OK) return s;
+    if (!v.empty()) OV2_HIP(c, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = p;
+    return OV2_OK;
+}
+
+struct ba_solver {
+    ov2_ctx *c;
+    const ov2_ba_problem *P;
+    const ov2_ba_options *o;
+    std::vector<void *> owned;
+    ba_dev d;
+    std::vector<int> order;      // sorted row -> original residual index
+    double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states
+    double *Wbuf = nullptr;
+    int *Wf = nullptr;
+    double *chi2_dev = nullptr;
+    unsigned char *depth_dev = nullptr;
+    int eval_blocks = 0;
+    std::vector<double> h_pose, h_lm;   // "parameters_": best state so far
+    std::vector<int> h_pose_of_f;
+
+    ~ba_solver()
+    {
+        for (void *p : owned) (void)hipFree(p);
+    }
+};
+
+#define BA_LAUNCH(S, id, ...) OV2_LAUNCH((S).c, id, __VA_ARGS__)
+
+ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
+{
+    ov2_ctx *c = S.c;
+    const ov2_ba_problem *P = S.P;
+    ba_dev &d = S.d;
+    memset(&d, 0, sizeof(d));
+    const int e = P->inv_depth ? 1 : 3;
+    d.e = e;
+    for (int i = 0; i < 4; ++i) { d.Kl[i] = P->calib_l[i]; d.Kr[i] = P->calib_r[i]; }
+    pose_Rt(P->T_rl, d.Rrl, d.trl);
+    // reduced program (program.cc RemoveFixedBlocks): unused / constant blocks leave
+    std::vector<int> eidx(P->n_lm, -1), fidx(P->n_pose, -1), rows;
+    for (int i = 0; i < P->n_res; ++i) {
+        if (!active[i]) continue;
+        const int t = P->res_type[i], l = P->res_lm[i];
+        if (l < 0 || l >= P->n_lm) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: landmark %d out of range", i, l);
+        if (t > OV2_BA_RANCH_INV) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: unknown type %d", i, t);
+        if ((t >= OV2_BA_L_INV) != (P->inv_depth != 0))
+            return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: type %d does not match inv_depth=%d", i, t, P->inv_depth);
+        if (t != OV2_BA_RANCH_INV && (P->res_pose[i] < 0 || P->res_pose[i] >= P->n_pose))
+            return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: pose out of range", i);
+        if (P->inv_depth && (P->lm_anchor_pose[l] < 0 || P->lm_anchor_pose[l] >= P->n_pose))
+            return ov2_set_err(c, OV2_ERR_INVALID, "landmark %d: anchor pose out of range", l);
+        rows.push_back(i);
+        eidx[l] = 0;
+        if (t != OV2_BA_RANCH_INV && !P->pose_const[P->res_pose[i]]) fidx[P->res_pose[i]] = 0;
+        if ((t == OV2_BA_L_INV || t == OV2_BA_R_INV) && !P->pose_const[P->lm_anchor_pose[l]]) fidx[P->lm_anchor_pose[l]] = 0;
+    }
+    std::vector<int> lm_of_e, pose_of_f;
+    for (int l = 0; l < P->n_lm; ++l) if (eidx[l] == 0) { eidx[l] = (int)lm_of_e.size(); lm_of_e.push_back(l); }
+    for (int p = 0; p < P->n_pose; ++p) if (fidx[p] == 0) { fidx[p] = (int)pose_of_f.size(); pose_of_f.push_back(p); }
+    d.n_e = (int)lm_of_e.size(); d.n_f = (int)pose_of_f.size();
+    S.h_pose_of_f = pose_of_f;
+    d.n_rows = (int)rows.size(); d.n_pose = P->n_pose; d.n_lm = P->n_lm;
+    d.m = 6 * d.n_f; d.nc = d.n_e * e + d.m;
+    // rows sorted by (landmark block, observing pose) -- LexicographicallyOrderResidualBlocks + run aggregation
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) {
+        const int ea = eidx[P->res_lm[a]], eb = eidx[P->res_lm[b]];
+        if (ea != eb) return ea < eb;
+        const int fa = (P->res_type[a] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[a]];
+        const int fb = (P->res_type[b] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[b]];
+        return fa < fb;
+    });
+    S.order = rows;
+    const int n = d.n_rows;
+    std::vector<unsigned char> type(n);
+    std::vector<int> pose(n), lm(n), anch(n), eb(n), fk(n), fa(n), row_ptr(d.n_e + 1, 0);
+    std::vector<double> uv(2 * (size_t)n), isg(n), auv(2 * (size_t)n, 0.0);
+    int max_runs = 0;
+    for (int r = 0; r < n; ++r) {
+        const int i = rows[r], t = P->res_type[i], l = P->res_lm[i];
+        type[r] = (unsigned char)t;
+        pose[r] = (t == OV2_BA_RANCH_INV) ? 0 : P->res_pose[i];
+        lm[r] = l;
+        anch[r] = P->inv_depth ? P->lm_anchor_pose[l] : -1;
+        eb[r] = eidx[l];
+        fk[r] = (t == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[i]];
+        fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[P->lm_anchor_pose[l]] : -1;
+        uv[2 * r] = P->res_uv[2 * i]; uv[2 * r + 1] = P->res_uv[2 * i + 1];
+        isg[r] = 1.0 / (P->res_sigma ? P->res_sigma[i] : 1.0);
+        if (P->inv_depth) { auv[2 * r] = P->lm_anchor_uv[2 * l]; auv[2 * r + 1] = P->lm_anchor_uv[2 * l + 1]; }
+        row_ptr[eb[r] + 1]++;
+    }
+    for (int k = 0; k < d.n_e; ++k) row_ptr[k + 1] += row_ptr[k];
+    for (int k = 0; k < d.n_e; ++k) {
+        int runs = 0, cur = -2;
+        for (int r = row_ptr[k]; r < row_ptr[k + 1]; ++r)
+            if (fk[r] >= 0 && fk[r] != cur) { cur = fk[r]; ++runs; }
+        max_runs = std::max(max_runs, runs);
+    }
+    if (max_runs > BA_MAX_RUNS)
+        return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "a landmark is observed by %d free keyframes (max %d)", max_runs, BA_MAX_RUNS);
+    ov2_status s;
+#define UP(field, vec) if ((s = dupload(c, S.owned, &d.field, vec)) != OV2_OK) return s
+    UP(type, type); UP(pose, pose); UP(lm, lm); UP(anch, anch); UP(eb, eb); UP(fk, fk); UP(fa, fa);
+    UP(uv, uv); UP(inv_sigma, isg); UP(auv, auv); UP(row_ptr, row_ptr); UP(lm_of_e, lm_of_e); UP(pose_of_f, pose_of_f);
+#undef UP
+#define AL(field, count) if ((s = dalloc(c, S.owned, &d.field, (size_t)(count))) != OV2_OK) return s
+    AL(res, 2 * (size_t)n); AL(Je, 2 * (size_t)e * n); AL(Jf, 24 * (size_t)n);
+    AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
+    AL(S, (size_t)d.m * d.m); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
+    S.eval_blocks = (n + 255) / 256;
+    AL(part, std::max<size_t>({(size_t)S.eval_blocks, (size_t)d.n_e + d.n_f, 1}) * 2 + 16);
+    AL(scal, SC_N + 2); AL(flags, 4);
+#undef AL
+    if ((s = dalloc(c, S.owned, &S.Wbuf, (size_t)d.n_e * (BA_MAX_RUNS + 1) * 6 * e)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.Wf, (size_t)d.n_e * (BA_MAX_RUNS + 1))) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.chi2_dev, (size_t)n)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.depth_dev, (size_t)n)) != OV2_OK) return s;
+    const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * e;
+    if ((s = dalloc(c, S.owned, &S.xp, np)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.cp, np)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.xl, nl)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.owned, &S.cl, nl)) != OV2_OK) return s;
+    return OV2_OK;
+}
+
+ov2_status get_scalars(ba_solver &S, double *h, int n)
+{
+    OV2_HIP(S.c, hipMemcpyAsync(h, S.d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, S.c->stream));
+    OV2_HIP(S.c, hipStreamSynchronize(S.c->stream));
+    return OV2_OK;
+}
+
+// EvaluateGradientAndJacobian at the current x (xp/xl): cost -> scal[SC_COST]; jacobian rows; sqn/grad
+ov2_status eval_jacobian(ba_solver &S, int use_loss, bool first)
+{
+    ov2_ctx *c = S.c;
+    ba_dev &d = S.d;
+    hipStream_t st = c->stream;
+    BA_LAUNCH(S, K_EVAL, ba_eval_kernel<true>, dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
+              S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
+    BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_COST, 1.0);
+    OV2_HIP(c, hipMemsetAsync(d.sqn, 0, sizeof(double) * d.nc, st));
+    OV2_HIP(c, hipMemsetAsync(d.grad, 0, sizeof(double) * d.nc, st));
+    BA_LAUNCH(S, K_COLNORM, ba_colnorm_kernel, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d);
+    if (first) {
+        if (S.o->jacobi_scaling) {
+            BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
+            BA_LAUNCH(S, K_SCALE, ba_scale_rows_kernel, dim3(S.eval_blocks), dim3(256), 0, st, d);
+            // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute
+            // norms on it; its gradient is the scaled one, unscale it for the tolerance test
+            OV2_HIP(c, hipMemsetAsync(d.sqn, 0, sizeof(double) * d.nc, st));
+            OV2_HIP(c, hipMemsetAsync(d.grad, 0, sizeof(double) * d.nc, st));
+            BA_LAUNCH(S, K_COLNORM, ba_colnorm_kernel, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d);
+            BA_LAUNCH(S, K_MISC, ba_unscale_grad_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, 1);
+            BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+        } else {
+            std::vector<double> ones(d.nc, 1.0);
+            OV2_HIP(c, hipMemcpyAsync(d.scale, ones.data(), sizeof(double) * d.nc, hipMemcpyHostToDevice, st));
+            OV2_HIP(c, hipStreamSynchronize(st));
+            BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+        }
+    } else {
+        // grad currently = scaled gradient; the tolerance test wants the unscaled one over the landmark block
+        BA_LAUNCH(S, K_MISC, ba_unscale_grad_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, S.o->jacobi_scaling);
+        BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+    }
+    OV2_HIP(c, hipGetLastError());
+    return OV2_OK;
+}
+
+void host_se3_plus(const double *x, const double *dlt, double *out);  // defined below (mirror of the device code)
+
+void log_iter(ov2_ba_result *R, double cost, double change, double radius, double rel, double model, int valid, int ok)
+{
+    if (!R || R->n_log >= OV2_BA_MAX_LOG) return;
+    ov2_ba_iter *it = &R->log[R->n_log++];
+    it->cost = cost; it->cost_change = change; it->radius = radius; it->relative_decrease = rel;
+    it->model_cost_change = model; it->step_is_valid = valid; it->step_is_successful = ok;
+}
+
+// TrustRegionMinimizer::Minimize on the device program; h_pose/h_lm hold "parameters_" (best state) on return
+ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_loss, int max_iters, ov2_ba_result *R,
+                    double *initial_cost, double *final_cost, int *termination)
+{
+    ov2_ctx *c = S.c;
+    const ov2_ba_options *o = S.o;
+    ov2_status s = build_program(S, active);
+    if (s != OV2_OK) return s;
+    ba_dev &d = S.d;
+    hipStream_t st = c->stream;
+    *termination = OV2_BA_TERM_MAX_ITER;
+    if (d.n_rows == 0 || d.nc == 0) {
+        *initial_cost = *final_cost = 0.0;
+        *termination = OV2_BA_TERM_SKIPPED;
+        return OV2_OK;
+    }
+    const int e = d.e;
+    const size_t np = (size_t)S.P->n_pose * 7, nl = (size_t)S.P->n_lm * e;
+    OV2_HIP(c, hipMemcpyAsync(S.xp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+    OV2_HIP(c, hipMemcpyAsync(S.xl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
+    OV2_HIP(c, hipMemcpyAsync(S.cp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+    OV2_HIP(c, hipMemcpyAsync(S.cl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
+
+    double sc[SC_N];
+    // IterationZero
+    if ((s = eval_jacobian(S, use_loss, true)) != OV2_OK) return s;
+    if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+    double x_cost = sc[SC_COST];
+    // gradient max norm: landmarks from the device, poses via Plus on the host (n_f is small)
+    auto grad_max = [&](double lm_part, double *out) -> ov2_status {
+        std::vector<double> g(d.m), xp(np);
+        double gm = lm_part;
+        if (d.m > 0) {
+            OV2_HIP(c, hipMemcpyAsync(g.data(), d.grad + d.n_e * e, sizeof(double) * d.m, hipMemcpyDeviceToHost, st));
+            OV2_HIP(c, hipMemcpyAsync(xp.data(), S.xp, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+            OV2_HIP(c, hipStreamSynchronize(st));
+            const std::vector<int> &pf = S.h_pose_of_f;
+            for (int f = 0; f < d.n_f; ++f) {
+                double dl[6], out7[7];
+                for (int k = 0; k < 6; ++k) dl[k] = -g[f * 6 + k];
+                host_se3_plus(&xp[7 * pf[f]], dl, out7);
+                for (int k = 0; k < 7; ++k) gm = std::max(gm, std::fabs(xp[7 * pf[f] + k] - out7[k]));
+            }
+        }
+        *out = gm;
+        return OV2_OK;
+    };
+    double gmax = 0.0;
+    if ((s = grad_max(sc[SC_GMAX_LM], &gmax)) != OV2_OK) return s;
+    *initial_cost = x_cost;
+    double minimum_cost = x_cost;
+    double x_norm = -1.0, radius = o->initial_radius, decrease_factor = 2.0;
+    int reuse_diagonal = 0, invalid_steps = 0, iteration = 0, last_ok = 1;
+    log_iter(R, x_cost, 0.0, radius, 0.0, 0.0, 1, 1);
+
+    for (;;) {
+        if (iteration >= max_iters) { *termination = OV2_BA_TERM_MAX_ITER; break; }
+        if (last_ok && gmax <= o->gradient_tolerance) { *termination = OV2_BA_TERM_GTOL; break; }
+        if (radius <= o->min_radius) { *termination = OV2_BA_TERM_MIN_RADIUS; break; }
+        ++iteration;
+        // ---- ComputeTrustRegionStep + candidate evaluation, all enqueued, one sync
+        BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, reuse_diagonal ? 0 : 1,
+                  o->min_lm_diagonal, o->max_lm_diagonal, radius);
+        reuse_diagonal = 1;
+        if (d.m > 0) {
+            const size_t mm = (size_t)d.m * d.m;
+            BA_LAUNCH(S, K_SINIT, ba_sinit_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, d);
+        } else {
+            OV2_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int), st));
+        }
+        if (e == 1) BA_LAUNCH(S, K_SCHUR, ba_schur_kernel<1>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, S.Wbuf, S.Wf);
+        else BA_LAUNCH(S, K_SCHUR, ba_schur_kernel<3>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, S.Wbuf, S.Wf);
+        if (d.m > 0) {
+            // panel width by LDS budget: (m+1) x (NB+1) + NB x 32 doubles <= 150 KiB
+            const size_t lds32 = ((size_t)(d.m + 1) * 33 + 32 * 32 + 2) * 8, lds16 = ((size_t)(d.m + 1) * 17 + 16 * 32 + 2) * 8,
+                         lds8 = ((size_t)(d.m + 1) * 9 + 8 * 32 + 2) * 8;
+            if (lds32 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(1024), lds32, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds16 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(1024), lds16, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds8 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(1024), lds8, st, d.S, d.rhs, d.m, d.flags);
+            else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", d.m);
+            BA_LAUNCH(S, K_MISC, ba_zstep_kernel, dim3((d.m + 255) / 256), dim3(256), 0, st, d);
+        }
+        if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub_kernel<1>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, d.part);
+        else BA_LAUNCH(S, K_BACKSUB, ba_backsub_kernel<3>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, d.part);
+        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, d.n_e, d.scal + SC_MODEL, -1.0);
+        const int nb = d.n_e + d.n_f;
+        double *part_step = d.part, *part_norm = d.part + nb;
+        BA_LAUNCH(S, K_PLUS, ba_plus_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, d, S.xp, S.xl, S.cp, S.cl, d.step,
+                  o->jacobi_scaling ? 1 : 0, part_step, part_norm);
+        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_step, nb, d.scal + SC_STEP2, 1.0);
+        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_norm, nb, d.scal + SC_XNORM2, 1.0);
+        BA_LAUNCH(S, K_EVAL, ba_eval_kernel<false>, dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
+                  o->huber_delta, 0, d.part);
+        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_CAND_COST, 1.0);
+        int h_flags[1];
+        OV2_HIP(c, hipMemcpyAsync(h_flags, d.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+        const double model_change = sc[SC_MODEL], cand_cost = sc[SC_CAND_COST];
+        const bool finite = !h_flags[0] && std::isfinite(model_change) && std::isfinite(sc[SC_STEP2]);
+        const bool valid = finite && model_change > 0.0;
+        if (!valid) {   // HandleInvalidStep
+            if (++invalid_steps >= o->max_consecutive_invalid_steps) { *termination = OV2_BA_TERM_FAILURE; break; }
+            radius /= decrease_factor; decrease_factor *= 2.0;
+            last_ok = 0;
+            log_iter(R, x_cost, 0.0, radius, 0.0, model_change, 0, 0);
+            continue;
+        }
+        invalid_steps = 0;
+        const double step_norm = std::sqrt(sc[SC_STEP2]);
+        if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { *termination = OV2_BA_TERM_PTOL; break; }
+        const double cost_change = x_cost - cand_cost;
+        if (std::fabs(cost_change) <= o->function_tolerance * x_cost) {
+            *termination = OV2_BA_TERM_FTOL;
+            log_iter(R, x_cost, cost_change, radius, 0.0, model_change, 1, 0);
+            break;
+        }
+        const double rel = std::isfinite(cand_cost) ? (x_cost - cand_cost) / model_change : -1e300;
+        if (rel > o->min_relative_decrease) {   // HandleSuccessfulStep
+            std::swap(S.xp, S.cp);
+            std::swap(S.xl, S.cl);
+            // keep the constant / unused blocks of the new candidate buffer in sync for the next Plus
+            OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, np * sizeof(double), hipMemcpyDeviceToDevice, st));
+            OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, nl * sizeof(double), hipMemcpyDeviceToDevice, st));
+            x_norm = std::sqrt(sc[SC_XNORM2]);
+            if ((s = eval_jacobian(S, use_loss, false)) != OV2_OK) return s;
+            if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+            x_cost = sc[SC_COST];
+            if ((s = grad_max(sc[SC_GMAX_LM], &gmax)) != OV2_OK) return s;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+            radius = std::min(o->max_radius, radius);
+            decrease_factor = 2.0;
+            reuse_diagonal = 0;
+            last_ok = 1;
+            if (x_cost < minimum_cost) {
+                minimum_cost = x_cost;
+                OV2_HIP(c, hipMemcpyAsync(S.h_pose.data(), S.xp, np * sizeof(double), hipMemcpyDeviceToHost, st));
+                OV2_HIP(c, hipMemcpyAsync(S.h_lm.data(), S.xl, nl * sizeof(double), hipMemcpyDeviceToHost, st));
+                OV2_HIP(c, hipStreamSynchronize(st));
+            }
+            log_iter(R, x_cost, cost_change, radius, rel, model_change, 1, 1);
+        } else {                                // StepRejected
+            radius = radius / decrease_factor; decrease_factor *= 2.0;
+            last_ok = 0;
+            log_iter(R, cand_cost, cost_change, radius, rel, model_change, 1, 0);
+        }
+    }
+    *final_cost = minimum_cost;
+    return OV2_OK;
+}
+
+void host_se3_plus(const double *x, const double *d, double *out)
+{
+    const double *u = d, *w = d + 3;
+    const double eps = 1e-10;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double theta, imag, real;
+    if (th2 < eps * eps) {
+        theta = 0.0;
+        const double th4 = th2 * th2;
+        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+    } else {
+        theta = std::sqrt(th2);
+        imag = std::sin(0.5 * theta) / theta;
+        real = std::cos(0.5 * theta);
+    }
+    const double a[4] = {imag * w[0], imag * w[1], imag * w[2], real};
+    double Ra[9], V[9];
+    quat_to_R(a, Ra);
+    if (theta < eps) {
+        for (int i = 0; i < 9; ++i) V[i] = Ra[i];
+    } else {
+        const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double O2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += O[3 * i + k] * O[3 * k + j];
+                O2[3 * i + j] = s;
+            }
+        const double t2 = theta * theta;
+        const double c1 = (1.0 - std::cos(theta)) / t2, c2 = (theta - std::sin(theta)) / (t2 * theta);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+    }
+    double b[4] = {x[3], x[4], x[5], x[6]};
+    const double nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
+    for (int i = 0; i < 4; ++i) b[i] /= nb;
+    double q[4];
+    q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int r = 0; r < 3; ++r)
+        out[r] = (V[3 * r] * u[0] + V[3 * r + 1] * u[1] + V[3 * r + 2] * u[2]) +
+                 (Ra[3 * r] * x[0] + Ra[3 * r + 1] * x[1] + Ra[3 * r + 2] * x[2]);
+    for (int i = 0; i < 4; ++i) out[3 + i] = q[i] / nq;
+}
+
+// chi2 / depth flags at the final state (src/optimizer.cpp:500-592, 637-735)
+ov2_status flag_outliers(ba_solver &S, std::vector<uint8_t> &active, ov2_ba_result *R, int pass, int *nbad, int *n_left,
+                         int *n_right)
+{
+    ov2_ctx *c = S.c;
+    const ov2_ba_problem *P = S.P;
+    *nbad = *n_left = *n_right = 0;
+    // program over the currently active rows (the previous minimize() left its program in S; rebuild for clarity)
+    for (void *p : S.owned) (void)hipFree(p);
+    S.owned.clear();
+    ov2_status s = build_program(S, active);
+    if (s != OV2_OK) return s;
+    ba_dev &d = S.d;
+    if (d.n_rows == 0) return OV2_OK;
+    hipStream_t st = c->stream;
+    const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * d.e;
+    OV2_HIP(c, hipMemcpyAsync(S.xp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
+    OV2_HIP(c, hipMemcpyAsync(S.xl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
+    BA_LAUNCH(S, K_FLAG, ba_flag_kernel, dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, S.chi2_dev, S.depth_dev);
+    std::vector<double> chi2(d.n_rows);
+    std::vector<unsigned char> depth(d.n_rows);
+    OV2_HIP(c, hipMemcpyAsync(chi2.data(), S.chi2_dev, sizeof(double) * d.n_rows, hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipMemcpyAsync(depth.data(), S.depth_dev, d.n_rows, hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipStreamSynchronize(st));
+    for (int r = 0; r < d.n_rows; ++r) {
+        const int i = S.order[r];
+        if (R->chi2) R->chi2[i] = chi2[r];
+        if (R->depth_positive) R->depth_positive[i] = depth[r];
+        if (chi2[r] > S.o->chi2_th || !depth[r]) {
+            active[i] = 0;
+            if (R->outlier) R->outlier[i] = (uint8_t)pass;
+            ++*nbad;
+        } else {
+            const int t = P->res_type[i];
+            if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) ++*n_left;
+            else if (t == OV2_BA_R_XYZ || t == OV2_BA_R_INV) ++*n_right;
+        }
+    }
+    return OV2_OK;
+}
+
+}  // namespace
+
+extern "C" void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->huber_delta = (double)sqrtf(robust_mono_th);  // HuberLoss(std::sqrt(mono_th)), float (src/optimizer.cpp:48-49)
+    o->chi2_th = (double)robust_mono_th;
+    o->max_iters = 5;
+    o->l2_refine = 1;
+    o->l2_max_iters = 10;
+    o->function_tolerance = 1e-3;
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32;
+    o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->min_relative_decrease = 1e-3; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
+    o->jacobi_scaling = 1;
+    o->max_consecutive_invalid_steps = 5;
+}
+
+extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (!P || !o || !R) return ov2_set_err(c, OV2_ERR_INVALID, "null problem/options/result");
+    if (P->n_pose < 0 || P->n_lm < 0 || P->n_res < 0 || (P->n_pose && (!P->pose || !P->pose_const)) ||
+        (P->n_lm && !P->lm) || (P->n_res && (!P->res_type || !P->res_pose || !P->res_lm || !P->res_uv)) ||
+        (P->inv_depth && P->n_lm && (!P->lm_anchor_pose || !P->lm_anchor_uv)))
+        return ov2_set_err(c, OV2_ERR_INVALID, "inconsistent ov2_ba_problem");
+    OV2_HIP(c, hipSetDevice(c->device));
+    R->n_log = 0; R->n_log_robust = 0; R->l2_done = 0; R->n_outliers_pass1 = R->n_outliers_pass2 = 0;
+    R->initial_cost = R->final_cost = R->l2_initial_cost = R->l2_final_cost = 0.0;
+    R->termination = R->l2_termination = OV2_BA_TERM_SKIPPED;
+    if (R->outlier) memset(R->outlier, 0, (size_t)P->n_res);
+    const int e = P->inv_depth ? 1 : 3;
+    ba_solver S;
+    S.c = c; S.P = P; S.o = o;
+    S.h_pose.assign(P->pose, P->pose + (size_t)P->n_pose * 7);
+    S.h_lm.assign(P->lm, P->lm + (size_t)P->n_lm * e);
+    std::vector<uint8_t> active(P->n_res, 1);
+    const int use_loss = o->huber_delta > 0.0;
+    ov2_status s = minimize(S, active, use_loss, o->max_iters, R, &R->initial_cost, &R->final_cost, &R->termination);
+    if (s != OV2_OK) return s;
+    R->n_log_robust = R->n_log;
+    int nbad, nl, nr;
+    if ((s = flag_outliers(S, active, R, 1, &nbad, &nl, &nr)) != OV2_OK) return s;
+    R->n_outliers_pass1 = nbad;
+    if (o->l2_refine && use_loss && nbad > 0) {
+        const int keep_loss = !(nl > 0 && nr > 0);   // src/optimizer.cpp:606-608
+        for (void *p : S.owned) (void)hipFree(p);
+        S.owned.clear();
+        s = minimize(S, active, keep_loss, o->l2_max_iters, R, &R->l2_initial_cost, &R->l2_final_cost, &R->l2_termination);
+        if (s != OV2_OK) return s;
+        R->l2_done = 1;
+        if ((s = flag_outliers(S, active, R, 2, &nbad, &nl, &nr)) != OV2_OK) return s;
+        R->n_outliers_pass2 = nbad;
+    }
+    // write back the non-constant blocks ("parameters_")
+    memcpy(P->pose, S.h_pose.data(), sizeof(double) * (size_t)P->n_pose * 7);
+    memcpy(P->lm, S.h_lm.data(), sizeof(double) * (size_t)P->n_lm * e);
+    return OV2_OK;
+}

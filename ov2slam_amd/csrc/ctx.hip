@@ -186,7 +186,10 @@ extern "C" void ov2_images_destroy(ov2_images *im)
 // ---- per-kernel event timing ------------------------------------------------------------------------
 
 const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", "level_kernel", "klt_fb_kernel",
-                                           "klt_stage1_kernel", "klt_stage2_kernel"};
+                                           "klt_stage1_kernel", "klt_stage2_kernel",
+                                           "ba_eval_kernel", "ba_colnorm_kernel", "ba_scale_kernels", "ba_lmdiag_kernel",
+                                           "ba_sinit_kernel", "ba_schur_kernel", "ba_chol_kernel", "ba_backsub_kernel",
+                                           "ba_plus_kernel", "ba_flag_kernel", "ba_reduce_kernel", "ba_misc_kernels"};
 
 static hipEvent_t ktime_event(ov2_ctx *c)
 {
