@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per stream (ping-pong cycle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--ba-kfs", type=int, default=50, help="keyframes in the local-BA window (north_star: ~50)")
+    ap.add_argument("--ba-lms", type=int, default=10000, help="landmarks in the local-BA window")
+    ap.add_argument("--no-ba", action="store_true", help="front-end only (no concurrent localBA worker)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -127,6 +131,61 @@ class Workload:
         return is_kf
 
 
+class BaWorker(threading.Thread):
+    """the Estimator thread of the reference (src/estimator.cpp:32-98): runs Optimizer::localBA on the newest pending
+    keyframe of any sequence, on its own HIP context/stream, concurrently with the front-end; a keyframe that arrives
+    while its sequence still has one pending replaces it (src/estimator.cpp:185-210 keeps only the newest)."""
+
+    def __init__(self, device, seqs, n_kf, n_lm, seed):
+        super().__init__(daemon=True)
+        from ov2slam_amd import frontend as fe, local_ba, synth_ba
+        self.ctx = fe.Context(device)
+        self.opt = local_ba.Optimizer(self.ctx)
+        self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
+        self.opt.localBA(self.P0.copy())          # warm-up (allocations, code objects)
+        self.pending = [False] * seqs
+        self.lock = threading.Lock()
+        self.wake = threading.Event()
+        self.stop_flag = False
+        self.counting = False
+        self.solves = self.iters = self.dropped = self.submitted = 0
+        self.busy_s = 0.0
+
+    def submit_all(self):
+        with self.lock:
+            for b in range(len(self.pending)):
+                if self.pending[b] and self.counting:
+                    self.dropped += 1
+                self.pending[b] = True
+                if self.counting:
+                    self.submitted += 1
+        self.wake.set()
+
+    def run(self):
+        rr = 0
+        while not self.stop_flag:
+            job = None
+            with self.lock:
+                n = len(self.pending)
+                for k in range(n):
+                    b = (rr + k) % n
+                    if self.pending[b]:
+                        self.pending[b] = False
+                        job, rr = b, b + 1
+                        break
+            if job is None:
+                self.wake.wait(0.002)
+                self.wake.clear()
+                continue
+            t0 = time.perf_counter()
+            R = self.opt.localBA(self.P0.copy())
+            dt = time.perf_counter() - t0
+            if self.counting:
+                self.solves += 1
+                self.iters += sum(R.summary()["iterations"])
+                self.busy_s += dt
+
+
 def cpu_baseline(workload, kf_every, budget_s):
     """the oracle (a scalar C port of the OpenCV path) timed on this host, 1 thread, on a bounded sample of the
     SAME workload (one sequence).  Reported beside the GPU number, never the thing measured or shipped."""
@@ -167,9 +226,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+    from ov2slam_amd import dist_util
+    dist_util.init_from_env("nccl", torch.device("cuda", local))   # nccl == RCCL on ROCm
 
     def barrier():
         if world > 1:
@@ -180,25 +238,38 @@ def main():
     ctx = fe.Context(local)
     wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank)
 
+    ba = None
+    if not a.no_ba:
+        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank)
+        ba.start()
     for _ in range(a.warmup):
-        wl.step(a.kf_every)
+        if wl.step(a.kf_every) and ba:
+            ba.submit_all()
     ctx.synchronize()
     barrier()
+    if ba:
+        ba.counting = True
     t0 = time.perf_counter()
     ctx.timer_start()
     nkf = 0
     for _ in range(a.steps):
-        nkf += wl.step(a.kf_every)
+        kf = wl.step(a.kf_every)
+        nkf += kf
+        if kf and ba:
+            ba.submit_all()                     # Mapper::run -> Estimator::addNewKf
     gpu_ms = ctx.timer_stop()     # synchronises the ctx stream
     barrier()
     el = time.perf_counter() - t0
+    if ba:
+        ba.counting = False
+        ba.stop_flag = True
+        ba.wake.set()
+        ba.join(timeout=30)
 
-    tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
-    frames = torch.tensor([float(a.steps * a.seqs)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
-    el_max, frames_all = float(tmax.item()), float(frames.item())
+    # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
+    el_max, cnt = dist_util.aggregate(el, [a.steps * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
+                                           ba.submitted if ba else 0, ba.dropped if ba else 0], device="cuda")
+    frames_all, ba_iters_all, ba_solves_all, ba_sub_all, ba_drop_all = cnt
 
     out = {
         "metric": "tracked_frames_per_sec", "value": frames_all / el_max, "unit": "frames/s",
@@ -213,6 +284,16 @@ def main():
         "gpu_stream_ms_per_step": gpu_ms / a.steps,
         "keyframes_per_step": nkf / a.steps,
     }
+    if ba:
+        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
+                           "solves_per_sec": ba_solves_all / el_max, "solves": ba_solves_all,
+                           "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
+                           "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
+                                      "parametrisation": "anchored inverse depth (buse_inv_depth: 1)"},
+                           "mode": "one Estimator-like worker per GPU on its own HIP stream, concurrent with the "
+                                   "front-end (reference: src/estimator.cpp:32-98); robust solve (<=5 it) + L2 (<=10 it)",
+                           "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
+        out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"
 
     if rank == 0 and not a.no_roofline:
         # second, instrumented pass over the same steps: every launch bracketed by hipEvents on the ctx stream
@@ -268,6 +349,16 @@ def main():
                                "sample": f"{nfr} frames of one sequence of the same workload ({sec:.1f} s), "
                                          "oracle/ C port of the OpenCV path, 1 thread; host has "
                                          f"{os.cpu_count()} logical cores"}
+    if rank == 0 and ba and not a.no_cpu_baseline:
+        from oracle import oracle_py as O
+        Pc = ba.P0.copy()
+        t1 = time.perf_counter()
+        Rc = O.ba_solve(Pc)
+        dt = time.perf_counter() - t1
+        out["local_ba"]["cpu_baseline"] = {"value": sum(Rc.summary()["iterations"]) / dt, "unit": "iters/s", "cores": 1,
+                                           "kind": "port", "sample": f"one solve of the same window ({dt:.2f} s), "
+                                           "oracle/ C restatement of the Ceres LM + Schur path, 1 thread "
+                                           "(the reference runs localBA with num_threads = 1, src/optimizer.cpp:460)"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
