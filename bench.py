@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--seqs", type=int, default=16, help="independent sequences per GPU (batched per launch)")
     ap.add_argument("--kps", type=int, default=2048, help="keypoints per frame (north_star: ~2k)")
     ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
@@ -261,10 +261,19 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if ba:
+        # a timed region shorter than one solve completes none: let the worker finish ONE job after the region and
+        # report its rate over its own busy time instead (flagged as such); the frames/s above is unaffected
+        ba_post_region = False
+        if ba.solves == 0:
+            ba_post_region = True
+            ba.submit_all()
+            t_wait = time.perf_counter()
+            while ba.solves == 0 and time.perf_counter() - t_wait < 60.0:
+                time.sleep(0.002)
         ba.counting = False
         ba.stop_flag = True
         ba.wake.set()
-        ba.join(timeout=30)
+        ba.join(timeout=60)
 
     # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
     el_max, cnt = dist_util.aggregate(el, [a.steps * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
@@ -285,8 +294,11 @@ def main():
         "keyframes_per_step": nkf / a.steps,
     }
     if ba:
-        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
-                           "solves_per_sec": ba_solves_all / el_max, "solves": ba_solves_all,
+        ba_den = el_max if not ba_post_region else max(ba.busy_s, 1e-9)
+        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / ba_den, "unit": "iters/s",
+                           "solves_per_sec": ba_solves_all / ba_den, "solves": ba_solves_all,
+                           "measured_over": "timed region (concurrent with the front-end)" if not ba_post_region else
+                                            "one solve finished after the timed region (region shorter than a solve)",
                            "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
                            "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
                                       "parametrisation": "anchored inverse depth (buse_inv_depth: 1)"},

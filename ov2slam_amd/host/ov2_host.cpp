@@ -1,0 +1,553 @@
+// ov2_host.cpp -- see ov2_host.hpp.  Graph walking / bookkeeping of the reference's hot-path callers, re-expressed on
+// the flat C ABI.  Reference line numbers (in /root/reference) are cited at each block.
+#include "ov2_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ov2 {
+
+// ---------------------------------------------------------------------------------------------- SE3
+void SE3::rotation(double R[9]) const
+{
+    double x = v[3], y = v[4], z = v[5], w = v[6];
+    const double n = std::sqrt(x * x + y * y + z * z + w * w);
+    x /= n; y /= n; z /= n; w /= n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+Vec3 SE3::operator*(const Vec3 &p) const
+{
+    double R[9];
+    rotation(R);
+    return {R[0] * p.x + R[1] * p.y + R[2] * p.z + v[0], R[3] * p.x + R[4] * p.y + R[5] * p.z + v[1],
+            R[6] * p.x + R[7] * p.y + R[8] * p.z + v[2]};
+}
+
+static void rot_to_quat(const double R[9], double q[4])
+{
+    const double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        const double s = std::sqrt(t + 1.0) * 2;
+        q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+        q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+        q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s;
+    } else {
+        const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+        q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s;
+    }
+}
+
+SE3 SE3::fromRt(const double R[9], const double t[3])
+{
+    SE3 T;
+    double q[4];
+    rot_to_quat(R, q);
+    T.v = {t[0], t[1], t[2], q[0], q[1], q[2], q[3]};
+    return T;
+}
+
+SE3 SE3::inverse() const
+{
+    double R[9], Rt[9];
+    rotation(R);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
+    const double t[3] = {-(Rt[0] * v[0] + Rt[1] * v[1] + Rt[2] * v[2]), -(Rt[3] * v[0] + Rt[4] * v[1] + Rt[5] * v[2]),
+                         -(Rt[6] * v[0] + Rt[7] * v[1] + Rt[8] * v[2])};
+    SE3 T;
+    const double n = std::sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5] + v[6] * v[6]);
+    T.v = {t[0], t[1], t[2], -v[3] / n, -v[4] / n, -v[5] / n, v[6] / n};
+    return T;
+}
+
+SE3 SE3::operator*(const SE3 &o) const
+{
+    double Ra[9], Rb[9], R[9];
+    rotation(Ra);
+    o.rotation(Rb);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = Ra[3 * i] * Rb[j] + Ra[3 * i + 1] * Rb[3 + j] + Ra[3 * i + 2] * Rb[6 + j];
+    const Vec3 t = (*this) * Vec3{o.v[0], o.v[1], o.v[2]};
+    const double tt[3] = {t.x, t.y, t.z};
+    return fromRt(R, tt);
+}
+
+// ---------------------------------------------------------------------------------------------- Frame
+std::vector<Keypoint> Frame::getKeypoints3d() const
+{
+    std::vector<Keypoint> v;
+    v.reserve(nb3dkps_);
+    for (const auto &kv : mapkps_) if (kv.second.is3d_) v.push_back(kv.second);
+    return v;
+}
+
+Keypoint Frame::getKeypointById(int lmid) const
+{
+    auto it = mapkps_.find(lmid);
+    return it == mapkps_.end() ? Keypoint() : it->second;
+}
+
+void Frame::addKeypoint(const Keypoint &kp)
+{
+    if (mapkps_.count(kp.lmid_)) return;
+    mapkps_.emplace(kp.lmid_, kp);
+    ++nbkps_;
+    if (kp.is3d_) ++nb3dkps_; else ++nb2dkps_;
+    if (kp.is_stereo_) ++nb_stereo_kps_;
+}
+
+void Frame::updateKeypoint(int lmid, const Point2f &pt)
+{
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end()) return;
+    it->second.px_ = pt;
+    it->second.unpx_ = pt;   // pinhole without distortion; the reference undistorts here (src/frame.cpp)
+}
+
+void Frame::removeKeypointById(int lmid)
+{
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end()) return;
+    if (it->second.is3d_) --nb3dkps_; else --nb2dkps_;
+    if (it->second.is_stereo_) --nb_stereo_kps_;
+    --nbkps_;
+    mapkps_.erase(it);
+}
+
+void Frame::removeStereoKeypointById(int lmid)
+{
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end() || !it->second.is_stereo_) return;
+    it->second.is_stereo_ = false;
+    --nb_stereo_kps_;
+}
+
+void Frame::turnKeypoint3d(int lmid)
+{
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end() || it->second.is3d_) return;
+    it->second.is3d_ = true;
+    ++nb3dkps_;
+    --nb2dkps_;
+}
+
+bool Frame::isInImage(const Point2f &pt) const
+{
+    return pt.x >= 0 && pt.y >= 0 && pt.x < pcalib_leftcam_->img_w_ && pt.y < pcalib_leftcam_->img_h_;
+}
+
+Point2f Frame::projWorldToImage(const Vec3 &wpt) const
+{
+    const Vec3 pc = Tcw_ * wpt;
+    const Vec3 px = pcalib_leftcam_->projectCamToImage(pc);
+    return {(float)px.x, (float)px.y};
+}
+
+// ---------------------------------------------------------------------------------------------- MapPoint / MapManager
+bool MapPoint::isBad()
+{   // src/map_point.cpp:215-234
+    if (set_kfids_.size() < 2) {
+        if (!isobs_ && is3d_) { is3d_ = false; return true; }
+    }
+    if (set_kfids_.size() == 0 && !isobs_) { is3d_ = false; return true; }
+    return false;
+}
+
+std::shared_ptr<Frame> MapManager::getKeyframe(int kfid) const
+{
+    auto it = map_pkfs_.find(kfid);
+    return it == map_pkfs_.end() ? nullptr : it->second;
+}
+
+std::shared_ptr<MapPoint> MapManager::getMapPoint(int lmid) const
+{
+    auto it = map_plms_.find(lmid);
+    return it == map_plms_.end() ? nullptr : it->second;
+}
+
+void MapManager::updateMapPoint(int lmid, const Vec3 &wpt, double kfanch_invdepth)
+{
+    auto plm = getMapPoint(lmid);
+    if (!plm) return;
+    if (!plm->is3d_) {   // turn the observations 3D (src/map_manager.cpp updateMapPoint)
+        for (int kfid : plm->getKfObsSet()) {
+            auto pkf = getKeyframe(kfid);
+            if (pkf) pkf->turnKeypoint3d(lmid);
+        }
+        if (plm->isobs_ && pcurframe_) pcurframe_->turnKeypoint3d(lmid);
+    }
+    plm->setPoint(wpt, kfanch_invdepth);
+}
+
+void MapManager::removeMapPointObs(int lmid, int kfid)
+{
+    auto pkf = getKeyframe(kfid);
+    if (pkf) pkf->removeKeypointById(lmid);
+    auto plm = getMapPoint(lmid);
+    if (plm) plm->removeKfObs(kfid);
+}
+
+void MapManager::removeMapPoint(int lmid)
+{
+    auto plm = getMapPoint(lmid);
+    if (!plm) return;
+    for (int kfid : plm->getKfObsSet()) {
+        auto pkf = getKeyframe(kfid);
+        if (pkf) pkf->removeKeypointById(lmid);
+    }
+    if (plm->isobs_ && pcurframe_) pcurframe_->removeKeypointById(lmid);
+    map_plms_.erase(lmid);
+}
+
+void MapManager::removeObsFromCurFrameById(int lmid)
+{
+    if (pcurframe_) pcurframe_->removeKeypointById(lmid);
+    auto plm = getMapPoint(lmid);
+    if (plm) plm->isobs_ = false;
+}
+
+void MapManager::updateFrameCovisibility(Frame &frame)
+{   // src/map_manager.cpp updateFrameCovisibility: count co-observed landmarks per keyframe
+    std::map<int, int> cov;
+    for (const auto &kv : frame.mapkps_) {
+        auto plm = getMapPoint(kv.first);
+        if (!plm) continue;
+        for (int kfid : plm->getKfObsSet())
+            if (kfid != frame.kfid_) cov[kfid]++;
+    }
+    frame.map_covkfs_ = cov;
+    for (const auto &kv : cov) {
+        auto pkf = getKeyframe(kv.first);
+        if (pkf) pkf->map_covkfs_[frame.kfid_] = kv.second;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- FeatureTracker
+ov2_status FeatureTracker::fbKltTracking(const Pyramid &vprevpyr, const Pyramid &vcurpyr, int nwinsize, int nbpyrlvl,
+                                         float ferr, float fmax_fbklt_dist, std::vector<Point2f> &vkps,
+                                         std::vector<Point2f> &vpriorkps, std::vector<bool> &vkpstatus) const
+{
+    if (vkps.empty()) return OV2_OK;   // src/feature_tracker.cpp:43-46
+    const int n = (int)vkps.size();
+    if ((int)vpriorkps.size() != n) return OV2_ERR_INVALID;
+    std::vector<uint8_t> st(n);
+    static_assert(sizeof(Point2f) == 2 * sizeof(float), "Point2f must be two packed floats");
+    ov2_status s = ov2_klt_track_fb(ctx_, vprevpyr.h, vcurpyr.h, nwinsize, nbpyrlvl, nmax_iter_, fmax_px_precision_, ferr,
+                                    fmax_fbklt_dist, n, &vkps[0].x, &vpriorkps[0].x, st.data());
+    if (s != OV2_OK) return s;
+    vkpstatus.resize(n);
+    for (int i = 0; i < n; ++i) vkpstatus[i] = st[i] != 0;
+    return OV2_OK;
+}
+
+bool FeatureTracker::inBorder(const Point2f &pt, int cols, int rows) const
+{
+    const float B = 1.f;
+    return B <= pt.x && pt.x < cols - B && B <= pt.y && pt.y < rows - B;
+}
+
+// ---------------------------------------------------------------------------------------------- VisualFrontEnd
+ov2_status VisualFrontEnd::preprocessImage(const uint8_t *img_raw, int w, int h, int stride)
+{   // src/visual_front_end.cpp:1143-1177: swap pyramids, CLAHE (tiles w/50 x h/50, src/ov2slam.cpp:85-89), pyramid
+    if (!cur_pyr_.empty()) prev_pyr_.swap(cur_pyr_);
+    ov2_pyr *p = nullptr;
+    ov2_status s = ov2_pyramid_build(ctx_, img_raw, w, h, stride, pslamstate_->nklt_win_size_, pslamstate_->nklt_pyr_lvl_,
+                                     pslamstate_->use_clahe_ ? 1 : 0, pslamstate_->fclahe_val_, w / 50, h / 50, &p);
+    if (s != OV2_OK) return s;
+    cur_pyr_ = Pyramid(p);
+    return OV2_OK;
+}
+
+ov2_status VisualFrontEnd::kltTracking()
+{   // src/visual_front_end.cpp:132-275
+    std::vector<int> v3dkpids, vkpids;
+    std::vector<Point2f> v3dkps, v3dpriors, vkps, vpriors;
+    for (const auto &it : pcurframe_->mapkps_) {   // :155-184
+        const Keypoint &kp = it.second;
+        if (pslamstate_->klt_use_prior_ && kp.is3d_) {
+            auto plm = pmap_->getMapPoint(kp.lmid_);
+            if (plm) {
+                const Point2f projpx = pcurframe_->projWorldToImage(plm->getPoint());
+                if (pcurframe_->isInImage(projpx)) {
+                    v3dkps.push_back(kp.px_); v3dpriors.push_back(projpx); v3dkpids.push_back(kp.lmid_);
+                    continue;
+                }
+            }
+        }
+        vkpids.push_back(kp.lmid_); vkps.push_back(kp.px_); vpriors.push_back(kp.px_);
+    }
+    if (pslamstate_->klt_use_prior_ && !v3dpriors.empty()) {   // :187-234
+        std::vector<bool> vkpstatus;
+        ov2_status s = ptracker_->fbKltTracking(prev_pyr_, cur_pyr_, pslamstate_->nklt_win_size_, 1, pslamstate_->nklt_err_,
+                                                pslamstate_->fmax_fbklt_dist_, v3dkps, v3dpriors, vkpstatus);
+        if (s != OV2_OK) return s;
+        size_t nbgood = 0;
+        const size_t nbkps = v3dkps.size();
+        for (size_t i = 0; i < nbkps; ++i) {
+            if (vkpstatus[i]) { pcurframe_->updateKeypoint(v3dkpids[i], v3dpriors[i]); ++nbgood; }
+            else { vkpids.push_back(v3dkpids[i]); vkps.push_back(v3dkps[i]); vpriors.push_back(v3dpriors[i]); }
+        }
+        if (nbgood < 0.33 * nbkps) { bp3preq_ = true; vpriors = vkps; }   // :228-233
+    }
+    if (!vkps.empty()) {   // :237-270
+        std::vector<bool> vkpstatus;
+        ov2_status s = ptracker_->fbKltTracking(prev_pyr_, cur_pyr_, pslamstate_->nklt_win_size_, pslamstate_->nklt_pyr_lvl_,
+                                                pslamstate_->nklt_err_, pslamstate_->fmax_fbklt_dist_, vkps, vpriors, vkpstatus);
+        if (s != OV2_OK) return s;
+        for (size_t i = 0; i < vkps.size(); ++i) {
+            if (vkpstatus[i]) pcurframe_->updateKeypoint(vkpids[i], vpriors[i]);
+            else pmap_->removeObsFromCurFrameById(vkpids[i]);
+        }
+    }
+    return OV2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Optimizer::localBA
+ov2_ba_problem LocalBAProblem::view(const SlamParams &st, const Frame &newframe)
+{
+    ov2_ba_problem p;
+    std::memset(&p, 0, sizeof(p));
+    const CameraCalibration &cl = *newframe.pcalib_leftcam_;
+    p.calib_l[0] = cl.fx_; p.calib_l[1] = cl.fy_; p.calib_l[2] = cl.cx_; p.calib_l[3] = cl.cy_;
+    p.T_rl[6] = 1.0;
+    if (st.stereo_ && newframe.pcalib_rightcam_) {
+        const CameraCalibration &cr = *newframe.pcalib_rightcam_;
+        p.calib_r[0] = cr.fx_; p.calib_r[1] = cr.fy_; p.calib_r[2] = cr.cx_; p.calib_r[3] = cr.cy_;
+        const SE3 Trl = cr.Tc0ci_.inverse();   // Tlr = getExtrinsic(); Trl = Tlr.inverse()  (src/optimizer.cpp:116-118)
+        for (int i = 0; i < 7; ++i) p.T_rl[i] = Trl.v[i];
+    }
+    p.inv_depth = st.buse_inv_depth_ ? 1 : 0;
+    p.n_pose = (int)pose_const.size(); p.pose = pose.data(); p.pose_const = pose_const.data();
+    p.n_lm = (int)lm_lmid.size(); p.lm = lm.data();
+    p.lm_anchor_pose = lm_anchor_pose.data(); p.lm_anchor_uv = lm_anchor_uv.data();
+    p.n_res = (int)res_type.size(); p.res_type = res_type.data(); p.res_pose = res_pose.data(); p.res_lm = res_lm.data();
+    p.res_uv = res_uv.data(); p.res_sigma = res_sigma.data();
+    return p;
+}
+
+void Optimizer::setupLocalBA(Frame &newframe, LocalBAProblem &pb)
+{   // src/optimizer.cpp:43-430
+    const int nmincovscore = pslamstate_->nmin_covscore_;
+    if ((int)newframe.nb3dkps_ < nmincovscore) { pb.aborted = true; return; }   // :61-63
+    size_t nmincstkfs = pslamstate_->stereo_ ? 1 : 2;                            // :65-68
+    const bool inv = pslamstate_->buse_inv_depth_;
+
+    auto add_pose = [&](int kfid, const std::shared_ptr<Frame> &pkf, bool cst) {
+        const int idx = (int)pb.pose_const.size();
+        pb.kfid_to_pose.emplace(kfid, idx);
+        pb.pose_kfid.push_back(kfid);
+        const SE3 T = pkf->getTwc();
+        pb.pose.insert(pb.pose.end(), T.v.begin(), T.v.end());
+        pb.pose_const.push_back(cst ? 1 : 0);
+        pb.map_local_pkfs.emplace(kfid, pkf);
+        if (cst) pb.set_cstkfids.insert(kfid);
+        return idx;
+    };
+
+    std::map<int, int> map_covkfs = newframe.getCovisibleKfMap();   // :128-131
+    map_covkfs.emplace(newframe.kfid_, (int)newframe.nb3dkps_);
+    std::vector<int> lmids2opt;                                     // insertion-ordered set_lmids2opt
+    std::unordered_set<int> set_lmids2opt;
+    bool all_cst = false;
+    const int nmaxkfid = map_covkfs.rbegin()->first;
+    for (auto it = map_covkfs.rbegin(); it != map_covkfs.rend(); ++it) {   // :150-190, newest -> oldest
+        const int kfid = it->first;
+        int covscore = it->second;
+        if (kfid > newframe.kfid_) covscore = (int)newframe.nbkps_;
+        auto pkf = pmap_->getKeyframe(kfid);
+        if (!pkf) { newframe.removeCovisibleKf(kfid); continue; }
+        if (covscore >= nmincovscore && !all_cst && kfid > 0) {
+            add_pose(kfid, pkf, false);
+            for (const auto &kp : pkf->getKeypoints3d())
+                if (set_lmids2opt.insert(kp.lmid_).second) lmids2opt.push_back(kp.lmid_);
+        } else {
+            add_pose(kfid, pkf, true);
+            all_cst = true;
+        }
+    }
+    std::sort(lmids2opt.begin(), lmids2opt.end());   // the reference iterates an unordered_set; any order is valid
+
+    for (int lmid : lmids2opt) {   // :193-392
+        auto plm = pmap_->getMapPoint(lmid);
+        if (!plm) continue;
+        if (plm->isBad()) { pb.set_badlmids.insert(lmid); continue; }
+        pb.map_local_plms.emplace(lmid, plm);
+        int lmidx = -1;
+        if (!inv) {
+            lmidx = (int)pb.lm_lmid.size();
+            pb.lmid_to_lm.emplace(lmid, lmidx);
+            pb.lm_lmid.push_back(lmid);
+            const Vec3 p = plm->getPoint();
+            pb.lm.push_back(p.x); pb.lm.push_back(p.y); pb.lm.push_back(p.z);
+            pb.lm_anchor_pose.push_back(-1); pb.lm_anchor_uv.push_back(0); pb.lm_anchor_uv.push_back(0);
+        }
+        int kfanchid = -1;
+        for (int kfid : plm->getKfObsSet()) {   // ascending kfid (std::set)
+            if (kfid > nmaxkfid) continue;
+            std::shared_ptr<Frame> pkf;
+            auto pkfit = pb.map_local_pkfs.find(kfid);
+            if (pkfit == pb.map_local_pkfs.end()) {   // :229-246: observers outside the window enter as constants
+                pkf = pmap_->getKeyframe(kfid);
+                if (!pkf) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+                add_pose(kfid, pkf, true);
+            } else {
+                pkf = pkfit->second;
+            }
+            const Keypoint kp = pkf->getKeypointById(lmid);
+            if (kp.lmid_ != lmid) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+            const double sigma = std::pow(2., kp.scale_);
+            auto add_res = [&](int type, const Point2f &uv) {
+                pb.res_type.push_back((uint8_t)type);
+                pb.res_pose.push_back(pb.kfid_to_pose.at(kfid));
+                pb.res_lm.push_back(lmidx);
+                pb.res_uv.push_back(uv.x); pb.res_uv.push_back(uv.y);
+                pb.res_sigma.push_back(sigma);
+            };
+            if (inv && kfanchid < 0) {   // :251-287 anchor = first valid observer
+                kfanchid = kfid;
+                const double zanch = (pkf->getTcw() * plm->getPoint()).z;
+                lmidx = (int)pb.lm_lmid.size();
+                pb.lmid_to_lm.emplace(lmid, lmidx);
+                pb.lm_lmid.push_back(lmid);
+                pb.lm.push_back(1. / zanch);
+                pb.lm_anchor_pose.push_back(pb.kfid_to_pose.at(kfid));
+                pb.lm_anchor_uv.push_back(kp.unpx_.x); pb.lm_anchor_uv.push_back(kp.unpx_.y);
+                if (kp.is_stereo_) { add_res(OV2_BA_RANCH_INV, kp.runpx_); pb.nbstereo++; }
+                else pb.nbmono++;
+                continue;
+            }
+            if (kp.is_stereo_) {   // :293-361
+                add_res(inv ? OV2_BA_L_INV : OV2_BA_L_XYZ, kp.unpx_);
+                add_res(inv ? OV2_BA_R_INV : OV2_BA_R_XYZ, kp.runpx_);
+                pb.nbstereo++;
+            } else {               // :363-391
+                add_res(inv ? OV2_BA_L_INV : OV2_BA_L_XYZ, kp.unpx_);
+                pb.nbmono++;
+            }
+        }
+    }
+    // gauge: at least nmincstkfs constant keyframes (:394-407; the reference walks an unordered_map, we take the
+    // smallest kfids first)
+    size_t nbcstkfs = pb.set_cstkfids.size();
+    if (nbcstkfs < nmincstkfs) {
+        std::vector<int> ids = pb.pose_kfid;
+        std::sort(ids.begin(), ids.end());
+        for (int kfid : ids) {
+            if (nbcstkfs >= nmincstkfs) break;
+            if (pb.set_cstkfids.count(kfid)) continue;
+            pb.pose_const[pb.kfid_to_pose.at(kfid)] = 1;
+            pb.set_cstkfids.insert(kfid);
+            ++nbcstkfs;
+        }
+    }
+}
+
+void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res)
+{   // flags :500-592 / :637-735, update :741-882
+    const bool inv = pslamstate_->buse_inv_depth_;
+    std::vector<std::pair<int, int>> vbadkflmids, vbadstereokflmids;
+    for (size_t i = 0; i < pb.res_type.size(); ++i) {
+        if (!res.outlier || !res.outlier[i]) continue;
+        const int kfid = pb.pose_kfid[pb.res_pose[i]], lmid = pb.lm_lmid[pb.res_lm[i]];
+        const int t = pb.res_type[i];
+        if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) vbadkflmids.emplace_back(kfid, lmid);
+        else vbadstereokflmids.emplace_back(kfid, lmid);
+        pb.set_badlmids.insert(lmid);
+    }
+    for (const auto &b : vbadstereokflmids) {   // :743-751
+        auto it = pb.map_local_pkfs.find(b.first);
+        if (it != pb.map_local_pkfs.end()) it->second->removeStereoKeypointById(b.second);
+        pb.set_badlmids.insert(b.second);
+    }
+    for (const auto &b : vbadkflmids) {         // :753-764
+        auto it = pb.map_local_pkfs.find(b.first);
+        if (it != pb.map_local_pkfs.end()) pmap_->removeMapPointObs(b.second, b.first);
+        if (pmap_->pcurframe_ && b.first == pmap_->pcurframe_->kfid_) pmap_->removeObsFromCurFrameById(b.second);
+        pb.set_badlmids.insert(b.second);
+    }
+    for (const auto &kv : pb.map_local_pkfs) {   // :767-786 poses of the non-constant keyframes
+        if (pb.set_cstkfids.count(kv.first) || !kv.second) continue;
+        const int idx = pb.kfid_to_pose.at(kv.first);
+        SE3 T;
+        for (int k = 0; k < 7; ++k) T.v[k] = pb.pose[7 * idx + k];
+        kv.second->setTwc(T);
+    }
+    for (const auto &kv : pb.map_local_plms) {   // :789-853 landmarks
+        const int lmid = kv.first;
+        auto plm = kv.second;
+        if (!plm) { pb.set_badlmids.erase(lmid); continue; }
+        if (plm->isBad()) { pmap_->removeMapPoint(lmid); pb.set_badlmids.erase(lmid); continue; }
+        if (plm->getKfObsSet().size() < 3) {
+            if (plm->kfid_ < newframe.kfid_ - 3 && !plm->isobs_) { pmap_->removeMapPoint(lmid); pb.set_badlmids.erase(lmid); continue; }
+        }
+        auto lit = pb.lmid_to_lm.find(lmid);
+        if (lit == pb.lmid_to_lm.end()) { pb.set_badlmids.insert(lmid); continue; }
+        if (inv) {
+            const double rho = pb.lm[lit->second];
+            const double zanch = 1. / rho;
+            if (zanch <= 0.) { pmap_->removeMapPoint(lmid); pb.set_badlmids.erase(lmid); continue; }
+            auto it = pb.map_local_pkfs.find(plm->kfid_);   // the MapPoint's own anchor keyframe (:822)
+            if (it == pb.map_local_pkfs.end() || !it->second) { pb.set_badlmids.insert(lmid); continue; }
+            auto pkfanch = it->second;
+            const Keypoint kp = pkfanch->getKeypointById(lmid);
+            const CameraCalibration &c = *pkfanch->pcalib_leftcam_;
+            const Vec3 cam{zanch * (kp.unpx_.x - c.cx_) / c.fx_, zanch * (kp.unpx_.y - c.cy_) / c.fy_, zanch};
+            pmap_->updateMapPoint(lmid, pkfanch->getTwc() * cam, rho);
+        } else {
+            pmap_->updateMapPoint(lmid, Vec3{pb.lm[3 * lit->second], pb.lm[3 * lit->second + 1], pb.lm[3 * lit->second + 2]});
+        }
+    }
+    for (int lmid : pb.set_badlmids) {   // :856-882 culling
+        std::shared_ptr<MapPoint> plm;
+        auto it = pb.map_local_plms.find(lmid);
+        plm = (it == pb.map_local_plms.end()) ? pmap_->getMapPoint(lmid) : it->second;
+        if (!plm) continue;
+        if (plm->isBad()) pmap_->removeMapPoint(lmid);
+        else if (plm->getKfObsSet().size() < 3 && plm->kfid_ < newframe.kfid_ - 3 && !plm->isobs_) pmap_->removeMapPoint(lmid);
+    }
+    bstop_localba_ = false;   // :896
+}
+
+ov2_status Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)
+{
+    LocalBAProblem pb;
+    setupLocalBA(newframe, pb);
+    if (pb.aborted || pb.res_type.empty()) { bstop_localba_ = false; return OV2_OK; }
+    ov2_ba_problem p = pb.view(*pslamstate_, newframe);
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    if (!buse_robust_cost) o.huber_delta = 0.0;                       // loss_function->Reset(nullptr) :51-53
+    o.l2_refine = (pslamstate_->apply_l2_after_robust_ && !stopLocalBA()) ? 1 : 0;   // :603-604
+    std::vector<double> chi2(p.n_res);
+    std::vector<uint8_t> depth(p.n_res), outlier(p.n_res);
+    std::memset(&last_result_, 0, sizeof(last_result_));
+    last_result_.chi2 = chi2.data(); last_result_.depth_positive = depth.data(); last_result_.outlier = outlier.data();
+    const ov2_status s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    if (s == OV2_OK) updateAfterLocalBA(newframe, pb, last_result_);
+    last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr;
+    return s;
+}
+
+ov2_status Estimator::applyLocalBA()
+{   // src/estimator.cpp:67-98
+    const int nmincstkfs = pslamstate_->mono_ ? 2 : 1;
+    if (!pnewkf_ || pnewkf_->kfid_ < nmincstkfs) return OV2_OK;
+    if (pnewkf_->nb3dkps_ == 0) return OV2_OK;
+    pslamstate_->blocalba_is_on_ = true;
+    const ov2_status s = poptimizer_->localBA(*pnewkf_, true);
+    pslamstate_->blocalba_is_on_ = false;
+    return s;
+}
+
+}  // namespace ov2

@@ -1,0 +1,213 @@
+// ov2_host.hpp -- C++ host side above the C ABI (include/ov2slam_hip.h): the reference's data model and call surface
+// for the hot path, without OpenCV / Eigen / Sophus / Ceres, so that the HIP path drops into a SlamManager-like
+// pipeline.  Names, members and control flow mirror the reference (file:line in /root/reference):
+//   Keypoint            include/frame.hpp:46-76          Frame        include/frame.hpp:78-237, src/frame.cpp
+//   MapPoint            include/map_point.hpp:37-97      MapManager   include/map_manager.hpp:41-129 (subset)
+//   FeatureTracker      include/feature_tracker.hpp:32-56, src/feature_tracker.cpp:35-137
+//   VisualFrontEnd      src/visual_front_end.cpp:132-275 (kltTracking), :1143-1177 (preprocessImage)
+//   MapManager::stereoMatching  src/map_manager.cpp:367-611 (KLT part + epipolar gate for rectified / row check)
+//   Optimizer::localBA  src/optimizer.cpp:34-897         Estimator::applyLocalBA  src/estimator.cpp:67-98
+// All arithmetic of the path runs behind the ABI on the GPU; this file is graph walking and bookkeeping.
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ov2slam_hip.h"
+
+namespace ov2 {
+
+struct Point2f {
+    float x = 0.f, y = 0.f;
+};
+
+struct Vec3 {
+    double x = 0, y = 0, z = 0;
+};
+
+// rigid transform stored like the reference's PoseParametersBlock: [tx ty tz qx qy qz qw]
+struct SE3 {
+    std::array<double, 7> v{{0, 0, 0, 0, 0, 0, 1}};
+    void rotation(double R[9]) const;
+    Vec3 operator*(const Vec3 &p) const;
+    SE3 inverse() const;
+    SE3 operator*(const SE3 &o) const;
+    static SE3 fromRt(const double R[9], const double t[3]);
+};
+
+struct CameraCalibration {   // pinhole part of src/camera_calibration.cpp that the path needs
+    double fx_ = 1, fy_ = 1, cx_ = 0, cy_ = 0;
+    int img_w_ = 0, img_h_ = 0;
+    SE3 Tc0ci_;               // extrinsic: this camera in the left-camera frame (getExtrinsic(), T_left_right)
+    Vec3 projectCamToImage(const Vec3 &pc) const { return {fx_ * pc.x / pc.z + cx_, fy_ * pc.y / pc.z + cy_, pc.z}; }
+};
+
+struct Keypoint {   // include/frame.hpp:46-76
+    int lmid_ = -1;
+    Point2f px_, unpx_;
+    int scale_ = 0;
+    float angle_ = -1.f;
+    bool is3d_ = false;
+    bool is_stereo_ = false;
+    Point2f rpx_, runpx_;
+    bool is_retracked_ = false;
+};
+
+class Frame {   // include/frame.hpp:78-237 (members the path touches)
+public:
+    int id_ = -1, kfid_ = 0;
+    double img_time_ = 0.;
+    std::unordered_map<int, Keypoint> mapkps_;
+    size_t nbkps_ = 0, nb2dkps_ = 0, nb3dkps_ = 0, nb_stereo_kps_ = 0;
+    SE3 Twc_, Tcw_;
+    std::shared_ptr<CameraCalibration> pcalib_leftcam_, pcalib_rightcam_;
+    std::map<int, int> map_covkfs_;
+
+    SE3 getTwc() const { return Twc_; }
+    SE3 getTcw() const { return Tcw_; }
+    void setTwc(const SE3 &Twc) { Twc_ = Twc; Tcw_ = Twc.inverse(); }
+    std::vector<Keypoint> getKeypoints3d() const;
+    Keypoint getKeypointById(int lmid) const;   // returns Keypoint with lmid_ = -1 if absent (src/frame.cpp)
+    std::map<int, int> getCovisibleKfMap() const { return map_covkfs_; }
+    void removeCovisibleKf(int kfid) { map_covkfs_.erase(kfid); }
+    void addKeypoint(const Keypoint &kp);
+    void updateKeypoint(int lmid, const Point2f &pt);   // src/frame.cpp: px_ / unpx_ update (pinhole: unpx = px)
+    void removeKeypointById(int lmid);
+    void removeStereoKeypointById(int lmid);
+    void turnKeypoint3d(int lmid);
+    bool isInImage(const Point2f &pt) const;
+    Point2f projWorldToImage(const Vec3 &wpt) const;
+};
+
+class MapPoint {   // include/map_point.hpp:37-97
+public:
+    MapPoint(int lmid, int kfid, bool bobs = true) : lmid_(lmid), isobs_(bobs), kfid_(kfid) { set_kfids_.insert(kfid); }
+    int lmid_;
+    bool isobs_;
+    bool is3d_ = false;
+    std::set<int> set_kfids_;
+    Vec3 ptxyz_;
+    int kfid_;
+    double invdepth_ = -1.;
+    void setPoint(const Vec3 &p, double kfanch_invdepth = -1.) { ptxyz_ = p; is3d_ = true; if (kfanch_invdepth >= 0.) invdepth_ = kfanch_invdepth; }
+    Vec3 getPoint() const { return ptxyz_; }
+    std::set<int> getKfObsSet() const { return set_kfids_; }
+    void addKfObs(int kfid) { set_kfids_.insert(kfid); }
+    void removeKfObs(int kfid) { set_kfids_.erase(kfid); }
+    bool isBad();   // src/map_point.cpp:215-234
+};
+
+class MapManager {   // subset of include/map_manager.hpp:41-129 used by localBA / kltTracking
+public:
+    std::shared_ptr<Frame> pcurframe_;
+    std::unordered_map<int, std::shared_ptr<Frame>> map_pkfs_;
+    std::unordered_map<int, std::shared_ptr<MapPoint>> map_plms_;
+    std::shared_ptr<Frame> getKeyframe(int kfid) const;
+    std::shared_ptr<MapPoint> getMapPoint(int lmid) const;
+    void updateMapPoint(int lmid, const Vec3 &wpt, double kfanch_invdepth = -1.);   // src/map_manager.cpp
+    void removeMapPointObs(int lmid, int kfid);
+    void removeMapPoint(int lmid);
+    void removeObsFromCurFrameById(int lmid);
+    void updateFrameCovisibility(Frame &frame);   // src/map_manager.cpp: co-observation counts
+};
+
+struct SlamParams {   // the subset of include/slam_params.hpp the path reads (YAML keys of the same name)
+    bool stereo_ = true, mono_ = false, buse_inv_depth_ = true, apply_l2_after_robust_ = true, klt_use_prior_ = true;
+    float robust_mono_th_ = 5.9915f;
+    int nmin_covscore_ = 25;
+    int nklt_win_size_ = 9, nklt_pyr_lvl_ = 3, nmax_iter_ = 30;
+    float fmax_px_precision_ = 0.01f, fmax_fbklt_dist_ = 0.5f, nklt_err_ = 30.f;
+    bool use_clahe_ = true;
+    float fclahe_val_ = 3.f;
+    bool blocalba_is_on_ = false, bforce_realtime_ = true;
+};
+
+// owning handle of an ov2_pyr (the std::vector<cv::Mat> pyramid of the reference)
+struct Pyramid {
+    ov2_pyr *h = nullptr;
+    Pyramid() = default;
+    explicit Pyramid(ov2_pyr *p) : h(p) {}
+    Pyramid(const Pyramid &o) : h(o.h) { if (h) ov2_pyr_retain(h); }
+    Pyramid &operator=(const Pyramid &o) { if (o.h) ov2_pyr_retain(o.h); if (h) ov2_pyr_release(h); h = o.h; return *this; }
+    ~Pyramid() { if (h) ov2_pyr_release(h); }
+    bool empty() const { return h == nullptr; }
+    void swap(Pyramid &o) { std::swap(h, o.h); }
+};
+
+class FeatureTracker {   // include/feature_tracker.hpp:32-56
+public:
+    FeatureTracker(ov2_ctx *ctx, int nmax_iter, float fmax_px_precision) : ctx_(ctx), nmax_iter_(nmax_iter), fmax_px_precision_(fmax_px_precision) {}
+    // src/feature_tracker.cpp:35-137; returns the ov2_status of the call (the reference has no error channel)
+    ov2_status fbKltTracking(const Pyramid &vprevpyr, const Pyramid &vcurpyr, int nwinsize, int nbpyrlvl, float ferr,
+                             float fmax_fbklt_dist, std::vector<Point2f> &vkps, std::vector<Point2f> &vpriorkps,
+                             std::vector<bool> &vkpstatus) const;
+    bool inBorder(const Point2f &pt, int cols, int rows) const;   // :216-221
+    ov2_ctx *ctx_;
+    int nmax_iter_;
+    float fmax_px_precision_;
+};
+
+class VisualFrontEnd {   // src/visual_front_end.cpp (preprocessImage + kltTracking)
+public:
+    VisualFrontEnd(ov2_ctx *ctx, std::shared_ptr<SlamParams> pstate, std::shared_ptr<Frame> pframe,
+                   std::shared_ptr<MapManager> pmap, std::shared_ptr<FeatureTracker> ptracker)
+        : ctx_(ctx), pslamstate_(pstate), pcurframe_(pframe), pmap_(pmap), ptracker_(ptracker) {}
+    ov2_status preprocessImage(const uint8_t *img_raw, int w, int h, int stride);   // :1143-1177
+    ov2_status kltTracking();                                                        // :132-275
+    bool bp3preq_ = false;
+    Pyramid prev_pyr_, cur_pyr_;
+    ov2_ctx *ctx_;
+    std::shared_ptr<SlamParams> pslamstate_;
+    std::shared_ptr<Frame> pcurframe_;
+    std::shared_ptr<MapManager> pmap_;
+    std::shared_ptr<FeatureTracker> ptracker_;
+};
+
+// flat problem assembled by Optimizer::localBA's set-up stage, kept for the update stage
+struct LocalBAProblem {
+    std::vector<double> pose, lm, lm_anchor_uv, res_uv, res_sigma;
+    std::vector<uint8_t> pose_const, res_type;
+    std::vector<int32_t> lm_anchor_pose, res_pose, res_lm;
+    std::vector<int> pose_kfid, lm_lmid;                 // block index -> reference ids
+    std::unordered_map<int, int> kfid_to_pose, lmid_to_lm;
+    std::unordered_set<int> set_cstkfids, set_badlmids;
+    std::unordered_map<int, std::shared_ptr<Frame>> map_local_pkfs;
+    std::unordered_map<int, std::shared_ptr<MapPoint>> map_local_plms;
+    size_t nbmono = 0, nbstereo = 0;
+    bool aborted = false;                                // early return of :61-63
+    ov2_ba_problem view(const SlamParams &st, const Frame &newframe);
+};
+
+class Optimizer {   // include/optimizer.hpp:42, src/optimizer.cpp:34-897
+public:
+    Optimizer(ov2_ctx *ctx, std::shared_ptr<SlamParams> pstate, std::shared_ptr<MapManager> pmap)
+        : ctx_(ctx), pslamstate_(pstate), pmap_(pmap) {}
+    ov2_status localBA(Frame &newframe, const bool buse_robust_cost);
+    // the three stages, exposed for tests
+    void setupLocalBA(Frame &newframe, LocalBAProblem &pb);                                   // :43-430
+    void updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res);   // :741-882
+    bool stopLocalBA() const { return bstop_localba_; }
+    void signalStopLocalBA() { bstop_localba_ = true; }
+    ov2_ba_result last_result_{};
+    ov2_ctx *ctx_;
+    std::shared_ptr<SlamParams> pslamstate_;
+    std::shared_ptr<MapManager> pmap_;
+    bool bstop_localba_ = false;
+};
+
+class Estimator {   // src/estimator.cpp:67-98
+public:
+    Estimator(std::shared_ptr<SlamParams> pstate, std::shared_ptr<MapManager> pmap, std::shared_ptr<Optimizer> popt)
+        : pslamstate_(pstate), pmap_(pmap), poptimizer_(popt) {}
+    ov2_status applyLocalBA();
+    std::shared_ptr<Frame> pnewkf_;
+    std::shared_ptr<SlamParams> pslamstate_;
+    std::shared_ptr<MapManager> pmap_;
+    std::shared_ptr<Optimizer> poptimizer_;
+};
+
+}  // namespace ov2

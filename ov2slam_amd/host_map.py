@@ -1,0 +1,135 @@
+"""ctypes driver of the C++ host mirror (libov2host.so, ov2slam_amd/host/): builds a Frame/MapPoint graph, runs
+Optimizer::setupLocalBA on the CPU or Estimator::applyLocalBA on the GPU.  Used by tests and bring-up only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ba_types as T
+from . import synth_ba
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.path.join(_HERE, "lib", "libov2host.so"))
+        dp, ip, u8 = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+        L.ov2h_map_create.restype = C.c_void_p
+        L.ov2h_map_create.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int]
+        L.ov2h_map_destroy.argtypes = [C.c_void_p]
+        L.ov2h_map_add_keyframe.argtypes = [C.c_void_p, C.c_int, dp]
+        L.ov2h_map_add_landmark.argtypes = [C.c_void_p, C.c_int, dp, C.c_int]
+        L.ov2h_map_add_obs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+        L.ov2h_map_finalize.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_local_ba_setup.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
+        L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
+        L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
+        L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
+        L.ov2h_count_keypoints.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HostMap:
+    """a MapManager + keyframes + map points built from a flat BaProblem (inverse-depth or XYZ window)."""
+
+    def __init__(self, prob, nmin_covscore=25, stereo=True):
+        L = lib()
+        self.prob = prob
+        T_rl = np.eye(4)
+        T_rl[:3, :3] = synth_ba.quat_to_rot(prob.T_rl[3:])
+        T_rl[:3, 3] = prob.T_rl[:3]
+        T_lr = np.linalg.inv(T_rl)
+        t_lr7 = np.ascontiguousarray(synth_ba.pose7(T_lr[:3, :3], T_lr[:3, 3]))
+        self.h = L.ov2h_map_create(int(stereo), prob.inv_depth, _dp(prob.calib_l), _dp(prob.calib_r), _dp(t_lr7), 752, 480,
+                                   nmin_covscore)
+        for k in range(len(prob.pose)):
+            L.ov2h_map_add_keyframe(self.h, k, _dp(np.ascontiguousarray(prob.pose[k])))
+        # observations per (kf, lm) from the residual list
+        obs = {}
+        for i in range(prob.n_res):
+            t, k, l = int(prob.res_type[i]), int(prob.res_pose[i]), int(prob.res_lm[i])
+            if t == T.RANCH_INV:
+                k = int(prob.lm_anchor_pose[l])
+            o = obs.setdefault((k, l), {})
+            if t in (T.L_XYZ, T.L_INV):
+                o["l"] = prob.res_uv[i]
+            else:
+                o["r"] = prob.res_uv[i]
+        self.xyz0 = np.zeros((len(prob.lm), 3))
+        for l in range(len(prob.lm)):
+            if prob.inv_depth:
+                a = int(prob.lm_anchor_pose[l])
+                obs.setdefault((a, l), {})["l"] = prob.lm_anchor_uv[l]
+                z = 1.0 / prob.lm[l, 0]
+                u, v = prob.lm_anchor_uv[l]
+                pc = z * np.array([(u - prob.calib_l[2]) / prob.calib_l[0], (v - prob.calib_l[3]) / prob.calib_l[1], 1.0])
+                xyz = synth_ba.quat_to_rot(prob.pose[a, 3:]) @ pc + prob.pose[a, :3]
+            else:
+                xyz = prob.lm[l]
+            self.xyz0[l] = xyz
+        anchor = {}
+        for (k, l) in obs:
+            anchor[l] = min(anchor.get(l, 10 ** 9), k)
+        for l in range(len(prob.lm)):
+            if l in anchor:
+                L.ov2h_map_add_landmark(self.h, l, _dp(np.ascontiguousarray(self.xyz0[l])), anchor[l])
+        for (k, l), o in sorted(obs.items()):
+            ul = o["l"]
+            ur = o.get("r")
+            L.ov2h_map_add_obs(self.h, k, l, ul[0], ul[1], int(ur is not None), 0.0 if ur is None else ur[0],
+                               0.0 if ur is None else ur[1])
+        self.newkf = len(prob.pose) - 1
+        assert L.ov2h_map_finalize(self.h, self.newkf) == 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ov2h_map_destroy(self.h)
+            self.h = None
+
+    def setup_local_ba(self):
+        """Optimizer::setupLocalBA (CPU). returns dict of the flat problem keyed by reference ids."""
+        L = lib()
+        npose, nlm, nres = C.c_int(), C.c_int(), C.c_int()
+        rc = L.ov2h_local_ba_setup(self.h, self.newkf, C.byref(npose), C.byref(nlm), C.byref(nres))
+        e = 1 if self.prob.inv_depth else 3
+        ip, u8 = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+        out = dict(aborted=rc == 1, pose_kfid=np.zeros(npose.value, np.int32), pose_const=np.zeros(npose.value, np.uint8),
+                   pose=np.zeros((npose.value, 7)), lm_lmid=np.zeros(nlm.value, np.int32), lm=np.zeros((nlm.value, e)),
+                   lm_anchor_kfid=np.zeros(nlm.value, np.int32), lm_anchor_uv=np.zeros((nlm.value, 2)),
+                   res_type=np.zeros(nres.value, np.uint8), res_kfid=np.zeros(nres.value, np.int32),
+                   res_lmid=np.zeros(nres.value, np.int32), res_uv=np.zeros((nres.value, 2)))
+        L.ov2h_local_ba_get(self.h, out["pose_kfid"].ctypes.data_as(ip), out["pose_const"].ctypes.data_as(u8), _dp(out["pose"]),
+                            out["lm_lmid"].ctypes.data_as(ip), _dp(out["lm"]), out["lm_anchor_kfid"].ctypes.data_as(ip),
+                            _dp(out["lm_anchor_uv"]), out["res_type"].ctypes.data_as(u8), out["res_kfid"].ctypes.data_as(ip),
+                            out["res_lmid"].ctypes.data_as(ip), _dp(out["res_uv"]))
+        return out
+
+    def apply_local_ba(self, ctx):
+        """Estimator::applyLocalBA on the GPU. returns (status, outliers pass1, pass2, final cost)."""
+        n1, n2, fc = C.c_int(), C.c_int(), C.c_double()
+        st = lib().ov2h_apply_local_ba(self.h, ctx.h, self.newkf, C.byref(n1), C.byref(n2), C.byref(fc))
+        return st, n1.value, n2.value, fc.value
+
+    def pose(self, kfid):
+        out = np.zeros(7)
+        assert lib().ov2h_get_pose(self.h, kfid, _dp(out)) == 0
+        return out
+
+    def landmark(self, lmid):
+        out, n = np.zeros(3), C.c_int()
+        rc = lib().ov2h_get_landmark(self.h, lmid, _dp(out), C.byref(n))
+        return (out, n.value) if rc == 0 else (None, 0)
+
+    def counts(self, kfid):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        lib().ov2h_count_keypoints(self.h, kfid, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value

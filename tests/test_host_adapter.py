@@ -1,0 +1,91 @@
+"""C++ host mirror (ov2slam_amd/host): Optimizer::localBA set-up stage reproduces the reference's residual layout
+(src/optimizer.cpp:43-430) on a Frame/MapPoint graph (CPU), and Estimator::applyLocalBA end to end equals the flat
+solve (GPU)."""
+import numpy as np
+import pytest
+
+from ov2slam_amd import ba_types as T, host_map, synth_ba
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as g
+    g.build()
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_setup_local_ba_reproduces_residual_layout(inv_depth):
+    P = synth_ba.make_window(8, 300, inv_depth=inv_depth, seed=4)
+    hm = host_map.HostMap(P)
+    pb = hm.setup_local_ba()
+    assert not pb["aborted"]
+    # same multiset of residual blocks (type, kf, landmark, measurement)
+    want = sorted((int(P.res_type[i]), int(P.lm_anchor_pose[P.res_lm[i]]) if P.res_type[i] == T.RANCH_INV else int(P.res_pose[i]),
+                   int(P.res_lm[i]), round(float(np.float32(P.res_uv[i, 0])), 2), round(float(np.float32(P.res_uv[i, 1])), 2)) for i in range(P.n_res))
+    got = sorted((int(pb["res_type"][i]), int(pb["res_kfid"][i]), int(pb["res_lmid"][i]), round(float(pb["res_uv"][i, 0]), 2),
+                  round(float(pb["res_uv"][i, 1]), 2)) for i in range(len(pb["res_type"])))
+    assert got == want
+    # every keyframe shares > 25 landmarks with the newest one -> optimised, except kfid 0 (:176 `kfid > 0`)
+    const = {int(k) for k, c in zip(pb["pose_kfid"], pb["pose_const"]) if c}
+    assert const == {0}
+    assert sorted(pb["pose_kfid"]) == list(range(8))
+    if inv_depth:   # anchor = first observing keyframe, rho = 1 / depth in the anchor camera (:251-267)
+        order = np.argsort(pb["lm_lmid"])
+        assert np.array_equal(pb["lm_anchor_kfid"][order], P.lm_anchor_pose[pb["lm_lmid"][order]])
+        assert np.allclose(pb["lm"][order, 0], P.lm[pb["lm_lmid"][order], 0], rtol=1e-6)   # unpx_ is float32
+    else:
+        order = np.argsort(pb["lm_lmid"])
+        assert np.allclose(pb["lm"][order], P.lm[pb["lm_lmid"][order]], atol=1e-12)
+
+
+def test_setup_aborts_on_poor_tracking_and_handles_outside_observers():
+    P = synth_ba.make_window(6, 200, inv_depth=True, seed=2)
+    hm = host_map.HostMap(P, nmin_covscore=10 ** 6)    # nb3dkps < nmin_covscore -> early return (:61-63)
+    assert hm.setup_local_ba()["aborted"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_apply_local_ba_equals_flat_solve(ctx, inv_depth):
+    from ov2slam_amd import local_ba
+    P = synth_ba.make_window(10, 600, inv_depth=inv_depth, seed=8)
+    hm = host_map.HostMap(P)
+    # flat solve with the constness the adapter derives (kfid 0 only) and float32 pixels (Keypoint::unpx_ is Point2f)
+    Q = P.copy()
+    Q.pose_const[:] = 0
+    Q.pose_const[0] = 1
+    Q.res_uv = Q.res_uv.astype(np.float32).astype(np.float64)
+    if inv_depth:
+        Q.lm_anchor_uv = Q.lm_anchor_uv.astype(np.float32).astype(np.float64)
+        # the adapter recomputes rho from the map point it was given
+        for l in range(len(Q.lm)):
+            a = int(Q.lm_anchor_pose[l])
+            Q.lm[l, 0] = 1.0 / (synth_ba.quat_to_rot(Q.pose[a, 3:]).T @ (hm.xyz0[l] - Q.pose[a, :3]))[2]
+    R = local_ba.Optimizer(ctx).localBA(Q)
+    st, n1, n2, fc = hm.apply_local_ba(ctx)
+    assert st == 0
+    assert (n1, n2) == (R.c.n_outliers_pass1, R.c.n_outliers_pass2)
+    assert fc == pytest.approx(R.c.l2_final_cost if R.c.l2_done else R.c.final_cost, rel=1e-6)
+    for k in range(len(Q.pose)):
+        assert np.allclose(hm.pose(k), Q.pose[k], atol=1e-7)
+    # landmarks written back as world points; bad observations were removed from the keyframes (:743-764)
+    nb_before = sum(1 for i in range(P.n_res) if P.res_type[i] in (T.L_XYZ, T.L_INV) and P.res_pose[i] == 5) + \
+        (int((P.lm_anchor_pose == 5).sum()) if inv_depth else 0)
+    nb_after, _, _ = hm.counts(5)
+    assert nb_after <= nb_before
+    moved = 0
+    for l in range(0, len(Q.lm), 7):
+        xyz, nobs = hm.landmark(l)
+        if xyz is None:
+            continue
+        if inv_depth:
+            a = int(Q.lm_anchor_pose[l])
+            z = 1.0 / Q.lm[l, 0]
+            u, v = Q.lm_anchor_uv[l]
+            pc = z * np.array([(u - Q.calib_l[2]) / Q.calib_l[0], (v - Q.calib_l[3]) / Q.calib_l[1], 1.0])
+            want = synth_ba.quat_to_rot(Q.pose[a, 3:]) @ pc + Q.pose[a, :3]
+        else:
+            want = Q.lm[l]
+        assert np.allclose(xyz, want, atol=1e-6)
+        moved += 1
+    assert moved > 20
