@@ -139,7 +139,7 @@ class BaWorker(threading.Thread):
     def __init__(self, device, seqs, n_kf, n_lm, seed):
         super().__init__(daemon=True)
         from ov2slam_amd import frontend as fe, local_ba, synth_ba
-        self.ctx = fe.Context(device)
+        self.ctx = fe.Context(device, high_priority=True)   # small latency-critical grids next to the front-end
         self.opt = local_ba.Optimizer(self.ctx)
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
         self.opt.localBA(self.P0.copy())          # warm-up (allocations, code objects)

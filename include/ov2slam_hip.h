@@ -44,6 +44,9 @@ typedef struct ov2_pyr ov2_pyr;        /* ref-counted device pyramid(s): B x lev
 
 /* ---- context --------------------------------------------------------------------------------- */
 ov2_status ov2_ctx_create(int device, ov2_ctx **out);
+/* high_priority != 0 creates the ctx stream at the highest HIP stream priority: for the latency-critical, small-grid
+ * caller (the Estimator / localBA thread) that shares the GPU with the front-end's large grids. */
+ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx **out);
 void ov2_ctx_destroy(ov2_ctx *ctx);
 const char *ov2_last_error(const ov2_ctx *ctx);
 const char *ov2_status_string(ov2_status s);

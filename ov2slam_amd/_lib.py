@@ -17,6 +17,7 @@ fp = C.POINTER(C.c_float)
 # name -> (restype, argtypes).  Must list every symbol of include/ov2slam_hip.h (tests check this).
 SIGNATURES = {
     "ov2_ctx_create": (C.c_int, [C.c_int, vpp]),
+    "ov2_ctx_create_ex": (C.c_int, [C.c_int, C.c_int, vpp]),
     "ov2_ctx_destroy": (None, [vp]),
     "ov2_last_error": (C.c_char_p, [vp]),
     "ov2_status_string": (C.c_char_p, [C.c_int]),

@@ -469,8 +469,8 @@ __device__ inline void add_block(double *S, int m, int fp, int fq, const double 
 #define BA_MAX_RUNS 40   // distinct free observing poses per landmark handled in registers/scratch per thread
 
 template <int E>
-__global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restrict__ Wbuf /* n_e x (RUNS+1) x 6E */,
-                                                      int *__restrict__ Wf /* n_e x (RUNS+1) */)
+__global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restrict__ Wbuf /* n_e x wstride x 6E */,
+                                                      int *__restrict__ Wf /* n_e x wstride */, int wstride)
 {
     const int l = blockIdx.x * 64 + threadIdx.x;
     if (l >= d.n_e) return;
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restri
     for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
 
     // second pass: per (landmark, pose) run aggregation, then the outer products
-    double *W = Wbuf + (size_t)l * (BA_MAX_RUNS + 1) * 6 * E;
-    int *wf = Wf + (size_t)l * (BA_MAX_RUNS + 1);
+    double *W = Wbuf + (size_t)l * wstride * 6 * E;
+    int *wf = Wf + (size_t)l * wstride;
     int nruns = 0, cur = -1, fa_seen = -1;
     double Wk[6 * E], vk[6], FkFk[36], FkFa[36];
     double Wa[6 * E], va[6], FaFa[36];
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restri
         for (int i = 0; i < 6; ++i) atomicAdd(&d.rhs[f * 6 + i], vk[i]);
         add_block(d.S, d.m, f, f, FkFk, 1.0);
         if (fa_seen >= 0) add_block(d.S, d.m, f, fa_seen, FkFa, 1.0);
-        if (nruns < BA_MAX_RUNS) {
+        if (nruns < wstride - 1) {
             for (int i = 0; i < 6 * E; ++i) W[nruns * 6 * E + i] = Wk[i];
             wf[nruns] = f;
             ++nruns;
@@ -587,6 +587,333 @@ __global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------------
+// 16-lane-group kernels: one DPP row (16 lanes) per landmark, lane = residual row (chunks of 16), coalesced row
+// loads, reductions by DPP inside the row (no LDS, no cross-wave traffic).  These replace the thread-per-landmark
+// kernels above on the hot path (kept for reference / fallback of exotic shapes).
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)   // lane must be wave-uniform
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// sum over the 16 lanes of a DPP row; every lane of the row receives the total (fixed order => reproducible)
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return v;
+}
+
+template <int E>
+__device__ __forceinline__ void invert_ete(const double *ete, double *ie)
+{
+    if (E == 1) {
+        ie[0] = 1.0 / ete[0];
+    } else {
+        const double a = ete[0], b = ete[1], c = ete[2], dd = ete[4], ee = ete[5], f = ete[8];
+        const double A = dd * f - ee * ee, B = c * ee - b * f, C = b * ee - c * dd;
+        const double id = 1.0 / (a * A + b * B + c * C);
+        ie[0] = A * id; ie[1] = B * id; ie[2] = C * id;
+        ie[3] = B * id; ie[4] = (a * f - c * c) * id; ie[5] = (b * c - a * ee) * id;
+        ie[6] = C * id; ie[7] = ie[5]; ie[8] = (a * dd - b * b) * id;
+    }
+}
+
+// column norms + gradient of the landmark (E) columns: 16 lanes per landmark, no atomics
+__global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d)
+{
+    const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const bool live = l < d.n_e;
+    const int e = d.e;
+    const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
+    double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        if (r < r1) {
+            const double *Je = d.Je + (size_t)r * 2 * e;
+            const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+            for (int c = 0; c < e; ++c) { se[c] += Je[c] * Je[c] + Je[e + c] * Je[e + c]; ge[c] += Je[c] * b0 + Je[e + c] * b1; }
+        }
+    }
+    for (int c = 0; c < e; ++c) { se[c] = row_sum(se[c]); ge[c] = row_sum(ge[c]); }
+    if (live && sub == 0)
+        for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
+}
+
+// column norms + gradient of the pose (F) columns: one workgroup per free pose gathers its cells through the
+// pose -> (row, cell) CSR built on the host.  No atomics (the per-pose sums are the most contended addresses of the
+// whole solve), fixed summation order => bitwise reproducible.
+__global__ __launch_bounds__(256) void ba_colnorm_pose_kernel(ba_dev d, const int *__restrict__ pose_ptr,
+                                                              const int *__restrict__ pose_ent)
+{
+    __shared__ double sh[4][12];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    double acc[12];
+    for (int c = 0; c < 12; ++c) acc[c] = 0.0;
+    for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
+        const int ent = pose_ent[k], r = ent >> 1;
+        const double *Jf = d.Jf + (size_t)r * 24 + (ent & 1) * 12;
+        const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+        for (int c = 0; c < 6; ++c) {
+            acc[c] += Jf[c] * Jf[c] + Jf[6 + c] * Jf[6 + c];
+            acc[6 + c] += Jf[c] * b0 + Jf[6 + c] * b1;
+        }
+    }
+    for (int c = 0; c < 12; ++c) {
+        const double v = row_sum(acc[c]);
+        const double w = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+        if ((tid & 63) == 0) sh[tid >> 6][c] = w;
+    }
+    __syncthreads();
+    if (tid < 12) {
+        const double t = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+        const int ne = d.n_e * d.e;
+        if (tid < 6) d.sqn[ne + f * 6 + tid] = t;
+        else d.grad[ne + f * 6 + tid - 6] = t;
+    }
+}
+
+// Schur elimination, 16 lanes per landmark.  W (= F'E per pose cell) goes through dynamic LDS.
+// f64 atomics are request-rate bound when every lane hits its own 64-B line (measured: ~20 G adds/s), so all 16
+// lanes of a group work on ONE 6x6 block at a time, consecutive lanes on consecutive addresses of a column of the
+// column-major S: a block costs ~3 memory-side requests per 16 adds instead of 16.
+__constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+__constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+
+template <int E>
+__global__ __launch_bounds__(256) void ba_schur16_kernel(ba_dev d, int wstride)
+{
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    constexpr int REC = 6 * E + 2;   // per cell: W (6 x E), F block id, first row of the run (-1 for the anchor cell)
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int l = blockIdx.x * (blockDim.x >> 4) + grp;
+    const bool live = l < d.n_e;
+    const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
+    double *W = wlds + (size_t)grp * wstride * REC;
+    const int m = d.m;
+    // ---- pass 1: E'E and E'b
+    double ete[E * E], g[E];
+    for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
+    for (int i = 0; i < E; ++i) g[i] = 0.0;
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        if (r < r1) {
+            const double *Je = d.Je + (size_t)r * 2 * E;
+            const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+            for (int i = 0; i < E; ++i) {
+                for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
+                g[i] += Je[i] * b0 + Je[E + i] * b1;
+            }
+        }
+    }
+    for (int i = 0; i < E * E; ++i) ete[i] = row_sum(ete[i]);
+    for (int i = 0; i < E; ++i) g[i] = row_sum(g[i]);
+    if (live) for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] += dv * dv; }
+    else for (int i = 0; i < E; ++i) ete[i * E + i] = 1.0;
+    double ie[E * E], ieg[E];
+    invert_ete<E>(ete, ie);
+    for (int i = 0; i < E; ++i) {
+        double sacc = 0;
+        for (int j = 0; j < E; ++j) sacc += ie[i * E + j] * g[j];
+        ieg[i] = sacc;
+    }
+    if (live && sub == 0) {
+        for (int i = 0; i < E * E; ++i) d.iete[(size_t)l * E * E + i] = ie[i];
+        for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
+    }
+    // ---- pass 2a: W = F'E of every pose cell -> LDS (observing cells by the first row of each run, anchor by row_sum)
+    double Wa[6 * E];
+    for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
+    int fa_seen = -1, ncell = 0;
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        const bool have = r < r1;
+        const int fk = have ? d.fk[r] : -1, fa = have ? d.fa[r] : -1;
+        const bool leader = have && fk >= 0 && (r == r0 || d.fk[r - 1] != fk);
+        const unsigned long long lmk = __ballot(leader);
+        const unsigned rowmask = (unsigned)((lmk >> (threadIdx.x & 48)) & 0xffffu);
+        const int slot = ncell + __popc(rowmask & ((1u << sub) - 1u));
+        if (have) {
+            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+            if (fa >= 0) {
+                fa_seen = fa;
+                for (int i = 0; i < 6; ++i)
+                    for (int c = 0; c < E; ++c) Wa[i * E + c] += Jf[12 + i] * Je[c] + Jf[18 + i] * Je[E + c];
+            }
+            if (leader && slot < wstride - 1) {
+                double Wk[6 * E];
+                for (int i = 0; i < 6 * E; ++i) Wk[i] = 0.0;
+                for (int r2 = r; r2 < r1 && d.fk[r2] == fk; ++r2) {
+                    const double *Je2 = d.Je + (size_t)r2 * 2 * E, *J2 = d.Jf + (size_t)r2 * 24;
+                    for (int i = 0; i < 6; ++i)
+                        for (int c = 0; c < E; ++c) Wk[i * E + c] += J2[i] * Je2[c] + J2[6 + i] * Je2[E + c];
+                }
+                for (int i = 0; i < 6 * E; ++i) W[slot * REC + i] = Wk[i];
+                W[slot * REC + 6 * E] = (double)fk;
+                W[slot * REC + 6 * E + 1] = (double)r;
+            }
+        }
+        ncell += __popc(rowmask);
+    }
+    for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
+    int fam = fa_seen;
+    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0xB1, 0xf, 0xf, false));
+    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x4E, 0xf, 0xf, false));
+    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x141, 0xf, 0xf, false));
+    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x140, 0xf, 0xf, false));
+    ncell = min(ncell, wstride - 1);
+    const int nobs = ncell;   // observing cells; the anchor cell (if any) comes last
+    if (live && fam >= 0) {
+        if (sub == 0) {
+            for (int i = 0; i < 6 * E; ++i) W[ncell * REC + i] = Wa[i];
+            W[ncell * REC + 6 * E] = (double)fam;
+            W[ncell * REC + 6 * E + 1] = -1.0;
+        }
+        ++ncell;
+    }
+    __syncthreads();
+    // ---- pass 2b: F'F, F'Fa and F'(b - E (E'E)^-1 g) of every cell, the 16 lanes share one cell at a time
+    for (int c = 0; c < nobs; ++c) {
+        const int fk = (int)W[c * REC + 6 * E], rs = (int)W[c * REC + 6 * E + 1];
+        for (int t = sub; t < 63; t += 16) {
+            int i, j, kind;   // kind 0: rhs[i] ; 1: F'F lower (i,j) ; 2: F'Fa (i,j)
+            if (t < 6) { kind = 0; i = t; j = 0; }
+            else if (t < 27) { kind = 1; i = c_tri_i[t - 6]; j = c_tri_j[t - 6]; }
+            else { kind = 2; i = (t - 27) % 6; j = (t - 27) / 6; }
+            if (kind == 2 && fam < 0) continue;
+            double v = 0.0;
+            for (int r2 = rs; r2 < r1 && d.fk[r2] == fk; ++r2) {
+                const double *J2 = d.Jf + (size_t)r2 * 24;
+                if (kind == 0) {
+                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
+                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
+                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
+                    v += J2[i] * t0 + J2[6 + i] * t1;
+                } else if (kind == 1) {
+                    v += J2[i] * J2[j] + J2[6 + i] * J2[6 + j];
+                } else if (d.fa[r2] >= 0) {
+                    v += J2[i] * J2[12 + j] + J2[6 + i] * J2[18 + j];
+                }
+            }
+            if (kind == 0) atomicAdd(&d.rhs[fk * 6 + i], v);
+            else if (kind == 1) atomicAdd(&d.S[(size_t)(fk * 6 + j) * m + fk * 6 + i], v);
+            else if (fk >= fam) atomicAdd(&d.S[(size_t)(fam * 6 + j) * m + fk * 6 + i], v);
+            else atomicAdd(&d.S[(size_t)(fk * 6 + i) * m + fam * 6 + j], v);
+        }
+    }
+    if (live && fam >= 0) {   // anchor cell: sums over every row of the landmark
+        for (int t = sub; t < 27; t += 16) {
+            const int i = (t < 6) ? t : c_tri_i[t - 6], j = (t < 6) ? 0 : c_tri_j[t - 6];
+            double v = 0.0;
+            for (int r2 = r0; r2 < r1; ++r2) {
+                if (d.fa[r2] < 0) continue;
+                const double *J2 = d.Jf + (size_t)r2 * 24;
+                if (t < 6) {
+                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
+                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
+                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
+                    v += J2[12 + i] * t0 + J2[18 + i] * t1;
+                } else {
+                    v += J2[12 + i] * J2[12 + j] + J2[18 + i] * J2[18 + j];
+                }
+            }
+            if (t < 6) atomicAdd(&d.rhs[fam * 6 + i], v);
+            else atomicAdd(&d.S[(size_t)(fam * 6 + j) * m + fam * 6 + i], v);
+        }
+    }
+    // ---- pass 2c: S -= W_p (E'E)^-1 W_q^T over all cell pairs p <= q (ChunkOuterProduct), one block at a time
+    for (int p = 0; p < ncell; ++p) {
+        const double *Wp = W + p * REC;
+        const int fp = (int)Wp[6 * E];
+        for (int q = p; q < ncell; ++q) {
+            const double *Wq = W + q * REC;
+            const int fq = (int)Wq[6 * E];
+            if (p == q) {
+                for (int t = sub; t < 21; t += 16) {
+                    const int i = c_tri_i[t], j = c_tri_j[t];
+                    double v = 0.0;
+                    for (int k = 0; k < E; ++k)
+                        for (int cc = 0; cc < E; ++cc) v += Wp[i * E + k] * ie[k * E + cc] * Wq[j * E + cc];
+                    atomicAdd(&d.S[(size_t)(fp * 6 + j) * m + fp * 6 + i], -v);
+                }
+            } else {
+                for (int t = sub; t < 36; t += 16) {
+                    // element (p_i, q_j); lanes run along the contiguous direction of the lower-triangle copy
+                    int i, j;
+                    if (fp >= fq) { i = t % 6; j = t / 6; } else { j = t % 6; i = t / 6; }
+                    double v = 0.0;
+                    for (int k = 0; k < E; ++k)
+                        for (int cc = 0; cc < E; ++cc) v += Wp[i * E + k] * ie[k * E + cc] * Wq[j * E + cc];
+                    if (fp >= fq) atomicAdd(&d.S[(size_t)(fq * 6 + j) * m + fp * 6 + i], -v);
+                    else atomicAdd(&d.S[(size_t)(fp * 6 + i) * m + fq * 6 + j], -v);
+                }
+            }
+        }
+    }
+}
+
+// back-substitution + model cost change, 16 lanes per landmark
+template <int E>
+__global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__restrict__ part)
+{
+    const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const bool live = l < d.n_e;
+    const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
+    double acc[E];
+    for (int i = 0; i < E; ++i) acc[i] = 0.0;
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        if (r < r1) {
+            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+            double sj0 = d.res[2 * r], sj1 = d.res[2 * r + 1];
+            const int fk = d.fk[r], fa = d.fa[r];
+            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; sj0 -= Jf[c] * z; sj1 -= Jf[6 + c] * z; }
+            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; sj0 -= Jf[12 + c] * z; sj1 -= Jf[18 + c] * z; }
+            for (int i = 0; i < E; ++i) acc[i] += Je[i] * sj0 + Je[E + i] * sj1;
+        }
+    }
+    double y[E];
+    for (int i = 0; i < E; ++i) acc[i] = row_sum(acc[i]);
+    for (int i = 0; i < E; ++i) {
+        double s = 0;
+        for (int j = 0; j < E; ++j) s += (live ? d.iete[(size_t)l * E * E + i * E + j] : 0.0) * acc[j];
+        y[i] = s;
+    }
+    double mc = 0.0;
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        if (r < r1) {
+            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+            double m0 = 0.0, m1 = 0.0;
+            for (int i = 0; i < E; ++i) { m0 -= Je[i] * y[i]; m1 -= Je[E + i] * y[i]; }
+            const int fk = d.fk[r], fa = d.fa[r];
+            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; m0 -= Jf[c] * z; m1 -= Jf[6 + c] * z; }
+            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; m0 -= Jf[12 + c] * z; m1 -= Jf[18 + c] * z; }
+            mc += m0 * (d.res[2 * r] + m0 / 2.0) + m1 * (d.res[2 * r + 1] + m1 / 2.0);
+        }
+    }
+    mc = row_sum(mc);
+    if (live && sub == 0) {
+        for (int i = 0; i < E; ++i) d.step[l * E + i] = -y[i];
+        part[l] = mc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K_CHOL: dense Cholesky of the reduced camera system by one workgroup (schur_complement_solver.cc:217-229 does an
 // Eigen LLT; :319-355 a sparse one -- same factor).  Column-major, lower triangle.  Left-looking, panels of NB
 // columns held in LDS; the right-hand side rides along as row m, so the forward substitution is free; the backward
@@ -600,9 +927,9 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
     const int tid = threadIdx.x, nth = blockDim.x;
     const int M1 = m + 1;               // augmented row count (row m = right-hand side)
     constexpr int PS = NB + 1;          // panel row stride (bank spread)
-    constexpr int KC = 32, HALF = NB / 2;
+    constexpr int KC = 64, HALF = NB / 2;
     double *P = lds;                    // panel: rows x NB
-    double *Lj = lds + (size_t)M1 * PS; // NB x KC chunk of the previous columns of rows j0..j0+nb
+    double *Lj = lds + (((size_t)M1 * PS + 1) & ~(size_t)1); // 16-B aligned; KC x NB chunk of the previous columns of rows j0..j0+nb  ([kk][c])
     volatile int *failp = reinterpret_cast<volatile int *>(Lj + NB * KC);
     if (tid == 0) *failp = 0;
     __syncthreads();
@@ -619,9 +946,9 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
         const int groups = (rows * 2 <= nth) ? 2 : 1;
         for (int k0 = 0; k0 < j0; k0 += KC) {
             const int kc = min(KC, j0 - k0);
-            for (int idx = tid; idx < nb * kc; idx += nth) {
-                const int kk = idx / nb, c = idx - kk * nb;
-                Lj[c * KC + kk] = A[(size_t)(k0 + kk) * m + j0 + c];
+            for (int idx = tid; idx < NB * KC; idx += nth) {
+                const int kk = idx / NB, c = idx - kk * NB;
+                Lj[idx] = (kk < kc && c < nb) ? A[(size_t)(k0 + kk) * m + j0 + c] : 0.0;
             }
             __syncthreads();
             for (int w = tid; w < rows * groups; w += nth) {
@@ -632,11 +959,23 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
                     double acc[HALF];
 #pragma unroll
                     for (int c = 0; c < HALF; ++c) acc[c] = 0.0;
-                    for (int kk = 0; kk < kc; ++kk) {
-                        // row m (rhs) of previous columns lives in rhs[] after their panel was written back
-                        const double lik = (gi < m) ? A[(size_t)(k0 + kk) * m + gi] : rhs[k0 + kk];
+                    // row m (rhs) of previous columns lives in rhs[] after their panel was written back
+                    const double *src = (gi < m) ? (A + (size_t)k0 * m + gi) : (rhs + k0);
+                    const size_t sstep = (gi < m) ? (size_t)m : 1;
+                    // register double buffer of 16 L[i][k] values: the next batch is in flight while this one is used
+                    double cur[16], nxt[16];
 #pragma unroll
-                        for (int c = 0; c < HALF; ++c) acc[c] += lik * Lj[(c0 + c) * KC + kk];
+                    for (int u = 0; u < 16; ++u) cur[u] = (u < kc) ? src[(size_t)u * sstep] : 0.0;
+                    for (int kk0 = 0; kk0 < kc; kk0 += 16) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) nxt[u] = (kk0 + 16 + u < kc) ? src[(size_t)(kk0 + 16 + u) * sstep] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                            for (int c = 0; c < HALF; ++c) acc[c] += cur[u] * Lj[(kk0 + u) * NB + c0 + c];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
                     }
 #pragma unroll
                     for (int c = 0; c < HALF; ++c)
@@ -645,26 +984,52 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
             }
             __syncthreads();
         }
-        // factor the panel (right-looking inside the panel)
-        for (int c = 0; c < nb; ++c) {
-            const double dkk = P[c * PS + c];
-            if (!(dkk > 0.0) && tid == 0) *failp = 1;
-            __syncthreads();
-            if (*failp) break;
-            const double dsq = sqrt(dkk);
-            for (int i = tid; i < rows; i += nth) {
-                if (i == c) P[i * PS + c] = dsq;
-                else if (i > c) P[i * PS + c] /= dsq;
+        // (a) the nb x nb diagonal block: ONE wave, lane i keeps row i in registers, pivots travel by v_readlane
+        if (tid < 64) {
+            double row[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) row[c] = (tid < nb && c < nb) ? P[tid * PS + c] : ((tid == c) ? 1.0 : 0.0);
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const double dcc = readlane_f64(row[c], c);
+                if (c < nb && !(dcc > 0.0)) bad = 1;
+                const double dsq = sqrt(dcc > 0.0 ? dcc : 1.0);
+                row[c] = (tid == c) ? dsq : row[c] / dsq;
+#pragma unroll
+                for (int c2 = c + 1; c2 < NB; ++c2) {
+                    const double l = readlane_f64(row[c], c2);
+                    row[c2] -= row[c] * l;      // rows above the diagonal collect garbage that is never read
+                }
             }
-            __syncthreads();
-            const int wc = nb - c - 1;
-            for (int idx = tid; idx < (rows - c - 1) * wc; idx += nth) {
-                const int i = c + 1 + idx / wc, c2 = c + 1 + idx % wc;
-                if (i >= c2) P[i * PS + c2] -= P[i * PS + c] * P[c2 * PS + c];
+            if (tid < nb) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c <= tid && c < nb) P[tid * PS + c] = row[c];
             }
-            __syncthreads();
+            if (bad && tid == 0) *failp = 1;
         }
+        __syncthreads();
         if (*failp) break;
+        // (b) rows below the block (and the rhs row): x L_D^T = P[i,:], forward substitution, one thread per row
+        for (int i = nb + tid; i < rows; i += nth) {
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? P[i * PS + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= x[k] * P[c * PS + k];
+                    x[c] = v / P[c * PS + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) P[i * PS + c] = x[c];
+        }
+        __syncthreads();
         for (int idx = tid; idx < rows * nb; idx += nth) {
             const int c = idx / rows, i = idx - c * rows;
             const int gi = j0 + i;
@@ -679,18 +1044,40 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
     }
     __threadfence_block();
     __syncthreads();
-    // backward substitution L^T z = y by ONE wave (wave-synchronous, no workgroup barriers): z kept in LDS
-    if (tid < 64) {
-        volatile double *zb = lds;
-        for (int i = tid; i < m; i += 64) zb[i] = rhs[i];
-        for (int j = m - 1; j >= 0; --j) {
-            double s = 0.0;
-            for (int i = j + 1 + tid; i < m; i += 64) s += A[(size_t)j * m + i] * zb[i];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (tid == 0) zb[j] = (zb[j] - s) / A[(size_t)j * m + j];
-            __builtin_amdgcn_wave_barrier();
+    // backward substitution L^T z = y, panel by panel from the bottom: (1) every wave takes panel columns and forms
+    // t_c = sum_{i below the panel} L[i][c] z[i] with coalesced column reads, (2) wave 0 solves the nb x nb triangle
+    // with the block's columns in registers (pivots by v_readlane).  z lives in LDS.
+    {
+        double *zb = lds, *tpart = lds + m;
+        const int lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+        for (int i = tid; i < m; i += nth) zb[i] = rhs[i];
+        __syncthreads();
+        for (int j0 = ((m - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+            const int nb = min(NB, m - j0);
+            for (int c = wave; c < nb; c += nwaves) {
+                double sacc = 0.0;
+                for (int i = j0 + nb + lane; i < m; i += 64) sacc += A[(size_t)(j0 + c) * m + i] * zb[i];
+                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+                if (lane == 0) tpart[c] = sacc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                double y = (lane < nb) ? zb[j0 + lane] - tpart[lane] : 0.0;
+                double colD[NB];   // lane i: colD[j] = L[j0+j][j0+i], j >= i
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    colD[j] = (lane < nb && j < nb && j >= lane) ? A[(size_t)(j0 + lane) * m + j0 + j] : ((j == lane) ? 1.0 : 0.0);
+#pragma unroll
+                for (int j = NB - 1; j >= 0; --j) {
+                    const double zj = readlane_f64(y, j) / readlane_f64(colD[j], j);
+                    if (lane == j) y = zj;
+                    else if (lane < j) y -= colD[j] * zj;
+                }
+                if (lane < nb) zb[j0 + lane] = y;
+            }
+            __syncthreads();
         }
-        for (int i = tid; i < m; i += 64) rhs[i] = zb[i];
+        for (int i = tid; i < m; i += nth) rhs[i] = zb[i];
     }
 }
 
@@ -809,22 +1196,24 @@ struct ba_workspace {
     size_t next = 0;
 };
 
+// device memory of a solve is carved from one arena owned by the ctx and kept across solves (no hipMalloc/hipFree on
+// the keyframe path); ov2_ba_solve sizes it from an upper bound before the first carve.
 template <typename T>
-ov2_status dalloc(ov2_ctx *c, std::vector<void *> &owned, T **out, size_t n)
+ov2_status dalloc(ov2_ctx *c, size_t &off, T **out, size_t n)
 {
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA hipMalloc(%zu)", n * sizeof(T));
-    owned.push_back(p);
-    *out = (T *)p;
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) / 256 * 256;
+    if (off + bytes > c->ba_arena_cap)
+        return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena exhausted (%zu + %zu > %zu)", off, bytes, c->ba_arena_cap);
+    *out = (T *)((char *)c->ba_arena + off);
+    off += bytes;
     return OV2_OK;
 }
 
 template <typename T>
-ov2_status dupload(ov2_ctx *c, std::vector<void *> &owned, const T **out, const std::vector<T> &v)
+ov2_status dupload(ov2_ctx *c, size_t &off, const T **out, const std::vector<T> &v)
 {
     T *p = nullptr;
-    ov2_status s = dalloc(c, owned, &p, v.size());
+    ov2_status s = dalloc(c, off, &p, v.size());
     if (s != OV2_OK) return s;
     if (!v.empty()) OV2_HIP(c, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
     *out = p;
@@ -835,8 +1224,9 @@ struct ba_solver {
     ov2_ctx *c;
     const ov2_ba_problem *P;
     const ov2_ba_options *o;
-    std::vector<void *> owned;
+    size_t arena_off = 0;
     ba_dev d;
+    int wstride = 1;             // cells (runs + anchor) reserved per landmark in Wbuf / Wf
     std::vector<int> order;      // sorted row -> original residual index
     double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states
     double *Wbuf = nullptr;
@@ -844,13 +1234,10 @@ struct ba_solver {
     double *chi2_dev = nullptr;
     unsigned char *depth_dev = nullptr;
     int eval_blocks = 0;
+    const int *pose_ptr = nullptr, *pose_ent = nullptr;   // pose -> (row*2 + cell) CSR
     std::vector<double> h_pose, h_lm;   // "parameters_": best state so far
     std::vector<int> h_pose_of_f;
 
-    ~ba_solver()
-    {
-        for (void *p : owned) (void)hipFree(p);
-    }
 };
 
 #define BA_LAUNCH(S, id, ...) OV2_LAUNCH((S).c, id, __VA_ARGS__)
@@ -891,13 +1278,17 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     d.n_rows = (int)rows.size(); d.n_pose = P->n_pose; d.n_lm = P->n_lm;
     d.m = 6 * d.n_f; d.nc = d.n_e * e + d.m;
     // rows sorted by (landmark block, observing pose) -- LexicographicallyOrderResidualBlocks + run aggregation
-    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) {
-        const int ea = eidx[P->res_lm[a]], eb = eidx[P->res_lm[b]];
-        if (ea != eb) return ea < eb;
-        const int fa = (P->res_type[a] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[a]];
-        const int fb = (P->res_type[b] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[b]];
-        return fa < fb;
-    });
+    {
+        std::vector<int> cnt(d.n_e + 1, 0), sorted(rows.size());
+        for (int i : rows) cnt[eidx[P->res_lm[i]] + 1]++;
+        for (int k = 0; k < d.n_e; ++k) cnt[k + 1] += cnt[k];
+        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+        for (int i : rows) sorted[pos[eidx[P->res_lm[i]]]++] = i;          // stable counting sort by landmark block
+        auto fkey = [&](int i) { return (P->res_type[i] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[i]]; };
+        for (int k = 0; k < d.n_e; ++k)                                    // a handful of rows per landmark
+            std::stable_sort(sorted.begin() + cnt[k], sorted.begin() + cnt[k + 1], [&](int a, int b) { return fkey(a) < fkey(b); });
+        rows.swap(sorted);
+    }
     S.order = rows;
     const int n = d.n_rows;
     std::vector<unsigned char> type(n);
@@ -927,12 +1318,26 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     }
     if (max_runs > BA_MAX_RUNS)
         return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "a landmark is observed by %d free keyframes (max %d)", max_runs, BA_MAX_RUNS);
+    S.wstride = max_runs + 1;
+    std::vector<int> pose_ptr(d.n_f + 1, 0), pose_ent;
+    {
+        for (int r = 0; r < n; ++r) { if (fk[r] >= 0) pose_ptr[fk[r] + 1]++; if (fa[r] >= 0) pose_ptr[fa[r] + 1]++; }
+        for (int k = 0; k < d.n_f; ++k) pose_ptr[k + 1] += pose_ptr[k];
+        pose_ent.resize(pose_ptr[d.n_f]);
+        std::vector<int> pos(pose_ptr.begin(), pose_ptr.end() - 1);
+        for (int r = 0; r < n; ++r) {
+            if (fk[r] >= 0) pose_ent[pos[fk[r]]++] = 2 * r;
+            if (fa[r] >= 0) pose_ent[pos[fa[r]]++] = 2 * r + 1;
+        }
+    }
     ov2_status s;
-#define UP(field, vec) if ((s = dupload(c, S.owned, &d.field, vec)) != OV2_OK) return s
+#define UP(field, vec) if ((s = dupload(c, S.arena_off, &d.field, vec)) != OV2_OK) return s
     UP(type, type); UP(pose, pose); UP(lm, lm); UP(anch, anch); UP(eb, eb); UP(fk, fk); UP(fa, fa);
     UP(uv, uv); UP(inv_sigma, isg); UP(auv, auv); UP(row_ptr, row_ptr); UP(lm_of_e, lm_of_e); UP(pose_of_f, pose_of_f);
 #undef UP
-#define AL(field, count) if ((s = dalloc(c, S.owned, &d.field, (size_t)(count))) != OV2_OK) return s
+    if ((s = dupload(c, S.arena_off, &S.pose_ptr, pose_ptr)) != OV2_OK) return s;
+    if ((s = dupload(c, S.arena_off, &S.pose_ent, pose_ent)) != OV2_OK) return s;
+#define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
     AL(res, 2 * (size_t)n); AL(Je, 2 * (size_t)e * n); AL(Jf, 24 * (size_t)n);
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
     AL(S, (size_t)d.m * d.m); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
@@ -940,15 +1345,15 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     AL(part, std::max<size_t>({(size_t)S.eval_blocks, (size_t)d.n_e + d.n_f, 1}) * 2 + 16);
     AL(scal, SC_N + 2); AL(flags, 4);
 #undef AL
-    if ((s = dalloc(c, S.owned, &S.Wbuf, (size_t)d.n_e * (BA_MAX_RUNS + 1) * 6 * e)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.Wf, (size_t)d.n_e * (BA_MAX_RUNS + 1))) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.chi2_dev, (size_t)n)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.depth_dev, (size_t)n)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.Wbuf, (size_t)d.n_e * S.wstride * 6 * e)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.Wf, (size_t)d.n_e * S.wstride)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.chi2_dev, (size_t)n)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.depth_dev, (size_t)n)) != OV2_OK) return s;
     const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * e;
-    if ((s = dalloc(c, S.owned, &S.xp, np)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.cp, np)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.xl, nl)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.owned, &S.cl, nl)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.xp, np)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.cp, np)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.xl, nl)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.cl, nl)) != OV2_OK) return s;
     return OV2_OK;
 }
 
@@ -968,18 +1373,18 @@ ov2_status eval_jacobian(ba_solver &S, int use_loss, bool first)
     BA_LAUNCH(S, K_EVAL, ba_eval_kernel<true>, dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
               S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
     BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_COST, 1.0);
-    OV2_HIP(c, hipMemsetAsync(d.sqn, 0, sizeof(double) * d.nc, st));
-    OV2_HIP(c, hipMemsetAsync(d.grad, 0, sizeof(double) * d.nc, st));
-    BA_LAUNCH(S, K_COLNORM, ba_colnorm_kernel, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d);
+    auto colnorm = [&]() {
+        BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d);
+        if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_colnorm_pose_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent);
+    };
+    colnorm();
     if (first) {
         if (S.o->jacobi_scaling) {
             BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
             BA_LAUNCH(S, K_SCALE, ba_scale_rows_kernel, dim3(S.eval_blocks), dim3(256), 0, st, d);
             // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute
             // norms on it; its gradient is the scaled one, unscale it for the tolerance test
-            OV2_HIP(c, hipMemsetAsync(d.sqn, 0, sizeof(double) * d.nc, st));
-            OV2_HIP(c, hipMemsetAsync(d.grad, 0, sizeof(double) * d.nc, st));
-            BA_LAUNCH(S, K_COLNORM, ba_colnorm_kernel, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d);
+            colnorm();
             BA_LAUNCH(S, K_MISC, ba_unscale_grad_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, 1);
             BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
         } else {
@@ -1013,8 +1418,8 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
 {
     ov2_ctx *c = S.c;
     const ov2_ba_options *o = S.o;
-    ov2_status s = build_program(S, active);
-    if (s != OV2_OK) return s;
+    ov2_status s = OV2_OK;
+    (void)active;   // the program over the active rows was built by the caller (build_program)
     ba_dev &d = S.d;
     hipStream_t st = c->stream;
     *termination = OV2_BA_TERM_MAX_ITER;
@@ -1077,20 +1482,27 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
         } else {
             OV2_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int), st));
         }
-        if (e == 1) BA_LAUNCH(S, K_SCHUR, ba_schur_kernel<1>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, S.Wbuf, S.Wf);
-        else BA_LAUNCH(S, K_SCHUR, ba_schur_kernel<3>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, S.Wbuf, S.Wf);
+        {
+            // 16 lanes per landmark; W of every cell through dynamic LDS, groups per workgroup sized to <= 48 KiB
+            int groups = 16;
+            while (groups > 1 && (size_t)groups * S.wstride * (6 * e + 2) * 8 > 48 * 1024) groups >>= 1;
+            const size_t lds = (size_t)groups * S.wstride * (6 * e + 2) * 8;
+            const int nblk = (d.n_e + groups - 1) / groups;
+            if (e == 1) BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<1>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
+            else BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<3>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
+        }
         if (d.m > 0) {
             // panel width by LDS budget: (m+1) x (NB+1) + NB x 32 doubles <= 150 KiB
-            const size_t lds32 = ((size_t)(d.m + 1) * 33 + 32 * 32 + 2) * 8, lds16 = ((size_t)(d.m + 1) * 17 + 16 * 32 + 2) * 8,
-                         lds8 = ((size_t)(d.m + 1) * 9 + 8 * 32 + 2) * 8;
-            if (lds32 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(1024), lds32, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds16 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(1024), lds16, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds8 <= 150 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(1024), lds8, st, d.S, d.rhs, d.m, d.flags);
+            const size_t lds32 = ((size_t)(d.m + 1) * 33 + 32 * 64 + 4) * 8, lds16 = ((size_t)(d.m + 1) * 17 + 16 * 64 + 4) * 8,
+                         lds8 = ((size_t)(d.m + 1) * 9 + 8 * 64 + 4) * 8;
+            if (lds32 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(1024), lds32, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(1024), lds16, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(1024), lds8, st, d.S, d.rhs, d.m, d.flags);
             else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", d.m);
             BA_LAUNCH(S, K_MISC, ba_zstep_kernel, dim3((d.m + 255) / 256), dim3(256), 0, st, d);
         }
-        if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub_kernel<1>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, d.part);
-        else BA_LAUNCH(S, K_BACKSUB, ba_backsub_kernel<3>, dim3((d.n_e + 63) / 64), dim3(64), 0, st, d, d.part);
+        if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
+        else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
         BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, d.n_e, d.scal + SC_MODEL, -1.0);
         const int nb = d.n_e + d.n_f;
         double *part_step = d.part, *part_norm = d.part + nb;
@@ -1213,11 +1625,7 @@ ov2_status flag_outliers(ba_solver &S, std::vector<uint8_t> &active, ov2_ba_resu
     ov2_ctx *c = S.c;
     const ov2_ba_problem *P = S.P;
     *nbad = *n_left = *n_right = 0;
-    // program over the currently active rows (the previous minimize() left its program in S; rebuild for clarity)
-    for (void *p : S.owned) (void)hipFree(p);
-    S.owned.clear();
-    ov2_status s = build_program(S, active);
-    if (s != OV2_OK) return s;
+    // the program of the preceding minimize() covers exactly the currently active rows: reuse it
     ba_dev &d = S.d;
     if (d.n_rows == 0) return OV2_OK;
     hipStream_t st = c->stream;
@@ -1286,7 +1694,25 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
     S.h_lm.assign(P->lm, P->lm + (size_t)P->n_lm * e);
     std::vector<uint8_t> active(P->n_res, 1);
     const int use_loss = o->huber_delta > 0.0;
-    ov2_status s = minimize(S, active, use_loss, o->max_iters, R, &R->initial_cost, &R->final_cost, &R->termination);
+    // arena: upper bound of everything build_program carves for the full problem
+    {
+        const size_t n = (size_t)P->n_res, L = (size_t)P->n_lm, m6 = 6 * (size_t)P->n_pose;
+        const size_t cells = (size_t)std::min(BA_MAX_RUNS, P->n_pose) + 1;
+        const size_t need = n * 376 + L * (512 + cells * (6 * 3 * 8 + 4)) + m6 * m6 * 8 + (L * 3 + m6) * 64 +
+                            (size_t)P->n_pose * 7 * 16 + L * 3 * 16 + 64 * 256 + (1u << 20);
+        if (need > c->ba_arena_cap) {
+            OV2_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->ba_arena) OV2_HIP(c, hipFree(c->ba_arena));
+            c->ba_arena = nullptr; c->ba_arena_cap = 0;
+            const size_t want = need + need / 4;
+            hipError_t he = hipMalloc(&c->ba_arena, want);
+            if (he != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena hipMalloc(%zu): %s", want, hipGetErrorString(he));
+            c->ba_arena_cap = want;
+        }
+    }
+    ov2_status s = build_program(S, active);
+    if (s != OV2_OK) return s;
+    s = minimize(S, active, use_loss, o->max_iters, R, &R->initial_cost, &R->final_cost, &R->termination);
     if (s != OV2_OK) return s;
     R->n_log_robust = R->n_log;
     int nbad, nl, nr;
@@ -1294,8 +1720,9 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
     R->n_outliers_pass1 = nbad;
     if (o->l2_refine && use_loss && nbad > 0) {
         const int keep_loss = !(nl > 0 && nr > 0);   // src/optimizer.cpp:606-608
-        for (void *p : S.owned) (void)hipFree(p);
-        S.owned.clear();
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
+        S.arena_off = 0;                                   // re-carve the arena for the reduced program
+        if ((s = build_program(S, active)) != OV2_OK) return s;
         s = minimize(S, active, keep_loss, o->l2_max_iters, R, &R->l2_initial_cost, &R->l2_final_cost, &R->l2_termination);
         if (s != OV2_OK) return s;
         R->l2_done = 1;

@@ -30,7 +30,9 @@ extern "C" const char *ov2_status_string(ov2_status s)
 
 extern "C" const char *ov2_last_error(const ov2_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
-extern "C" ov2_status ov2_ctx_create(int device, ov2_ctx **out)
+extern "C" ov2_status ov2_ctx_create(int device, ov2_ctx **out) { return ov2_ctx_create_ex(device, 0, out); }
+
+extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx **out)
 {
     if (!out) return OV2_ERR_INVALID;
     *out = nullptr;
@@ -44,7 +46,11 @@ extern "C" ov2_status ov2_ctx_create(int device, ov2_ctx **out)
     c->scratch_bytes = 0;
     c->tmp_img = nullptr;
     c->ktime_on = false;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    c->ba_arena = nullptr;
+    c->ba_arena_cap = 0;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return OV2_ERR_HIP;
@@ -67,6 +73,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     for (auto &r : c->ktime_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ktime_free) (void)hipEventDestroy(e);
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
+    if (c->ba_arena) (void)hipFree(c->ba_arena);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);

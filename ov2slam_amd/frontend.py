@@ -23,10 +23,10 @@ def _check(ctx_handle, status):
 class Context:
     """one device + one HIP stream (reference: one per calling thread, T1 front-end / T3 mapper)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, high_priority=False):
         self.lib = _lib.load()
         h = C.c_void_p()
-        st = self.lib.ov2_ctx_create(device, C.byref(h))
+        st = self.lib.ov2_ctx_create_ex(device, int(bool(high_priority)), C.byref(h))
         if st != 0:
             raise _lib.Ov2Error(f"ov2_ctx_create(device={device}): {self.lib.ov2_status_string(st).decode()} -- "
                                 "an MI355X/gfx950 device is required, there is no CPU fallback")
