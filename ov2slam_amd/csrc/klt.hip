@@ -1,18 +1,21 @@
-// klt.hip -- forward-backward pyramidal Lucas-Kanade, one keypoint per 64-lane wavefront (gfx950).
+// klt.hip -- forward-backward pyramidal Lucas-Kanade, FOUR keypoints per 64-lane wavefront (gfx950).
 //
 // Replaces (reference, /root/reference): FeatureTracker::fbKltTracking src/feature_tracker.cpp:35-137
 // (= 2x cv::calcOpticalFlowPyrLK + the status / err / inBorder / forward-backward gates) and the two-stage
 // batching of VisualFrontEnd::kltTracking src/visual_front_end.cpp:132-275.
 // Arithmetic: OpenCV LKTrackerInvoker semantics as restated in oracle/ov2_oracle_fe.c -- 14-bit bilinear
 // weights (v_rndne == cvRound), CV_DESCALE fixed point, EXACT integer sums for A11/A12/A22/b1/b2 converted to
-// fp32 once (order independent, so the wave reduction is bit-identical to the oracle's scalar loop), fp32
+// fp32 once (order independent, so the lane reduction is bit-identical to the oracle's scalar loop), fp32
 // 2x2 solve with contraction off, fp64 for the two comparisons OpenCV does in double.
 //
-// Mapping: the (win x win <= 121) window pixels are spread over the 64 lanes (2 px per lane); the template
-// (I, Ix, Iy as int16 values) lives in registers for the whole level; every LK iteration is
-//   gather 2x4 u8 of J (L1/L2 resident, padded planes => no bounds logic)  ->  2 int32 MACs per lane
-//   ->  DPP row reduction (quad_perm, row_half_mirror, row_mirror) + 4 v_readlane + scalar int64 add
-//   ->  wave-uniform fp32 update.
+// Mapping (round-1 measurement: the one-keypoint-per-wave version spent ~200 wave-instructions per LK iteration,
+// most of them wave-uniform scalar work replicated on 64 lanes, and was VALU-issue bound): one keypoint per DPP
+// row of 16 lanes, lane = window column (win <= 11 of 16 lanes busy), each lane walks the win rows of its column.
+//   - every "scalar" of the LK update is per-row vector math, so the 4 keypoints of a wave share each instruction;
+//   - a column needs win+1 two-byte loads per iteration (row y+1's load is row y's lower neighbours);
+//   - sums over the window = DPP row reduction (quad_perm, row_half_mirror, row_mirror), no readlane, no LDS;
+//   - template (I, Ix, Iy per window pixel) stays in registers for the whole level;
+//   - 24-bit multiplies (v_mad_u32_u24 / v_mad_i32_i24) for the fixed-point bilinear taps.
 // The whole pyramid loop, the gates and the backward pass run inside one launch; no host round trip.
 #include "ov2_internal.h"
 
@@ -27,25 +30,40 @@ struct klt_params {
 };
 
 #define W_BITS 14
-__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 template <int CTRL>
-__device__ __forceinline__ int dpp_add(int v)
+__device__ __forceinline__ int dpp_i32(int v)
 {
-    // v + (v moved by the DPP pattern); all lanes active, bound_ctrl irrelevant for these patterns
-    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
 
-// exact wave sum of one int32 per lane whose 16-lane partial sums fit int32; result as int64, wave-uniform
-__device__ __forceinline__ long long wave_sum_i64(int v)
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int row_sum_i32(int v)
 {
-    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);  // row_half_mirror
-    v = dpp_add<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row total
-    const long long r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
-                    r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    v += dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_i32<0x141>(v);   // row_half_mirror
+    v += dpp_i32<0x140>(v);   // row_mirror
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64k(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// exact: the addends are integers below 2^32, every partial sum is an integer below 2^53
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v += dpp_f64k<0xB1>(v);
+    v += dpp_f64k<0x4E>(v);
+    v += dpp_f64k<0x141>(v);
+    v += dpp_f64k<0x140>(v);
+    return v;
 }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11)
@@ -56,167 +74,174 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
     w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
-__device__ __forceinline__ int bilin_u8(const unsigned char *p, int stride, int w00, int w01, int w10, int w11)
+__device__ __forceinline__ unsigned ld_u16(const unsigned char *p)
 {
-    // two unaligned 16-bit loads: (x,y),(x+1,y) and (x,y+1),(x+1,y+1)
-    unsigned short r0, r1;
-    __builtin_memcpy(&r0, p, 2);
-    __builtin_memcpy(&r1, p + stride, 2);
-    return (r0 & 255) * w00 + (r0 >> 8) * w01 + (r1 & 255) * w10 + (r1 >> 8) * w11;
+    unsigned short r;
+    __builtin_memcpy(&r, p, 2);   // unaligned 16-bit load: (x, x+1) of one row
+    return r;
 }
 
-// One LKTrackerInvoker pass for the wave's keypoint on one level.  All scalar state is wave-uniform.
-// returns the number of iterations executed.
-__device__ __forceinline__ int lk_level(const unsigned char *__restrict__ Iimg, const short *__restrict__ Igrad,
-                                        const unsigned char *__restrict__ Jimg, const ov2_level_desc &LI,
-                                        const ov2_level_desc &LJ, int pad, int level, int max_level, float kx,
-                                        float ky, float &nx_io, float &ny_io, int &status, float &err,
-                                        const klt_params &P, int lane)
+struct level_ptrs {
+    const unsigned char *img;
+    const int *grad;   // (Ix,Iy) int16 pair per pixel
+    int istride, gstride, w, h;
+};
+
+__device__ __forceinline__ level_ptrs level_of(const ov2_pyr_view &v, int l, int b)
+{
+    level_ptrs p;
+    const ov2_level_desc &L = v.lv[l];
+    p.img = v.base + L.img_off + L.img_bstride * b;
+    p.grad = reinterpret_cast<const int *>(v.base + L.grad_off + L.grad_bstride * b);
+    p.istride = L.istride; p.gstride = L.gstride; p.w = L.w; p.h = L.h;
+    return p;
+}
+
+// One LKTrackerInvoker pass (one pyramid level) for the keypoint of this DPP row.  `run` (row-uniform) says whether
+// the row takes part; everything below is row-uniform except the window column `sub`.  Returns iterations executed.
+template <int WIN>
+__device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
+                                          bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
+                                          float &err, const klt_params &P, int sub, unsigned &passes)
 {
     const float FLT_SCALE = 1.f / (float)(1 << 20);
-    const int win = P.win;
-    const float half = (float)(win - 1) * 0.5f;
+    const float half = (float)(WIN - 1) * 0.5f;
     const float lscale = 1.f / (float)(1 << level);
     float px = kx * lscale, py = ky * lscale;
     float nx, ny;
     if (level == max_level) { nx = nx_io * lscale; ny = ny_io * lscale; }
     else { nx = nx_io * 2.f; ny = ny_io * 2.f; }
-    nx_io = nx; ny_io = ny;
+    if (run) { nx_io = nx; ny_io = ny; }
 
     px -= half; py -= half;
     const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-    if (ipx < -win || ipx >= LI.w || ipy < -win || ipy >= LI.h) {
+    if (run && (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h)) {
         if (level == 0) { status = 0; err = 0.f; }
-        return 0;
+        run = false;
     }
+    if (!__any(run)) return 0;
+    if (run) passes += 1u;
     int w00, w01, w10, w11;
     lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
 
-    // window pixel(s) of this lane
-    const int npx = win * win;
-    const int q0 = lane, q1 = lane + 64;
-    const bool v0 = q0 < npx, v1 = q1 < npx;
-    const int wy0 = q0 / win, wx0 = q0 - wy0 * win;
-    const int wy1 = q1 / win, wx1 = q1 - wy1 * win;
-
-    int Iv0 = 0, Ix0 = 0, Iy0 = 0, Iv1 = 0, Ix1 = 0, Iy1 = 0;
+    // template of this lane's column: WIN pixels (I, Ix, Iy); lanes >= WIN and idle rows hold zeros
+    const bool col = sub < WIN;
+    const int sc = col ? sub : 0;
+    int Iv[WIN], Ixy[WIN];   // Ixy = Ix | Iy << 16 (both fit int16)
+    int sA11 = 0, sA12 = 0, sA22 = 0;
     {
-        const int sI = LI.istride, sG = LI.gstride;
-        if (v0) {
-            const size_t r = (size_t)(wy0 + ipy + pad);
-            const int c = OV2_LM + ipx + wx0;
-            Iv0 = descale(bilin_u8(Iimg + r * sI + c, sI, w00, w01, w10, w11), W_BITS - 5);
-            const int *g = reinterpret_cast<const int *>(Igrad) + r * sG + c;  // (Ix,Iy) packed in one dword
-            const int g00 = g[0], g01 = g[1], g10 = g[sG], g11 = g[sG + 1];
-            Ix0 = descale((short)(g00 & 0xffff) * w00 + (short)(g01 & 0xffff) * w01 + (short)(g10 & 0xffff) * w10 +
-                          (short)(g11 & 0xffff) * w11, W_BITS);
-            Iy0 = descale((g00 >> 16) * w00 + (g01 >> 16) * w01 + (g10 >> 16) * w10 + (g11 >> 16) * w11, W_BITS);
-        }
-        if (v1) {
-            const size_t r = (size_t)(wy1 + ipy + pad);
-            const int c = OV2_LM + ipx + wx1;
-            Iv1 = descale(bilin_u8(Iimg + r * sI + c, sI, w00, w01, w10, w11), W_BITS - 5);
-            const int *g = reinterpret_cast<const int *>(Igrad) + r * sG + c;
-            const int g00 = g[0], g01 = g[1], g10 = g[sG], g11 = g[sG + 1];
-            Ix1 = descale((short)(g00 & 0xffff) * w00 + (short)(g01 & 0xffff) * w01 + (short)(g10 & 0xffff) * w10 +
-                          (short)(g11 & 0xffff) * w11, W_BITS);
-            Iy1 = descale((g00 >> 16) * w00 + (g01 >> 16) * w01 + (g10 >> 16) * w10 + (g11 >> 16) * w11, W_BITS);
+        const int bx = run ? (OV2_LM + ipx + sc) : OV2_LM, by = run ? (ipy + pad) : pad;
+        const unsigned char *ip = I.img + (size_t)by * I.istride + bx;
+        const int *gp = I.grad + (size_t)by * I.gstride + bx;
+        unsigned t = ld_u16(ip);
+        int g0 = gp[0], g1 = gp[1];
+#pragma unroll
+        for (int y = 0; y < WIN; ++y) {
+            ip += I.istride; gp += I.gstride;
+            const unsigned bb = ld_u16(ip);
+            const int h0 = gp[0], h1 = gp[1];
+            // signed 24-bit taps: w11 = 2^14 - w00 - w01 - w10 can be -1 after rounding
+            const int iv = (__mul24((int)(t & 255u), w00) + __mul24((int)(t >> 8), w01) + __mul24((int)(bb & 255u), w10) +
+                            __mul24((int)(bb >> 8), w11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const int ix = (__mul24((short)(g0 & 0xffff), w00) + __mul24((short)(g1 & 0xffff), w01) +
+                            __mul24((short)(h0 & 0xffff), w10) + __mul24((short)(h1 & 0xffff), w11) + (1 << (W_BITS - 1))) >> W_BITS;
+            const int iy = (__mul24(g0 >> 16, w00) + __mul24(g1 >> 16, w01) + __mul24(h0 >> 16, w10) +
+                            __mul24(h1 >> 16, w11) + (1 << (W_BITS - 1))) >> W_BITS;
+            const bool on = run && col;
+            Iv[y] = on ? iv : 0;
+            Ixy[y] = on ? ((ix & 0xffff) | (iy << 16)) : 0;
+            if (on) { sA11 += ix * ix; sA12 += ix * iy; sA22 += iy * iy; }
+            t = bb; g0 = h0; g1 = h1;
         }
     }
-    // |Ix|,|Iy| <= 4080 for u8 images: 2 products per lane and 16-lane partial sums fit int32 exactly
-    const long long sA11 = wave_sum_i64(Ix0 * Ix0 + Ix1 * Ix1);
-    const long long sA12 = wave_sum_i64(Ix0 * Iy0 + Ix1 * Iy1);
-    const long long sA22 = wave_sum_i64(Iy0 * Iy0 + Iy1 * Iy1);
-    const float A11 = (float)(double)sA11 * FLT_SCALE;
-    const float A12 = (float)(double)sA12 * FLT_SCALE;
-    const float A22 = (float)(double)sA22 * FLT_SCALE;
+    // |Ix|,|Iy| <= 4080 for u8 images: WIN*WIN <= 121 products stay below 2^31 -> exact in int32
+    const float A11 = (float)(double)row_sum_i32(sA11) * FLT_SCALE;
+    const float A12 = (float)(double)row_sum_i32(sA12) * FLT_SCALE;
+    const float A22 = (float)(double)row_sum_i32(sA22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float min_eig = __fdiv_rn(A22 + A11 - __fsqrt_rn((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
-                                    (float)(2 * win * win));
-    err = min_eig;  // OPTFLOW_LK_GET_MIN_EIGENVALS
-    if (min_eig < P.min_eig_thr || D < 1.1920929e-07f /* FLT_EPSILON */) {
-        if (level == 0) status = 0;
-        return 0;
+                                    (float)(2 * WIN * WIN));
+    if (run) {
+        err = min_eig;  // OPTFLOW_LK_GET_MIN_EIGENVALS
+        if (min_eig < P.min_eig_thr || D < 1.1920929e-07f /* FLT_EPSILON */) {
+            if (level == 0) status = 0;
+            run = false;
+        }
     }
     D = __fdiv_rn(1.f, D);
 
     nx -= half; ny -= half;
     float pdx = 0.f, pdy = 0.f;
-    const int sJ = LJ.istride;
-    int j;
-    for (j = 0; j < P.max_iter; ++j) {
+    int iters = 0;
+    for (int j = 0; j < P.max_iter; ++j) {
+        if (!__any(run)) break;
         const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-        if (inx < -win || inx >= LJ.w || iny < -win || iny >= LJ.h) {
+        if (run && (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h)) {
             if (level == 0) status = 0;
-            break;
+            run = false;
         }
         lk_weights(nx - (float)inx, ny - (float)iny, w00, w01, w10, w11);
+        const unsigned char *jp = J.img + (size_t)((run ? iny : 0) + pad) * J.istride + OV2_LM + (run ? inx + sc : 0);
         int pb1 = 0, pb2 = 0;
-        if (v0) {
-            const int diff = descale(bilin_u8(Jimg + (size_t)(wy0 + iny + pad) * sJ + OV2_LM + inx + wx0, sJ, w00, w01,
-                                              w10, w11), W_BITS - 5) - Iv0;
-            pb1 = diff * Ix0; pb2 = diff * Iy0;
+        unsigned t = ld_u16(jp);
+#pragma unroll
+        for (int y = 0; y < WIN; ++y) {
+            jp += J.istride;
+            const unsigned bb = ld_u16(jp);
+            const int jv = (__mul24((int)(t & 255u), w00) + __mul24((int)(t >> 8), w01) + __mul24((int)(bb & 255u), w10) +
+                            __mul24((int)(bb >> 8), w11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const int diff = jv - Iv[y];
+            pb1 += __mul24(diff, (short)(Ixy[y] & 0xffff));   // |diff| <= 8160, |Ix| <= 4080
+            pb2 += __mul24(diff, Ixy[y] >> 16);
+            t = bb;
         }
-        if (v1) {
-            const int diff = descale(bilin_u8(Jimg + (size_t)(wy1 + iny + pad) * sJ + OV2_LM + inx + wx1, sJ, w00, w01,
-                                              w10, w11), W_BITS - 5) - Iv1;
-            pb1 += diff * Ix1; pb2 += diff * Iy1;
-        }
-        // |diff| <= 8160, |Ix| <= 4080: 2 products/lane <= 6.7e7, 16-lane partials <= 1.07e9 fit int32
-        const float b1 = (float)(double)wave_sum_i64(pb1) * FLT_SCALE;
-        const float b2 = (float)(double)wave_sum_i64(pb2) * FLT_SCALE;
+        // a lane holds <= 11 products of <= 3.4e7: fits int32; the row total may not, so sum exactly in f64
+        const float b1 = (float)row_sum_f64((double)pb1) * FLT_SCALE;
+        const float b2 = (float)row_sum_f64((double)pb2) * FLT_SCALE;
         const float dx = (A12 * b2 - A22 * b1) * D;
         const float dy = (A12 * b1 - A11 * b2) * D;
-        nx += dx; ny += dy;
-        nx_io = nx + half; ny_io = ny + half;
-        if ((double)dx * dx + (double)dy * dy <= P.eps2) { ++j; break; }
-        // std::abs(float) < 0.01 (double literal)  <=>  <= 0.01f
-        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-            nx_io -= dx * 0.5f; ny_io -= dy * 0.5f;
-            ++j; break;
+        if (run) {
+            ++iters;
+            nx += dx; ny += dy;
+            nx_io = nx + half; ny_io = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= P.eps2) run = false;
+            // std::abs(float) < 0.01 (double literal)  <=>  <= 0.01f
+            else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                nx_io -= dx * 0.5f; ny_io -= dy * 0.5f;
+                run = false;
+            }
+            pdx = dx; pdy = dy;
         }
-        pdx = dx; pdy = dy;
     }
-    return j;
+    return iters;
 }
 
-struct plane_ptrs {
-    const unsigned char *img;
-    const short *grad;
-};
-
-__device__ __forceinline__ plane_ptrs level_planes(const ov2_pyr_view &v, int l, int b)
-{
-    plane_ptrs p;
-    p.img = v.base + v.lv[l].img_off + v.lv[l].img_bstride * b;
-    p.grad = reinterpret_cast<const short *>(v.base + v.lv[l].grad_off + v.lv[l].grad_bstride * b);
-    return p;
-}
-
-// FeatureTracker::fbKltTracking for the wave's keypoint. returns status (0/1); fx,fy = forward result.
-__device__ __forceinline__ int fb_track_one(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, float kx, float ky,
-                                            float &fx, float &fy, const klt_params &P, int nlevels, int lane,
-                                            unsigned &iters)
+// FeatureTracker::fbKltTracking for the keypoint of this DPP row (act = row has a keypoint).
+// returns status (0/1); fx,fy = forward result; work = iterations | level passes << 16.
+template <int WIN>
+__device__ __forceinline__ int fb_track16(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx,
+                                          float ky, float &fx, float &fy, const klt_params &P, int nlevels, int sub,
+                                          unsigned &work)
 {
     int status = 1;
     float err = 0.f;
-    unsigned it = 0;
+    unsigned it = 0, passes = 0;
     for (int l = nlevels; l >= 0; --l) {
-        const plane_ptrs I = level_planes(pv, l, b), J = level_planes(cv, l, b);
-        it += lk_level(I.img, I.grad, J.img, pv.lv[l], cv.lv[l], pv.pad, l, nlevels, kx, ky, fx, fy, status, err, P, lane);
-        it += 1u << 16;  // one level pass (template fetch) -- high half of the work word
+        const level_ptrs I = level_of(pv, l, b), J = level_of(cv, l, b);
+        it += lk_level16<WIN>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes);
     }
     // gates of src/feature_tracker.cpp:79-101
     const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
-    int ok = status && !(err > P.err_th) &&
+    int ok = act && status && !(err > P.err_th) &&
              (1.f <= fx && fx < (float)W0 - 1.f && 1.f <= fy && fy < (float)H0 - 1.f);
+    // backward pass cur -> prev on level 0 from the original keypoint (src/feature_tracker.cpp:113)
+    int st2 = 1;
+    float e2 = 0.f, bx = kx, by = ky;
+    {
+        const level_ptrs I = level_of(cv, 0, b), J = level_of(pv, 0, b);
+        it += lk_level16<WIN>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes);
+    }
     if (ok) {
-        // backward pass cur -> prev on level 0 from the original keypoint (src/feature_tracker.cpp:113)
-        int st2 = 1;
-        float e2 = 0.f, bx = kx, by = ky;
-        const plane_ptrs I = level_planes(cv, 0, b), J = level_planes(pv, 0, b);
-        it += lk_level(I.img, I.grad, J.img, cv.lv[0], pv.lv[0], cv.pad, 0, 0, fx, fy, bx, by, st2, e2, P, lane);
-        it += 1u << 16;
         if (!st2) ok = 0;
         else {
             const float dx = kx - bx, dy = ky - by;
@@ -224,56 +249,82 @@ __device__ __forceinline__ int fb_track_one(const ov2_pyr_view &pv, const ov2_py
             if (nrm > P.fb_th) ok = 0;
         }
     }
-    iters = it;
+    work = it | (passes << 16);
     return ok;
 }
 
+// 64 threads = 4 keypoints.  grid = ceil(n / 4)
+template <int WIN>
 __global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                     const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                     unsigned char *__restrict__ status,
                                                     const int *__restrict__ img_idx, unsigned *__restrict__ iters)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
-    if (i >= n) return;
-    const int b = img_idx ? img_idx[i] : 0;
-    const float2 kp = kps[i];
-    float2 pr = priors[i];
-    unsigned it = 0;
-    const int ok = fb_track_one(pv, cv, b, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, lane, it);
-    if (lane == 0) {
+    const int sub = threadIdx.x & 15, i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const bool act = i < n;
+    const int ii = act ? i : 0;
+    const int b = img_idx ? img_idx[ii] : 0;
+    const float2 kp = kps[ii];
+    float2 pr = priors[ii];
+    unsigned work = 0;
+    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    if (act && sub == 0) {
         priors[i] = pr;
         status[i] = (unsigned char)ok;
-        if (iters) iters[i] = it;
+        if (iters) iters[i] = work;
     }
 }
 
 // ---- VisualFrontEnd::kltTracking, two stages without a host round trip -------------------------------
-// stage 1: keypoints with a prior, 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190)
-__global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
-                                                        const float2 *__restrict__ kps,
-                                                        const float2 *__restrict__ prior,
-                                                        const unsigned char *__restrict__ has_prior,
-                                                        const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
-                                                        unsigned char *__restrict__ out_status,
-                                                        unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
-                                                        unsigned *__restrict__ iters)
+// Only a fraction of the keypoints is live in each stage (those with a prior in stage 1; the rest + the stage-1
+// failures in stage 2).  A workgroup of 8 waves owns a window of 32 consecutive keypoints; every wave ballots the
+// same 32 liveness flags and the j-th live keypoint goes to DPP row j of the workgroup, so the launched waves are
+// full (instead of 30-70 % idle rows) and waves beyond the live count retire at once.  No atomics, no LDS.
+#define KLT_WINDOW 32
+
+__device__ __forceinline__ int nth_set_bit(unsigned m, int idx)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
-    if (i >= n) return;
-    const float2 kp = kps[i];
-    if (!has_prior[i]) {
-        if (lane == 0) { out_xy[i] = kp; out_status[i] = 0; if (iters) iters[i] = 0; }
-        return;
+    for (int t = 0; t < idx; ++t) m &= m - 1u;
+    return __ffs(m) - 1;
+}
+
+// stage 1: keypoints with a prior, 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190)
+template <int WIN>
+__global__ __launch_bounds__(512) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+                                                         const float2 *__restrict__ kps,
+                                                         const float2 *__restrict__ prior,
+                                                         const unsigned char *__restrict__ has_prior,
+                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
+                                                         unsigned char *__restrict__ out_status,
+                                                         unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
+                                                         unsigned *__restrict__ iters)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
+    const int base = blockIdx.x * KLT_WINDOW;
+    const int f = base + (lane & 31);
+    const bool live = f < n && has_prior[f] != 0;
+    if (wv == 0 && lane < 32 && f < n && !live) {   // no prior: stage 2 starts from the keypoint itself
+        out_xy[f] = kps[f];
+        out_status[f] = 0;
+        if (iters) iters[f] = 0;
     }
-    const int b = img_idx ? img_idx[i] : 0;
-    float2 pr = prior[i];
-    unsigned it = 0;
+    const unsigned m32 = (unsigned)(__ballot(live) & 0xffffffffull);
+    const int total = __popc(m32);
+    if (wv * 4 >= total) return;
+    const int idx = wv * 4 + row;
+    const bool act = idx < total;
+    const int i = base + (act ? nth_set_bit(m32, idx) : 0);
+    const int ii = min(i, n - 1);
+    const float2 kp = kps[ii];
+    const int b = img_idx ? img_idx[ii] : 0;
+    float2 pr = prior[ii];
+    unsigned work = 0;
     const int nl = min(1, pv.nlevels - 1);
-    const int ok = fb_track_one(pv, cv, b, kp.x, kp.y, pr.x, pr.y, P, nl, lane, it);
-    if (lane == 0) {
-        out_xy[i] = pr;  // tracked position, or the failed forward result that seeds stage 2 (:217-219)
+    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work);
+    if (act && sub == 0) {
+        out_xy[i] = pr;   // tracked position, or the failed forward result that seeds stage 2 (:217-219)
         out_status[i] = (unsigned char)ok;
-        if (iters) iters[i] = it;
+        if (iters) iters[i] = work;
         // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
         // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
         atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
@@ -281,34 +332,47 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
 }
 
 // stage 2: keypoints without prior + stage-1 failures, full pyramid (src/visual_front_end.cpp:237-270)
-__global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
-                                                        const float2 *__restrict__ kps,
-                                                        const unsigned char *__restrict__ has_prior,
-                                                        const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
-                                                        unsigned char *__restrict__ out_status,
-                                                        const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
-                                                        unsigned *__restrict__ iters)
+template <int WIN>
+__global__ __launch_bounds__(512) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+                                                         const float2 *__restrict__ kps,
+                                                         const unsigned char *__restrict__ has_prior,
+                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
+                                                         unsigned char *__restrict__ out_status,
+                                                         const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
+                                                         unsigned *__restrict__ iters)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
-    if (i >= n) return;
-    const int b = img_idx ? img_idx[i] : 0;
-    const unsigned cw = counts[64 * b + lane];
-    const int n3 = (int)wave_sum_i64((int)(cw & 0xffffu)), good = (int)wave_sum_i64((int)(cw >> 16));
-    const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
-    if (lane == 0 && p3p_req && drop) p3p_req[b] = 1;
-    const bool hp = has_prior[i] != 0;
-    if (hp && out_status[i]) {  // tracked in stage 1
-        if (lane == 0 && iters) iters[n + i] = 0;
-        return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
+    const int base = blockIdx.x * KLT_WINDOW;
+    const int f = base + (lane & 31);
+    const bool hpf = f < n && has_prior[f] != 0;
+    const bool live = f < n && !(hpf && out_status[f] != 0);   // not already tracked in stage 1
+    if (wv == 0 && lane < 32 && f < n && !live && iters) iters[n + f] = 0;
+    const unsigned m32 = (unsigned)(__ballot(live) & 0xffffffffull);
+    const int total = __popc(m32);
+    if (wv * 4 >= total) return;
+    const int idx = wv * 4 + row;
+    const bool act = idx < total;
+    const int i = base + (act ? nth_set_bit(m32, idx) : 0);
+    const int ii = min(i, n - 1);
+    const int b = img_idx ? img_idx[ii] : 0;
+    // per-image stage-1 tally: 64 slots, 4 per lane of the row
+    int n3 = 0, good = 0;
+    for (int q = 0; q < 4; ++q) {
+        const unsigned cw = counts[64 * b + sub * 4 + q];
+        n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
     }
-    const float2 kp = kps[i];
-    float2 pr = (hp && !drop) ? out_xy[i] : kp;
-    unsigned it = 0;
-    const int ok = fb_track_one(pv, cv, b, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, lane, it);
-    if (lane == 0) {
+    n3 = row_sum_i32(n3); good = row_sum_i32(good);
+    const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
+    if (act && sub == 0 && p3p_req && drop) p3p_req[b] = 1;
+    const bool hp = has_prior[ii] != 0;
+    const float2 kp = kps[ii];
+    float2 pr = (hp && !drop) ? out_xy[ii] : kp;
+    unsigned work = 0;
+    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    if (act && sub == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
-        if (iters) iters[n + i] = it;  // second half of the work-word array = stage 2
+        if (iters) iters[n + i] = work;  // second half of the work-word array = stage 2
     }
 }
 
@@ -352,9 +416,18 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     ov2_status s = make_params(c, prev, cur, win, nlevels, max_iter, eps, err_th, fb_th, &P);
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
-    OV2_LAUNCH(c, OV2_K_KLT_FB, klt_fb_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
-                       reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_priors), d_status,
-                       d_img_idx, d_iters);
+#define KLT_FB(W)                                                                                              \
+    OV2_LAUNCH(c, OV2_K_KLT_FB, klt_fb_kernel<W>, dim3((n + 3) / 4), dim3(64), 0, c->stream, prev->buf->view,  \
+               cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_priors), \
+               d_status, d_img_idx, d_iters)
+    switch (win) {
+    case 3: KLT_FB(3); break;
+    case 5: KLT_FB(5); break;
+    case 7: KLT_FB(7); break;
+    case 9: KLT_FB(9); break;
+    default: KLT_FB(11); break;
+    }
+#undef KLT_FB
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
 }
@@ -404,12 +477,24 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     unsigned *counts = (unsigned *)scr;
     OV2_HIP(c, hipMemsetAsync(counts, 0, (size_t)B * 64 * sizeof(unsigned), c->stream));
     if (d_p3p_req) OV2_HIP(c, hipMemsetAsync(d_p3p_req, 0, (size_t)B * sizeof(int), c->stream));
-    OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
-                       reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<const float2 *>(d_prior), d_has_prior,
-                       d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters);
-    OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel, dim3(n), dim3(64), 0, c->stream, prev->buf->view, cur->buf->view, P, n,
-                       reinterpret_cast<const float2 *>(d_kps), d_has_prior, d_img_idx,
-                       reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters);
+#define KLT_STAGES(W)                                                                                           \
+    do {                                                                                                        \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(512), 0, c->stream,        \
+                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),             \
+                   reinterpret_cast<const float2 *>(d_prior), d_has_prior, d_img_idx,                          \
+                   reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters);                       \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(512), 0, c->stream,        \
+                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_has_prior, \
+                   d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters);  \
+    } while (0)
+    switch (win) {
+    case 3: KLT_STAGES(3); break;
+    case 5: KLT_STAGES(5); break;
+    case 7: KLT_STAGES(7); break;
+    case 9: KLT_STAGES(9); break;
+    default: KLT_STAGES(11); break;
+    }
+#undef KLT_STAGES
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
 }
