@@ -233,3 +233,77 @@ def ba_solve(prob, options=None):
     rc = L.ov2o_ba_solve(C.byref(pc), C.byref(o), C.byref(res.c))
     assert rc == 0
     return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# detectors (keyframe rate)
+
+def _det_lib():
+    L = lib()
+    if not getattr(L, "_det_bound", False):
+        L.ov2o_detect_single_scale.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, i32p, f64p,
+                                               C.c_int, i32p, f32p]
+        L.ov2o_detect_grid_fast.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, i32p, i32p,
+                                            C.c_int, i32p, f32p]
+        L.ov2o_corner_subpix.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_double]
+        L.ov2o_draw_disc_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint8]
+        L.ov2o_min_eig_cell.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        L.ov2o_fast_score.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ov2o_fast_score.restype = C.c_int
+        L._det_bound = True
+    return L
+
+
+def _roi(roi, w, h):
+    return np.ascontiguousarray([0, 0, w, h] if roi is None else roi, dtype=np.int32)
+
+
+def detect_single_scale(img, cell, cur_xy, dmaxquality, roi=None, subpix=True):
+    """FeatureExtractor::detectSingleScale. returns (pts (n,2) f32, new dmaxquality)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cur = np.ascontiguousarray(cur_xy, np.float32).reshape(-1, 2)
+    out = np.zeros(((h // cell) * (w // cell) * 2 + 2, 2), np.float32)
+    n, q, r = C.c_int(0), C.c_double(dmaxquality), _roi(roi, w, h)
+    _det_lib().ov2o_detect_single_scale(_p(img, u8p), w, h, w, cell, len(cur), _p(cur, f32p), _p(r, i32p), C.byref(q),
+                                        int(subpix), C.byref(n), _p(out, f32p))
+    return out[:n.value].copy(), q.value
+
+
+def detect_grid_fast(img, cell, cur_xy, nfast_th, roi=None, subpix=True):
+    """FeatureExtractor::detectGridFAST. returns (pts (n,2) f32, new nfast_th)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cur = np.ascontiguousarray(cur_xy, np.float32).reshape(-1, 2)
+    out = np.zeros(((h // cell) * (w // cell) + 2, 2), np.float32)
+    n, t, r = C.c_int(0), C.c_int(nfast_th), _roi(roi, w, h)
+    _det_lib().ov2o_detect_grid_fast(_p(img, u8p), w, h, w, cell, len(cur), _p(cur, f32p), _p(r, i32p), C.byref(t),
+                                     int(subpix), C.byref(n), _p(out, f32p))
+    return out[:n.value].copy(), t.value
+
+
+def corner_subpix(img, pts, half_win=3, max_iter=30, eps=0.01):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.ascontiguousarray(pts, np.float32).reshape(-1, 2).copy()
+    _det_lib().ov2o_corner_subpix(_p(img, u8p), w, h, w, len(out), _p(out, f32p), half_win, max_iter, eps)
+    return out
+
+
+def draw_disc(mask, cx, cy, radius, value=0):
+    h, w = mask.shape
+    _det_lib().ov2o_draw_disc_u8(_p(mask, u8p), w, h, cx, cy, radius, value)
+    return mask
+
+
+def min_eig_cell(img, x0, y0, cell):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((cell, cell), np.float32)
+    _det_lib().ov2o_min_eig_cell(_p(img, u8p), w, h, w, x0, y0, cell, _p(out, f32p))
+    return out
+
+
+def fast_score(img, x, y, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    return _det_lib().ov2o_fast_score(_p(img, u8p), img.shape[1], x, y, threshold)

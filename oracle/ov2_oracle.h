@@ -77,6 +77,28 @@ void ov2o_klt_tracking_frame(const ov2o_pyr *prev, const ov2o_pyr *cur, int win,
                              const float *kps_xy, const float *prior_xy, const uint8_t *has_prior,
                              float *out_xy, uint8_t *out_status, int *p3p_req);
 
+/* ------------------------------------------------------------------ detectors (keyframe rate) ---- */
+
+/* FeatureExtractor::detectSingleScale (src/feature_extractor.cpp:288-440): per empty grid cell GaussianBlur 3x3 +
+ * cornerMinEigenVal(3,3) + masked arg-max (two candidates per cell), threshold adaptation, cornerSubPix(3x3,30,0.01).
+ * The reference runs the cells in a racy parallel_for_ over a SHARED mask: any cell order is a
+ * valid execution.  The canonical order used here and on the GPU is the 2x2 colouring of the grid -- colour
+ * (r&1)*2+(c&1) ascending, cells of one colour never interact (mask discs have radius cell/4).
+ * roi = {x, y, w, h}; dmaxquality in/out; out_xy capacity = number of cells * 2. */
+void ov2o_detect_single_scale(const uint8_t *img, int w, int h, int stride, int cell, int n_cur, const float *cur_xy,
+                              const int roi[4], double *dmaxquality, int do_subpix, int *n_out, float *out_xy);
+/* FeatureExtractor::detectGridFAST (src/feature_extractor.cpp:443-570): per empty cell FAST-9/16 (threshold
+ * nfast_th, non-max suppression, mask), best response >= 20, threshold adaptation, cornerSubPix. */
+void ov2o_detect_grid_fast(const uint8_t *img, int w, int h, int stride, int cell, int n_cur, const float *cur_xy,
+                           const int roi[4], int *nfast_th, int do_subpix, int *n_out, float *out_xy);
+/* cv::cornerSubPix(img, pts, Size(3,3), Size(-1,-1), TermCriteria(EPS+MAX_ITER, max_iter, eps)) */
+void ov2o_corner_subpix(const uint8_t *img, int w, int h, int stride, int n, float *xy, int half_win, int max_iter,
+                        double eps);
+/* pieces exposed for unit tests */
+void ov2o_draw_disc_u8(uint8_t *mask, int w, int h, int cx, int cy, int radius, uint8_t value);   /* cv::circle filled */
+void ov2o_min_eig_cell(const uint8_t *img, int w, int h, int stride, int x0, int y0, int cell, float *hmap);
+int ov2o_fast_score(const uint8_t *img, int stride, int x, int y, int threshold);   /* cornerScore<16>, 0 if not a corner */
+
 #ifdef __cplusplus
 }
 #endif

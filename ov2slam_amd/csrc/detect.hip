@@ -1,0 +1,468 @@
+// detect.hip -- keyframe-rate grid detectors + cornerSubPix on gfx950.
+//
+// Replaces (reference, /root/reference): FeatureExtractor::detectSingleScale src/feature_extractor.cpp:288-440,
+// FeatureExtractor::detectGridFAST :443-570 and the cv::cornerSubPix(3x3, 30, 0.01) call that ends both; caller
+// MapManager::extractKeypoints src/map_manager.cpp:286-340.  Arithmetic = OpenCV semantics as restated in
+// oracle/ov2_oracle_det.c (same fp32 evaluation order, contraction off => bit-identical results).
+//
+// The reference mutates ONE shared mask from a racy cv::parallel_for_ over the cells; the canonical schedule used by
+// the oracle and here is the 2x2 colouring of the cell grid (colour = (r&1)*2+(c&1) ascending): same-colour cells are
+// at least one cell apart while a mask disc has radius cell/4, so one launch per colour runs its cells in parallel
+// without interaction and the four launches reproduce the sequential result exactly.
+//
+// Kernels: det_mask_kernel (occupancy + discs of the existing keypoints), det_mineig_kernel / det_fast_kernel (one
+// workgroup per cell: response map in LDS, masked arg-max, disc, second arg-max), subpix_kernel (one wave per point).
+#include "ov2_internal.h"
+
+#include <cmath>
+
+namespace {
+
+#define DET_MAX_CELL 64
+#define DET_MAX_R 16
+
+struct disc_shape {
+    int r;
+    signed char hw[2 * DET_MAX_R + 1];   // half-width of row offset dy+r of cv::circle's filled midpoint circle
+};
+
+disc_shape make_disc(int radius)
+{   // drawing.cpp Circle(): spans (cy+-dy: +-dx) and (cy+-dx: +-dy)
+    disc_shape s;
+    s.r = radius;
+    for (int i = 0; i < 2 * DET_MAX_R + 1; ++i) s.hw[i] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        auto upd = [&](int row, int half) {
+            if (s.hw[radius + row] < half) s.hw[radius + row] = (signed char)half;
+            if (s.hw[radius - row] < half) s.hw[radius - row] = (signed char)half;
+        };
+        upd(dy, dx);
+        upd(dx, dy);
+        dy++;
+        err += plus;
+        plus += 2;
+        const int m = (err <= 0) - 1;
+        err -= minus & m;
+        dx += m;
+        minus -= m & 2;
+    }
+    return s;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// all threads of the workgroup zero the disc around (cx, cy) in the w x h mask
+__device__ __forceinline__ void draw_disc(unsigned char *mask, int w, int h, int cx, int cy, const disc_shape &ds)
+{
+    const int side = 2 * ds.r + 1;
+    for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
+        const int oy = i / side - ds.r, ox = i % side - ds.r;
+        const int hw = ds.hw[ds.r + oy];
+        const int x = cx + ox, y = cy + oy;
+        if (hw >= 0 && ox >= -hw && ox <= hw && x >= 0 && x < w && y >= 0 && y < h) mask[(size_t)y * w + x] = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void det_mask_kernel(const float2 *__restrict__ cur, int n_cur, int cell, int nwcells,
+                                                      int nhcells, unsigned char *__restrict__ occ,
+                                                      unsigned char *__restrict__ mask, int w, int h, disc_shape ds)
+{
+    const int k = blockIdx.x;
+    if (k >= n_cur) return;
+    const float2 p = cur[k];
+    if (threadIdx.x == 0) {
+        const int cr = (int)(p.y / (float)cell), cc = (int)(p.x / (float)cell);
+        if (cr >= 0 && cr <= nhcells && cc >= 0 && cc <= nwcells) occ[cr * (nwcells + 1) + cc] = 1;
+    }
+    draw_disc(mask, w, h, (int)__builtin_rintf(p.x), (int)__builtin_rintf(p.y), ds);
+}
+
+// ordered key: larger value wins, on ties the smaller index (cv::minMaxLoc returns the first maximum)
+__device__ __forceinline__ unsigned long long argmax_key(float v, int idx)
+{
+    unsigned b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)b << 32) | (unsigned)(0x7fffffff - idx);
+}
+
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = sh[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = sh[k] > r ? sh[k] : r;
+    __syncthreads();
+    return r;
+}
+
+struct det_out {          // per cell
+    float fx, fy, sx, sy;
+    int has_first, has_second, occupied, pad;
+};
+
+// detectSingleScale: one workgroup (256 threads) per cell of the current colour
+__global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
+                                                         int cell, int nwcells, int colour,
+                                                         const unsigned char *__restrict__ occ,
+                                                         unsigned char *__restrict__ mask, disc_shape ds, int rx, int ry,
+                                                         int rw, int rh, double quality, det_out *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long shk[4];
+    const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
+    if (((rr & 1) * 2 + (cc & 1)) != colour) return;
+    const int tid = threadIdx.x, n = cell, n2 = cell * cell;
+    if (occ[rr * (nwcells + 1) + cc]) {
+        if (tid == 0) out[i].occupied = 1;
+        return;
+    }
+    const int x0 = cc * cell, y0 = rr * cell;
+    if (!(x0 + cell < w - 1 && y0 + cell < h - 1)) return;
+    float *dxs = reinterpret_cast<float *>(lds_raw);   // n2
+    float *dys = dxs + n2;                              // n2
+    float *hmap = dys + n2;                             // n2
+    unsigned char *bl = reinterpret_cast<unsigned char *>(hmap + n2);   // n2 blurred cell
+    // GaussianBlur 3x3 (fixed point, round half up), parent pixels beyond the cell, REFLECT_101 at the image border
+    for (int p = tid; p < n2; p += 256) {
+        const int y = p / n, x = p - y * n;
+        int s = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const unsigned char *row = img + (size_t)reflect101(y0 + y + j, h) * istride;
+            const int kj = j == 0 ? 2 : 1;
+            s += kj * (row[reflect101(x0 + x - 1, w)] + 2 * row[x0 + x] + row[reflect101(x0 + x + 1, w)]);
+        }
+        bl[p] = (unsigned char)((s + 8) >> 4);
+    }
+    __syncthreads();
+    const float sc = (float)(1.0 / (4.0 * 3.0 * 255.0)), sc2 = sc * 2.f;
+#define BL(yy, xx) ((float)bl[reflect101((yy), n) * n + reflect101((xx), n)])
+    for (int p = tid; p < n2; p += 256) {
+        const int y = p / n, x = p - y * n;
+        const float rm = BL(y - 1, x + 1) - BL(y - 1, x - 1), r0 = BL(y, x + 1) - BL(y, x - 1), rp = BL(y + 1, x + 1) - BL(y + 1, x - 1);
+        dxs[p] = sc2 * r0 + sc * (rm + rp);
+        const float tm = (BL(y - 1, x - 1) + BL(y - 1, x + 1)) * sc + BL(y - 1, x) * sc2;
+        const float tp = (BL(y + 1, x - 1) + BL(y + 1, x + 1)) * sc + BL(y + 1, x) * sc2;
+        dys[p] = tp - tm;
+    }
+#undef BL
+    __syncthreads();
+    for (int p = tid; p < n2; p += 256) {
+        const int y = p / n, x = p - y * n;
+        double a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+            for (int ii = -1; ii <= 1; ++ii) {
+                const int q = reflect101(y + j, n) * n + reflect101(x + ii, n);
+                const float gx = dxs[q], gy = dys[q];
+                a += (double)(gx * gx);
+                b += (double)(gx * gy);
+                c += (double)(gy * gy);
+            }
+        const float fa = (float)a * 0.5f, fb = (float)b, fc = (float)c * 0.5f;
+        hmap[p] = (fa + fc) - __fsqrt_rn((fa - fc) * (fa - fc) + fb * fb);
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long key = argmax_key(-3.4028234663852886e38f, 0x7ffffffe);
+        for (int p = tid; p < n2; p += 256) {
+            const int y = p / n, x = p - y * n;
+            const float v = mask[(size_t)(y0 + y) * w + x0 + x] ? hmap[p] : 0.f;
+            const unsigned long long k2 = argmax_key(v, p);
+            key = k2 > key ? k2 : key;
+        }
+        key = block_max_u64(key, shk);
+        const int idx = 0x7fffffff - (int)(key & 0xffffffffu);
+        unsigned kb = (unsigned)(key >> 32);
+        kb = (kb & 0x80000000u) ? (kb & 0x7fffffffu) : ~kb;
+        const float best = __uint_as_float(kb);
+        const int bx = x0 + idx % n, by = y0 + idx / n;
+        if (bx < rx || by < ry || bx >= rx + rw || by >= ry + rh) return;   // `continue` of the reference: cell done
+        if ((double)best >= quality) {
+            if (tid == 0) {
+                if (pass == 0) { out[i].fx = (float)bx; out[i].fy = (float)by; out[i].has_first = 1; }
+                else { out[i].sx = (float)bx; out[i].sy = (float)by; out[i].has_second = 1; }
+            }
+            draw_disc(mask, w, h, bx, by, ds);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
+
+// FAST-9/16 score of the centre pixel p (cornerScore<16>); 0 when not a corner at `threshold`
+__device__ inline int fast_score(const unsigned char *p, int stride, int threshold)
+{
+    const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    const int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    const int v = p[0];
+    int d[25];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - p[oy[k] * stride + ox[k]];
+#pragma unroll
+    for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
+    unsigned br = 0, dk = 0;   // bit k: ring pixel k brighter / darker than the centre by more than the threshold
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { br |= (d[k] < -threshold ? 1u : 0u) << k; dk |= (d[k] > threshold ? 1u : 0u) << k; }
+    br |= br << 16; dk |= dk << 16;
+    bool corner = false;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) corner |= (((br >> s) & 0x1ffu) == 0x1ffu) | (((dk >> s) & 0x1ffu) == 0x1ffu);
+    if (!corner) return 0;
+    int a0 = threshold;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(min(d[k + 1], d[k + 2]), d[k + 3]);
+        if (a <= a0) continue;
+        a = min(a, min(min(d[k + 4], d[k + 5]), min(min(d[k + 6], d[k + 7]), d[k + 8])));
+        a0 = max(a0, min(a, d[k]));
+        a0 = max(a0, min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int b = max(max(d[k + 1], d[k + 2]), max(d[k + 3], max(d[k + 4], d[k + 5])));
+        if (b >= b0) continue;
+        b = max(b, max(d[k + 6], max(d[k + 7], d[k + 8])));
+        b0 = min(b0, max(b, d[k]));
+        b0 = min(b0, max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+// detectGridFAST: one workgroup per cell of the current colour
+__global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
+                                                       int cell, int nwcells, int colour,
+                                                       const unsigned char *__restrict__ occ,
+                                                       unsigned char *__restrict__ mask, disc_shape ds, int threshold,
+                                                       det_out *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long shk[4];
+    const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
+    if (((rr & 1) * 2 + (cc & 1)) != colour) return;
+    const int tid = threadIdx.x, n = cell, n2 = cell * cell;
+    if (occ[rr * (nwcells + 1) + cc]) {
+        if (tid == 0) out[i].occupied = 1;
+        return;
+    }
+    if (tid == 0) out[i].pad = 1;   // counted as "empty" (nbempty++ precedes the border test, :496)
+    const int x0 = cc * cell, y0 = rr * cell;
+    if (!(x0 + cell < w - 1 && y0 + cell < h - 1)) return;
+    int *score = reinterpret_cast<int *>(lds_raw);
+    for (int p = tid; p < n2; p += 256) {
+        const int y = p / n, x = p - y * n;
+        int s = 0;
+        if (x >= 3 && x < n - 3 && y >= 3 && y < n - 3) s = fast_score(img + (size_t)(y0 + y) * istride + x0 + x, istride, threshold);
+        score[p] = s;
+    }
+    __syncthreads();
+    unsigned long long key = 0ull;   // scores are > 0
+    for (int p = tid; p < n2; p += 256) {
+        const int y = p / n, x = p - y * n;
+        const int s = score[p];
+        if (s <= 0) continue;
+        bool nms = true;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+            for (int ii = -1; ii <= 1; ++ii)
+                if ((j || ii) && !(s > score[(y + j) * n + x + ii])) nms = false;
+        if (!nms) continue;
+        // the reference passes its CV_32F mask to FastFeatureDetector::detect, which reads it as bytes (oracle header)
+        if ((x & 3) < 2 || !mask[(size_t)(y0 + y) * w + x0 + (x >> 2)]) continue;
+        const unsigned long long k2 = ((unsigned long long)(unsigned)s << 32) | (unsigned)(0x7fffffff - p);
+        key = k2 > key ? k2 : key;
+    }
+    key = block_max_u64(key, shk);
+    const int best = (int)(key >> 32);
+    if (best >= 20) {
+        const int idx = 0x7fffffff - (int)(key & 0xffffffffu);
+        const int bx = x0 + idx % n, by = y0 + idx / n;
+        if (tid == 0) { out[i].fx = (float)bx; out[i].fy = (float)by; out[i].has_first = 1; }
+        draw_disc(mask, w, h, bx, by, ds);
+    }
+}
+
+// cv::cornerSubPix, one wave per point: the (2hw+3)^2 bilinear samples are computed by the lanes, the 2x2 normal
+// equations are then accumulated by lane 0 in the row-major order of the oracle (double), so results are bit-equal.
+__global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
+                                                    int n, float2 *__restrict__ pts, int hw, int max_iter, double eps2,
+                                                    const float *__restrict__ wmask)
+{
+    __shared__ float buf[17 * 17];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n) return;
+    const int win = 2 * hw + 1, bw = win + 2;
+    const float cTx = pts[p].x, cTy = pts[p].y;
+    float cIx = cTx, cIy = cTy;
+    int iter = 0;
+    double err = 0;
+    bool go = true;
+    while (go) {
+        const float cx = cIx - (float)(bw - 1) * 0.5f, cy = cIy - (float)(bw - 1) * 0.5f;
+        const int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
+        const float a = cx - (float)ipx, b = cy - (float)ipy;
+        const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+        for (int q = lane; q < bw * bw; q += 64) {
+            const int i = q / bw, j = q - i * bw;
+            const int xa = min(max(ipx + j, 0), w - 1), xb = min(max(ipx + j + 1, 0), w - 1);
+            const int ya = min(max(ipy + i, 0), h - 1), yb = min(max(ipy + i + 1, 0), h - 1);
+            buf[q] = (float)img[(size_t)ya * istride + xa] * a11 + (float)img[(size_t)ya * istride + xb] * a12 +
+                     (float)img[(size_t)yb * istride + xa] * a21 + (float)img[(size_t)yb * istride + xb] * a22;
+        }
+        __syncthreads();
+        float nx = cIx, ny = cIy;
+        int stop = 0;
+        if (lane == 0) {
+            double A = 0, Bm = 0, C = 0, bb1 = 0, bb2 = 0;
+            for (int i = 0; i < win; ++i) {
+                const double py = i - hw;
+                for (int j = 0; j < win; ++j) {
+                    const float *sp = buf + (i + 1) * bw + (j + 1);
+                    const double m = wmask[i * win + j];
+                    const double tgx = sp[1] - sp[-1];
+                    const double tgy = sp[bw] - sp[-bw];
+                    const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                    const double px = j - hw;
+                    A += gxx; Bm += gxy; C += gyy;
+                    bb1 += gxx * px + gxy * py;
+                    bb2 += gxy * px + gyy * py;
+                }
+            }
+            const double det = A * C - Bm * Bm;
+            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) stop = 1;
+            else {
+                const double scale = 1.0 / det;
+                nx = (float)(cIx + C * scale * bb1 - Bm * scale * bb2);
+                ny = (float)(cIy - Bm * scale * bb1 + A * scale * bb2);
+            }
+        }
+        stop = __shfl(stop, 0);
+        nx = __shfl(nx, 0);
+        ny = __shfl(ny, 0);
+        __syncthreads();
+        if (stop) break;
+        err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
+        cIx = nx; cIy = ny;
+        if (cIx < 0 || cIx >= (float)w || cIy < 0 || cIy >= (float)h) break;
+        go = (++iter < max_iter) && (err > eps2);
+    }
+    if (fabsf(cIx - cTx) > (float)hw || fabsf(cIy - cTy) > (float)hw) { cIx = cTx; cIy = cTy; }
+    if (lane == 0) pts[p] = make_float2(cIx, cIy);
+}
+
+}  // namespace
+
+extern "C" ov2_status ov2_detect_grid(ov2_ctx *c, const ov2_pyr *pyr, int b, int cell, int mode, double *thresh,
+                                      int n_cur, const float *cur_xy, const int *roi, int do_subpix, int *n_out,
+                                      float *out_xy)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (!pyr || !thresh || !n_out || !out_xy || n_cur < 0 || (n_cur && !cur_xy))
+        return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    if (b < 0 || b >= pyr->buf->batch) return ov2_set_err(c, OV2_ERR_INVALID, "image index %d out of the batch", b);
+    if (cell < 8 || cell > DET_MAX_CELL || cell / 4 > DET_MAX_R)
+        return ov2_set_err(c, OV2_ERR_INVALID, "cell size %d unsupported (8..%d)", cell, DET_MAX_CELL);
+    if (mode != OV2_DETECT_FAST && mode != OV2_DETECT_MINEIG) return ov2_set_err(c, OV2_ERR_INVALID, "mode %d", mode);
+    OV2_HIP(c, hipSetDevice(c->device));
+    const ov2_pyr_view &v = pyr->buf->view;
+    const ov2_level_desc &L = v.lv[0];
+    const int w = L.w, h = L.h;
+    const unsigned char *img = v.base + L.img_off + L.img_bstride * b + (size_t)v.pad * L.istride + OV2_LM;
+    const int nh = h / cell, nw = w / cell, nb = nh * nw;
+    *n_out = 0;
+    if (nb == 0) return OV2_OK;
+    const int rx = roi ? roi[0] : 0, ry = roi ? roi[1] : 0, rw = roi ? roi[2] : w, rh = roi ? roi[3] : h;
+    // scratch: mask | occ | det_out[nb] | cur kps | pts | subpix weights
+    const size_t off_mask = 0, off_occ = ((size_t)w * h + 255) / 256 * 256;
+    const size_t off_out = off_occ + (((size_t)(nh + 1) * (nw + 1)) + 255) / 256 * 256;
+    const size_t off_cur = off_out + ((sizeof(det_out) * nb + 255) / 256) * 256;
+    const size_t off_pts = off_cur + (((size_t)n_cur * 8 + 255) / 256) * 256;
+    const size_t off_wm = off_pts + (((size_t)nb * 2 * 8 + 255) / 256) * 256;
+    const size_t total = off_wm + 1024;
+    void *scr = nullptr;
+    ov2_status s = ov2_scratch(c, total, &scr);
+    if (s != OV2_OK) return s;
+    unsigned char *mask = (unsigned char *)scr + off_mask, *occ = (unsigned char *)scr + off_occ;
+    det_out *dout = (det_out *)((char *)scr + off_out);
+    float2 *dcur = (float2 *)((char *)scr + off_cur), *dpts = (float2 *)((char *)scr + off_pts);
+    float *dwm = (float *)((char *)scr + off_wm);
+    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemsetAsync(mask, 1, (size_t)w * h, st));
+    OV2_HIP(c, hipMemsetAsync(occ, 0, (size_t)(nh + 1) * (nw + 1), st));
+    OV2_HIP(c, hipMemsetAsync(dout, 0, sizeof(det_out) * nb, st));
+    const disc_shape ds = make_disc(cell / 4);
+    if (n_cur > 0) {
+        OV2_HIP(c, hipMemcpyAsync(dcur, cur_xy, (size_t)n_cur * 8, hipMemcpyHostToDevice, st));
+        OV2_LAUNCH(c, OV2_K_DETECT, det_mask_kernel, dim3(n_cur), dim3(64), 0, st, dcur, n_cur, cell, nw, nh, occ, mask, w, h, ds);
+    }
+    int th_fast = 0;
+    if (mode == OV2_DETECT_FAST) {
+        th_fast = (int)*thresh;
+        th_fast = th_fast < 0 ? 0 : (th_fast > 255 ? 255 : th_fast);
+    }
+    for (int colour = 0; colour < 4; ++colour) {
+        if (mode == OV2_DETECT_MINEIG)
+            OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nb), dim3(256), (size_t)cell * cell * 13, st, img, L.istride, w,
+                       h, cell, nw, colour, occ, mask, ds, rx, ry, rw, rh, *thresh, dout);
+        else
+            OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nb), dim3(256), (size_t)cell * cell * 4, st, img, L.istride, w,
+                       h, cell, nw, colour, occ, mask, ds, th_fast, dout);
+    }
+    std::vector<det_out> hout(nb);
+    OV2_HIP(c, hipMemcpyAsync(hout.data(), dout, sizeof(det_out) * nb, hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipStreamSynchronize(st));
+    // assemble in cell order (:393-412 / :532-538) and adapt the threshold (:418-423 / :546-552)
+    int n = 0, nboccup = 0, nbempty = 0;
+    for (int i = 0; i < nb; ++i) {
+        nboccup += hout[i].occupied;
+        nbempty += hout[i].pad;
+        if (hout[i].has_first) { out_xy[2 * n] = hout[i].fx; out_xy[2 * n + 1] = hout[i].fy; ++n; }
+    }
+    if (mode == OV2_DETECT_MINEIG) {
+        if (n + nboccup < nb) {
+            const int nbsec = nb - (n + nboccup);
+            int k = 0;
+            for (int i = 0; i < nb && k < nbsec; ++i)
+                if (hout[i].has_second) { out_xy[2 * n] = hout[i].sx; out_xy[2 * n + 1] = hout[i].sy; ++n; ++k; }
+        }
+        if ((double)n < 0.33 * (double)(nb - nboccup)) *thresh /= 2.;
+        else if ((double)n > 0.9 * (double)(nb - nboccup)) *thresh *= 1.5;
+    } else {
+        const int cur_th = (int)*thresh;
+        if ((double)n < 0.5 * (double)nbempty && nbempty > 10) *thresh = (double)(int)((double)cur_th * 0.66);
+        else if (n == nbempty) *thresh = (double)(int)((double)cur_th * 1.5);
+    }
+    if (n > 0 && do_subpix) {
+        const int hw = 3, win = 7;
+        float wm[49];
+        for (int i = 0; i < win; ++i) {
+            const float y = (float)(i - hw) / (float)hw;
+            const float vy = expf(-y * y);
+            for (int j = 0; j < win; ++j) {
+                const float x = (float)(j - hw) / (float)hw;
+                wm[i * win + j] = (float)(vy * expf(-x * x));
+            }
+        }
+        OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));
+        OV2_HIP(c, hipMemcpyAsync(dpts, out_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        OV2_LAUNCH(c, OV2_K_DETECT, subpix_kernel, dim3(n), dim3(64), 0, st, img, L.istride, w, h, n, dpts, hw, 30, 0.01 * 0.01, dwm);
+        OV2_HIP(c, hipMemcpyAsync(out_xy, dpts, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        OV2_HIP(c, hipStreamSynchronize(st));
+    }
+    OV2_HIP(c, hipGetLastError());
+    *n_out = n;
+    return OV2_OK;
+}

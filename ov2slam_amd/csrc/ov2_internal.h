@@ -45,7 +45,8 @@ struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,ba
 
 enum ov2_kernel_id {
     OV2_K_CLAHE_LUT = 0, OV2_K_LEVEL0, OV2_K_LEVEL, OV2_K_KLT_FB, OV2_K_KLT_STAGE1, OV2_K_KLT_STAGE2,
-    OV2_K_BA_FIRST,  // BA kernels register from here (ba.hip)
+    OV2_K_BA_FIRST,  // BA kernels register from here (ba.hip): 12 ids
+    OV2_K_DETECT = 20,
     OV2_K_MAX = 48
 };
 extern const char *ov2_kernel_names[OV2_K_MAX];

@@ -242,3 +242,39 @@ class FeatureTracker:
                              n, None, d_r, None)
         ctx.synchronize()
         return d_o.get(), d_s.get().astype(bool), bool(d_r.get()[0])
+
+
+class FeatureExtractor:
+    """mirror of the reference FeatureExtractor for the two grid detectors (include/feature_extractor.hpp:37-46):
+    keeps the adaptive thresholds dmaxquality_ / nfast_th_ across calls exactly as the reference object does."""
+
+    def __init__(self, ctx, nmaxdist=35, dmaxquality=0.001, nfast_th=10):
+        self.ctx, self.nmaxdist_ = ctx, int(nmaxdist)
+        self.dmaxquality_ = float(dmaxquality)
+        self.nfast_th_ = int(nfast_th)
+
+    def _detect(self, mode, pyr, vcurkps, roi, b, subpix):
+        cur = np.ascontiguousarray(vcurkps, np.float32).reshape(-1, 2)
+        w, h, _ = pyr.level_size(0)
+        cap = max(1, (w // self.nmaxdist_) * (h // self.nmaxdist_)) * 2 + 2
+        out = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        th = C.c_double(self.dmaxquality_ if mode == 1 else float(self.nfast_th_))
+        r = None if roi is None else np.ascontiguousarray(roi, np.int32)
+        _check(self.ctx.h, self.ctx.lib.ov2_detect_grid(self.ctx.h, pyr.h, b, self.nmaxdist_, mode, C.byref(th), len(cur),
+                                                       cur.ctypes.data_as(C.c_void_p),
+                                                       None if r is None else r.ctypes.data_as(C.c_void_p), int(subpix),
+                                                       C.byref(n), out.ctypes.data_as(C.c_void_p)))
+        if mode == 1:
+            self.dmaxquality_ = th.value
+        else:
+            self.nfast_th_ = int(th.value)
+        return out[:n.value].copy()
+
+    def detectSingleScale(self, pyr, vcurkps, roi=None, b=0, subpix=True):
+        """src/feature_extractor.cpp:288-440 on level 0 of `pyr` (the CLAHE'd frame)."""
+        return self._detect(1, pyr, vcurkps, roi, b, subpix)
+
+    def detectGridFAST(self, pyr, vcurkps, roi=None, b=0, subpix=True):
+        """src/feature_extractor.cpp:443-570."""
+        return self._detect(0, pyr, vcurkps, roi, b, subpix)

@@ -1,0 +1,73 @@
+"""GPU parity tests (through the C ABI) of the keyframe-rate detectors against the CPU oracle: bit-exact point lists
+(integer arg-max positions, fp32 cornerSubPix positions) and identical threshold adaptation."""
+import numpy as np
+import pytest
+
+from ov2slam_amd import frontend as fe
+
+pytestmark = pytest.mark.gpu
+
+
+def _corner_image(w=752, h=480, seed=3):
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:h, 0:w]
+    img = 60 + 120 * (((xs // 47) + (ys // 41)) % 2) + rng.normal(0, 2.0, size=(h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subpix", [False, True])
+@pytest.mark.parametrize("cell", [35, 50])
+def test_detect_single_scale_bit_exact(ctx, oracle, stream, cell, subpix):
+    for img in (_corner_image(), stream.left(4)):
+        pyr = fe.preprocess_image(ctx, img, use_clahe=False, nklt_pyr_lvl=0)
+        cur = np.zeros((0, 2), np.float32)
+        ex = fe.FeatureExtractor(ctx, nmaxdist=cell, dmaxquality=0.001)
+        q = 0.001
+        for _ in range(3):      # three keyframes in a row: existing keypoints mask cells, thresholds adapt
+            got = ex.detectSingleScale(pyr, cur, subpix=subpix)
+            want, q = oracle.detect_single_scale(img, cell, cur, q, subpix=subpix)
+            assert got.shape == want.shape
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert ex.dmaxquality_ == q
+            cur = np.concatenate([cur, got[: len(got) // 2]])
+
+
+def test_detect_single_scale_roi_and_clahe_frame(ctx, oracle, stream):
+    img = stream.left(2)
+    pyr = fe.preprocess_image(ctx, img, use_clahe=True)      # the reference detects on the CLAHE'd frame
+    cl = oracle.clahe(img)
+    roi = [40, 30, 600, 400]
+    ex = fe.FeatureExtractor(ctx, nmaxdist=35, dmaxquality=0.001)
+    got = ex.detectSingleScale(pyr, np.array([[100.2, 100.7], [400.0, 300.0]], np.float32), roi=roi)
+    want, q = oracle.detect_single_scale(cl, 35, np.array([[100.2, 100.7], [400.0, 300.0]], np.float32), 0.001, roi=roi)
+    assert len(want) > 50 and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and ex.dmaxquality_ == q
+
+
+@pytest.mark.parametrize("th", [10, 25])
+def test_detect_grid_fast_bit_exact(ctx, oracle, stream, th):
+    for img in (stream.left(1), _corner_image(seed=9)):
+        pyr = fe.preprocess_image(ctx, img, use_clahe=False, nklt_pyr_lvl=0)
+        ex = fe.FeatureExtractor(ctx, nmaxdist=50, nfast_th=th)
+        cur = np.zeros((0, 2), np.float32)
+        t = th
+        for _ in range(3):
+            got = ex.detectGridFAST(pyr, cur)
+            want, t = oracle.detect_grid_fast(img, 50, cur, t)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert ex.nfast_th_ == t
+            cur = np.concatenate([cur, got])
+
+
+def test_detect_edge_cases(ctx, oracle):
+    flat = np.full((480, 752), 90, np.uint8)
+    pyr = fe.preprocess_image(ctx, flat, use_clahe=False, nklt_pyr_lvl=0)
+    ex = fe.FeatureExtractor(ctx, nmaxdist=35, dmaxquality=0.001, nfast_th=10)
+    assert len(ex.detectSingleScale(pyr, np.zeros((0, 2), np.float32))) == 0 and ex.dmaxquality_ == 0.0005
+    ex.nmaxdist_ = 50
+    assert len(ex.detectGridFAST(pyr, np.zeros((0, 2), np.float32))) == 0 and ex.nfast_th_ == 6
+    # image smaller than one cell: no cells, no output
+    small = fe.preprocess_image(ctx, np.zeros((30, 30), np.uint8), use_clahe=False, nklt_pyr_lvl=0)
+    ex.nmaxdist_ = 35
+    assert len(ex.detectSingleScale(small, np.zeros((0, 2), np.float32))) == 0
+    with pytest.raises(Exception):
+        fe.FeatureExtractor(ctx, nmaxdist=4).detectSingleScale(pyr, np.zeros((0, 2), np.float32))
