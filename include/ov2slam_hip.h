@@ -139,6 +139,11 @@ enum { OV2_DETECT_FAST = 0, OV2_DETECT_MINEIG = 1 };
  * The cells of the reference's racy parallel_for_ are visited in the 2x2-colouring order. */
 ov2_status ov2_detect_grid(ov2_ctx *ctx, const ov2_pyr *pyr, int b, int cell, int mode, double *thresh, int n_cur,
                            const float *cur_xy, const int *roi, int do_subpix, int *n_out, float *out_xy);
+/* every image of the pyramid batch in one call (one synchronisation for all of them): thresh[B] in/out, n_cur[B],
+ * cur_xy = the keypoints of image 0, then image 1, ... ; out_xy[B][out_cap][2], n_out[B]; out_cap >= 2 * cells. */
+ov2_status ov2_detect_grid_batch(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, int mode, double *thresh,
+                                 const int *n_cur, const float *cur_xy, const int *roi, int do_subpix, int *n_out,
+                                 float *out_xy, int out_cap);
 
 /* ---- local bundle adjustment ------------------------------------------------------------------- */
 /* Flat, POD restatement of the ceres::Problem that Optimizer::localBA assembles (src/optimizer.cpp:76-392).

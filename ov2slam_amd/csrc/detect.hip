@@ -69,13 +69,17 @@ __device__ __forceinline__ void draw_disc(unsigned char *mask, int w, int h, int
     }
 }
 
-__global__ __launch_bounds__(64) void det_mask_kernel(const float2 *__restrict__ cur, int n_cur, int cell, int nwcells,
-                                                      int nhcells, unsigned char *__restrict__ occ,
-                                                      unsigned char *__restrict__ mask, int w, int h, disc_shape ds)
+__global__ __launch_bounds__(64) void det_mask_kernel(const float2 *__restrict__ cur, const int *__restrict__ cur_img,
+                                                      int n_cur, int cell, int nwcells, int nhcells,
+                                                      unsigned char *__restrict__ occ_all,
+                                                      unsigned char *__restrict__ mask_all, int w, int h, disc_shape ds)
 {
     const int k = blockIdx.x;
     if (k >= n_cur) return;
     const float2 p = cur[k];
+    const int bimg = cur_img[k];
+    unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
+    unsigned char *mask = mask_all + (size_t)bimg * w * h;
     if (threadIdx.x == 0) {
         const int cr = (int)(p.y / (float)cell), cc = (int)(p.x / (float)cell);
         if (cr >= 0 && cr <= nhcells && cc >= 0 && cc <= nwcells) occ[cr * (nwcells + 1) + cc] = 1;
@@ -111,14 +115,21 @@ struct det_out {          // per cell
 };
 
 // detectSingleScale: one workgroup (256 threads) per cell of the current colour
-__global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
-                                                         int cell, int nwcells, int colour,
-                                                         const unsigned char *__restrict__ occ,
-                                                         unsigned char *__restrict__ mask, disc_shape ds, int rx, int ry,
-                                                         int rw, int rh, double quality, det_out *__restrict__ out)
+__global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
+                                                         int istride, int w, int h, int cell, int nwcells, int nhcells,
+                                                         int colour, const unsigned char *__restrict__ occ_all,
+                                                         unsigned char *__restrict__ mask_all, disc_shape ds, int rx,
+                                                         int ry, int rw, int rh, const double *__restrict__ quality_all,
+                                                         det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
+    const int bimg = blockIdx.y;
+    const unsigned char *img = img0 + img_bstride * bimg;
+    const unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
+    unsigned char *mask = mask_all + (size_t)bimg * w * h;
+    det_out *out = out_all + (size_t)bimg * nwcells * nhcells;
+    const double quality = quality_all[bimg];
     const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
     if (((rr & 1) * 2 + (cc & 1)) != colour) return;
     const int tid = threadIdx.x, n = cell, n2 = cell * cell;
@@ -242,14 +253,21 @@ __device__ inline int fast_score(const unsigned char *p, int stride, int thresho
 }
 
 // detectGridFAST: one workgroup per cell of the current colour
-__global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
-                                                       int cell, int nwcells, int colour,
-                                                       const unsigned char *__restrict__ occ,
-                                                       unsigned char *__restrict__ mask, disc_shape ds, int threshold,
-                                                       det_out *__restrict__ out)
+__global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
+                                                       int istride, int w, int h, int cell, int nwcells, int nhcells,
+                                                       int colour, const unsigned char *__restrict__ occ_all,
+                                                       unsigned char *__restrict__ mask_all, disc_shape ds,
+                                                       const double *__restrict__ thresh_all,
+                                                       det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
+    const int bimg = blockIdx.y;
+    const unsigned char *img = img0 + img_bstride * bimg;
+    const unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
+    unsigned char *mask = mask_all + (size_t)bimg * w * h;
+    det_out *out = out_all + (size_t)bimg * nwcells * nhcells;
+    const int threshold = min(max((int)thresh_all[bimg], 0), 255);
     const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
     if (((rr & 1) * 2 + (cc & 1)) != colour) return;
     const int tid = threadIdx.x, n = cell, n2 = cell * cell;
@@ -297,13 +315,15 @@ __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__re
 
 // cv::cornerSubPix, one wave per point: the (2hw+3)^2 bilinear samples are computed by the lanes, the 2x2 normal
 // equations are then accumulated by lane 0 in the row-major order of the oracle (double), so results are bit-equal.
-__global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restrict__ img, int istride, int w, int h,
-                                                    int n, float2 *__restrict__ pts, int hw, int max_iter, double eps2,
+__global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
+                                                    const int *__restrict__ pt_img, int istride, int w, int h, int n,
+                                                    float2 *__restrict__ pts, int hw, int max_iter, double eps2,
                                                     const float *__restrict__ wmask)
 {
     __shared__ float buf[17 * 17];
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
+    const unsigned char *img = img0 + img_bstride * pt_img[p];
     const int win = 2 * hw + 1, bw = win + 2;
     const float cTx = pts[p].x, cTy = pts[p].y;
     float cIx = cTx, cIy = cTy;
@@ -365,87 +385,106 @@ __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restr
 
 }  // namespace
 
-extern "C" ov2_status ov2_detect_grid(ov2_ctx *c, const ov2_pyr *pyr, int b, int cell, int mode, double *thresh,
-                                      int n_cur, const float *cur_xy, const int *roi, int do_subpix, int *n_out,
-                                      float *out_xy)
+extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int cell, int mode, double *thresh,
+                                            const int *n_cur, const float *cur_xy, const int *roi, int do_subpix,
+                                            int *n_out, float *out_xy, int out_cap)
 {
     if (!c) return OV2_ERR_INVALID;
-    if (!pyr || !thresh || !n_out || !out_xy || n_cur < 0 || (n_cur && !cur_xy))
-        return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
-    if (b < 0 || b >= pyr->buf->batch) return ov2_set_err(c, OV2_ERR_INVALID, "image index %d out of the batch", b);
+    if (!pyr || !thresh || !n_out || !out_xy || !n_cur) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
     if (cell < 8 || cell > DET_MAX_CELL || cell / 4 > DET_MAX_R)
         return ov2_set_err(c, OV2_ERR_INVALID, "cell size %d unsupported (8..%d)", cell, DET_MAX_CELL);
     if (mode != OV2_DETECT_FAST && mode != OV2_DETECT_MINEIG) return ov2_set_err(c, OV2_ERR_INVALID, "mode %d", mode);
     OV2_HIP(c, hipSetDevice(c->device));
     const ov2_pyr_view &v = pyr->buf->view;
     const ov2_level_desc &L = v.lv[0];
-    const int w = L.w, h = L.h;
-    const unsigned char *img = v.base + L.img_off + L.img_bstride * b + (size_t)v.pad * L.istride + OV2_LM;
+    const int B = pyr->buf->batch, w = L.w, h = L.h;
+    const unsigned char *img = v.base + L.img_off + (size_t)v.pad * L.istride + OV2_LM;
     const int nh = h / cell, nw = w / cell, nb = nh * nw;
-    *n_out = 0;
+    for (int b = 0; b < B; ++b) n_out[b] = 0;
     if (nb == 0) return OV2_OK;
-    const int rx = roi ? roi[0] : 0, ry = roi ? roi[1] : 0, rw = roi ? roi[2] : w, rh = roi ? roi[3] : h;
-    // scratch: mask | occ | det_out[nb] | cur kps | pts | subpix weights
-    const size_t off_mask = 0, off_occ = ((size_t)w * h + 255) / 256 * 256;
-    const size_t off_out = off_occ + (((size_t)(nh + 1) * (nw + 1)) + 255) / 256 * 256;
-    const size_t off_cur = off_out + ((sizeof(det_out) * nb + 255) / 256) * 256;
-    const size_t off_pts = off_cur + (((size_t)n_cur * 8 + 255) / 256) * 256;
-    const size_t off_wm = off_pts + (((size_t)nb * 2 * 8 + 255) / 256) * 256;
-    const size_t total = off_wm + 1024;
-    void *scr = nullptr;
-    ov2_status s = ov2_scratch(c, total, &scr);
-    if (s != OV2_OK) return s;
-    unsigned char *mask = (unsigned char *)scr + off_mask, *occ = (unsigned char *)scr + off_occ;
-    det_out *dout = (det_out *)((char *)scr + off_out);
-    float2 *dcur = (float2 *)((char *)scr + off_cur), *dpts = (float2 *)((char *)scr + off_pts);
-    float *dwm = (float *)((char *)scr + off_wm);
-    hipStream_t st = c->stream;
-    OV2_HIP(c, hipMemsetAsync(mask, 1, (size_t)w * h, st));
-    OV2_HIP(c, hipMemsetAsync(occ, 0, (size_t)(nh + 1) * (nw + 1), st));
-    OV2_HIP(c, hipMemsetAsync(dout, 0, sizeof(det_out) * nb, st));
-    const disc_shape ds = make_disc(cell / 4);
-    if (n_cur > 0) {
-        OV2_HIP(c, hipMemcpyAsync(dcur, cur_xy, (size_t)n_cur * 8, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT, det_mask_kernel, dim3(n_cur), dim3(64), 0, st, dcur, n_cur, cell, nw, nh, occ, mask, w, h, ds);
+    if (out_cap < 2 * nb) return ov2_set_err(c, OV2_ERR_INVALID, "out_cap %d < 2 * cells (%d)", out_cap, 2 * nb);
+    int ncur_tot = 0;
+    for (int b = 0; b < B; ++b) {
+        if (n_cur[b] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative keypoint count");
+        ncur_tot += n_cur[b];
     }
-    int th_fast = 0;
-    if (mode == OV2_DETECT_FAST) {
-        th_fast = (int)*thresh;
-        th_fast = th_fast < 0 ? 0 : (th_fast > 255 ? 255 : th_fast);
+    if (ncur_tot && !cur_xy) return ov2_set_err(c, OV2_ERR_INVALID, "null cur_xy");
+    const int rx = roi ? roi[0] : 0, ry = roi ? roi[1] : 0, rw = roi ? roi[2] : w, rh = roi ? roi[3] : h;
+    // scratch: masks | occupancy | det_out[B][nb] | thresholds | cur kps + image ids | points + image ids | weights
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t occ_sz = (size_t)(nh + 1) * (nw + 1);
+    const size_t off_mask = 0, off_occ = up((size_t)w * h * B), off_out = off_occ + up(occ_sz * B);
+    const size_t off_th = off_out + up(sizeof(det_out) * nb * B), off_cur = off_th + up(sizeof(double) * B);
+    const size_t off_cimg = off_cur + up((size_t)ncur_tot * 8), off_pts = off_cimg + up((size_t)ncur_tot * 4);
+    const size_t off_pimg = off_pts + up((size_t)nb * 2 * 8 * B), off_wm = off_pimg + up((size_t)nb * 2 * 4 * B);
+    void *scr = nullptr;
+    ov2_status s = ov2_scratch(c, off_wm + 1024, &scr);
+    if (s != OV2_OK) return s;
+    char *base = (char *)scr;
+    unsigned char *mask = (unsigned char *)(base + off_mask), *occ = (unsigned char *)(base + off_occ);
+    det_out *dout = (det_out *)(base + off_out);
+    double *dth = (double *)(base + off_th);
+    float2 *dcur = (float2 *)(base + off_cur), *dpts = (float2 *)(base + off_pts);
+    int *dcimg = (int *)(base + off_cimg), *dpimg = (int *)(base + off_pimg);
+    float *dwm = (float *)(base + off_wm);
+    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemsetAsync(mask, 1, (size_t)w * h * B, st));
+    OV2_HIP(c, hipMemsetAsync(occ, 0, occ_sz * B, st));
+    OV2_HIP(c, hipMemsetAsync(dout, 0, sizeof(det_out) * nb * B, st));
+    OV2_HIP(c, hipMemcpyAsync(dth, thresh, sizeof(double) * B, hipMemcpyHostToDevice, st));
+    const disc_shape ds = make_disc(cell / 4);
+    std::vector<int> cimg(ncur_tot);
+    if (ncur_tot > 0) {
+        int k = 0;
+        for (int b = 0; b < B; ++b)
+            for (int q = 0; q < n_cur[b]; ++q) cimg[k++] = b;
+        OV2_HIP(c, hipMemcpyAsync(dcur, cur_xy, (size_t)ncur_tot * 8, hipMemcpyHostToDevice, st));
+        OV2_HIP(c, hipMemcpyAsync(dcimg, cimg.data(), (size_t)ncur_tot * 4, hipMemcpyHostToDevice, st));
+        OV2_LAUNCH(c, OV2_K_DETECT, det_mask_kernel, dim3(ncur_tot), dim3(64), 0, st, dcur, dcimg, ncur_tot, cell, nw, nh, occ,
+                   mask, w, h, ds);
     }
     for (int colour = 0; colour < 4; ++colour) {
         if (mode == OV2_DETECT_MINEIG)
-            OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nb), dim3(256), (size_t)cell * cell * 13, st, img, L.istride, w,
-                       h, cell, nw, colour, occ, mask, ds, rx, ry, rw, rh, *thresh, dout);
+            OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nb, B), dim3(256), (size_t)cell * cell * 13, st, img,
+                       L.img_bstride, L.istride, w, h, cell, nw, nh, colour, occ, mask, ds, rx, ry, rw, rh, dth, dout);
         else
-            OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nb), dim3(256), (size_t)cell * cell * 4, st, img, L.istride, w,
-                       h, cell, nw, colour, occ, mask, ds, th_fast, dout);
+            OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nb, B), dim3(256), (size_t)cell * cell * 4, st, img,
+                       L.img_bstride, L.istride, w, h, cell, nw, nh, colour, occ, mask, ds, dth, dout);
     }
-    std::vector<det_out> hout(nb);
-    OV2_HIP(c, hipMemcpyAsync(hout.data(), dout, sizeof(det_out) * nb, hipMemcpyDeviceToHost, st));
+    std::vector<det_out> hout((size_t)nb * B);
+    OV2_HIP(c, hipMemcpyAsync(hout.data(), dout, sizeof(det_out) * nb * B, hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipStreamSynchronize(st));
-    // assemble in cell order (:393-412 / :532-538) and adapt the threshold (:418-423 / :546-552)
-    int n = 0, nboccup = 0, nbempty = 0;
-    for (int i = 0; i < nb; ++i) {
-        nboccup += hout[i].occupied;
-        nbempty += hout[i].pad;
-        if (hout[i].has_first) { out_xy[2 * n] = hout[i].fx; out_xy[2 * n + 1] = hout[i].fy; ++n; }
-    }
-    if (mode == OV2_DETECT_MINEIG) {
-        if (n + nboccup < nb) {
-            const int nbsec = nb - (n + nboccup);
-            int k = 0;
-            for (int i = 0; i < nb && k < nbsec; ++i)
-                if (hout[i].has_second) { out_xy[2 * n] = hout[i].sx; out_xy[2 * n + 1] = hout[i].sy; ++n; ++k; }
+    // per image: assemble in cell order (:393-412 / :532-538) and adapt the threshold (:418-423 / :546-552)
+    std::vector<int> pimg;
+    std::vector<float> pts;
+    for (int b = 0; b < B; ++b) {
+        const det_out *ho = hout.data() + (size_t)b * nb;
+        float *o = out_xy + (size_t)b * out_cap * 2;
+        int n = 0, nboccup = 0, nbempty = 0;
+        for (int i = 0; i < nb; ++i) {
+            nboccup += ho[i].occupied;
+            nbempty += ho[i].pad;
+            if (ho[i].has_first) { o[2 * n] = ho[i].fx; o[2 * n + 1] = ho[i].fy; ++n; }
         }
-        if ((double)n < 0.33 * (double)(nb - nboccup)) *thresh /= 2.;
-        else if ((double)n > 0.9 * (double)(nb - nboccup)) *thresh *= 1.5;
-    } else {
-        const int cur_th = (int)*thresh;
-        if ((double)n < 0.5 * (double)nbempty && nbempty > 10) *thresh = (double)(int)((double)cur_th * 0.66);
-        else if (n == nbempty) *thresh = (double)(int)((double)cur_th * 1.5);
+        if (mode == OV2_DETECT_MINEIG) {
+            if (n + nboccup < nb) {
+                const int nbsec = nb - (n + nboccup);
+                int k = 0;
+                for (int i = 0; i < nb && k < nbsec; ++i)
+                    if (ho[i].has_second) { o[2 * n] = ho[i].sx; o[2 * n + 1] = ho[i].sy; ++n; ++k; }
+            }
+            if ((double)n < 0.33 * (double)(nb - nboccup)) thresh[b] /= 2.;
+            else if ((double)n > 0.9 * (double)(nb - nboccup)) thresh[b] *= 1.5;
+        } else {
+            const int cur_th = (int)thresh[b];
+            if ((double)n < 0.5 * (double)nbempty && nbempty > 10) thresh[b] = (double)(int)((double)cur_th * 0.66);
+            else if (n == nbempty) thresh[b] = (double)(int)((double)cur_th * 1.5);
+        }
+        n_out[b] = n;
+        for (int k = 0; k < n; ++k) { pts.push_back(o[2 * k]); pts.push_back(o[2 * k + 1]); pimg.push_back(b); }
     }
-    if (n > 0 && do_subpix) {
+    const int ntot = (int)pimg.size();
+    if (ntot > 0 && do_subpix) {
         const int hw = 3, win = 7;
         float wm[49];
         for (int i = 0; i < win; ++i) {
@@ -457,12 +496,47 @@ extern "C" ov2_status ov2_detect_grid(ov2_ctx *c, const ov2_pyr *pyr, int b, int
             }
         }
         OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));
-        OV2_HIP(c, hipMemcpyAsync(dpts, out_xy, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT, subpix_kernel, dim3(n), dim3(64), 0, st, img, L.istride, w, h, n, dpts, hw, 30, 0.01 * 0.01, dwm);
-        OV2_HIP(c, hipMemcpyAsync(out_xy, dpts, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        OV2_HIP(c, hipMemcpyAsync(dpts, pts.data(), (size_t)ntot * 8, hipMemcpyHostToDevice, st));
+        OV2_HIP(c, hipMemcpyAsync(dpimg, pimg.data(), (size_t)ntot * 4, hipMemcpyHostToDevice, st));
+        OV2_LAUNCH(c, OV2_K_DETECT, subpix_kernel, dim3(ntot), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride, w, h, ntot,
+                   dpts, hw, 30, 0.01 * 0.01, dwm);
+        OV2_HIP(c, hipMemcpyAsync(pts.data(), dpts, (size_t)ntot * 8, hipMemcpyDeviceToHost, st));
         OV2_HIP(c, hipStreamSynchronize(st));
+        int k = 0;
+        for (int b = 0; b < B; ++b) {
+            memcpy(out_xy + (size_t)b * out_cap * 2, pts.data() + 2 * (size_t)k, (size_t)n_out[b] * 8);
+            k += n_out[b];
+        }
     }
     OV2_HIP(c, hipGetLastError());
-    *n_out = n;
     return OV2_OK;
+}
+
+extern "C" ov2_status ov2_detect_grid(ov2_ctx *c, const ov2_pyr *pyr, int b, int cell, int mode, double *thresh,
+                                      int n_cur, const float *cur_xy, const int *roi, int do_subpix, int *n_out,
+                                      float *out_xy)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (!pyr || !thresh || !n_out || !out_xy || n_cur < 0) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    const int B = pyr->buf->batch;
+    if (b < 0 || b >= B) return ov2_set_err(c, OV2_ERR_INVALID, "image index %d out of the batch", b);
+    if (B == 1) {
+        const int cap = 2 * (pyr->buf->view.lv[0].w / (cell > 0 ? cell : 1)) * (pyr->buf->view.lv[0].h / (cell > 0 ? cell : 1));
+        return ov2_detect_grid_batch(c, pyr, cell, mode, thresh, &n_cur, cur_xy, roi, do_subpix, n_out, out_xy, cap > 0 ? cap : 1);
+    }
+    // one image of a batch: run the batch call with the other images fully masked out is wasteful; detect on a
+    // single-image view of the pyramid instead
+    ov2_pyr_buf one = *pyr->buf;
+    one.batch = 1;
+    one.view.batch = 1;
+    for (int l = 0; l < one.view.nlevels; ++l) {
+        one.view.lv[l].img_off += one.view.lv[l].img_bstride * b;
+        one.view.lv[l].grad_off += one.view.lv[l].grad_bstride * b;
+    }
+    ov2_pyr tmp;
+    tmp.refs.store(1);
+    tmp.ctx = pyr->ctx;
+    tmp.buf = &one;
+    const int cap = 2 * (one.view.lv[0].w / (cell > 0 ? cell : 1)) * (one.view.lv[0].h / (cell > 0 ? cell : 1));
+    return ov2_detect_grid_batch(c, &tmp, cell, mode, thresh, &n_cur, cur_xy, roi, do_subpix, n_out, out_xy, cap > 0 ? cap : 1);
 }

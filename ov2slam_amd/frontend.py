@@ -278,3 +278,23 @@ class FeatureExtractor:
     def detectGridFAST(self, pyr, vcurkps, roi=None, b=0, subpix=True):
         """src/feature_extractor.cpp:443-570."""
         return self._detect(0, pyr, vcurkps, roi, b, subpix)
+
+
+def detect_grid_batch(ctx, pyr, cell, mode, thresh, cur_list, roi=None, subpix=True):
+    """every image of `pyr` in one call.  thresh: float array [B] (updated in place), cur_list: list of (n_b,2) arrays.
+    returns list of (n_b, 2) float32 arrays."""
+    B = pyr.batch
+    w, h, _ = pyr.level_size(0)
+    cap = max(1, (w // cell) * (h // cell)) * 2
+    n_cur = np.ascontiguousarray([len(c) for c in cur_list], np.int32)
+    cur = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32).reshape(-1, 2) for c in cur_list]) if B else
+                               np.zeros((0, 2)), np.float32)
+    out = np.zeros((B, cap, 2), np.float32)
+    n_out = np.zeros(B, np.int32)
+    r = None if roi is None else np.ascontiguousarray(roi, np.int32)
+    assert thresh.dtype == np.float64 and len(thresh) == B
+    _check(ctx.h, ctx.lib.ov2_detect_grid_batch(ctx.h, pyr.h, cell, mode, thresh.ctypes.data_as(C.POINTER(C.c_double)),
+                                                n_cur.ctypes.data_as(C.POINTER(C.c_int)), cur.ctypes.data_as(C.c_void_p),
+                                                None if r is None else r.ctypes.data_as(C.c_void_p), int(subpix),
+                                                n_out.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.c_void_p), cap))
+    return [out[b, :n_out[b]].copy() for b in range(B)]

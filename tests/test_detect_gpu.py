@@ -71,3 +71,29 @@ def test_detect_edge_cases(ctx, oracle):
     assert len(ex.detectSingleScale(small, np.zeros((0, 2), np.float32))) == 0
     with pytest.raises(Exception):
         fe.FeatureExtractor(ctx, nmaxdist=4).detectSingleScale(pyr, np.zeros((0, 2), np.float32))
+
+
+def test_detect_batched_equals_per_image(ctx, oracle, stream):
+    B = 3
+    raw = [stream.left(t) for t in (0, 3, 7)]
+    imgs = fe.Images(ctx, B, 752, 480)
+    for b in range(B):
+        imgs.upload(b, raw[b])
+    pyr = fe.preprocess_images(ctx, imgs, use_clahe=True)
+    ctx.synchronize()
+    cur = [np.zeros((0, 2), np.float32), np.array([[200.5, 100.25], [50.0, 400.0]], np.float32), np.zeros((0, 2), np.float32)]
+    for mode, cell, th0 in ((1, 35, 0.001), (0, 50, 10.0)):
+        th = np.full(B, th0, np.float64)
+        got = fe.detect_grid_batch(ctx, pyr, cell, mode, th, cur)
+        for b in range(B):
+            cl = oracle.clahe(raw[b])
+            if mode == 1:
+                want, t = oracle.detect_single_scale(cl, cell, cur[b], th0)
+            else:
+                want, t = oracle.detect_grid_fast(cl, cell, cur[b], int(th0))
+            assert np.array_equal(got[b].view(np.uint32), want.view(np.uint32)), (mode, b)
+            assert th[b] == t
+        # single-image call on image 1 of the batch gives the same points
+        ex = fe.FeatureExtractor(ctx, nmaxdist=cell, dmaxquality=th0, nfast_th=int(th0))
+        one = ex.detectSingleScale(pyr, cur[1], b=1) if mode == 1 else ex.detectGridFAST(pyr, cur[1], b=1)
+        assert np.array_equal(one.view(np.uint32), got[1].view(np.uint32))
