@@ -111,6 +111,15 @@ class Workload:
         self.prev = None
         self.step_no = 0
         self.host_frames = (left, right, order, base, S)
+        # keyframe creation (MapManager::extractKeypoints -> detectSingleScale): cell size such that the grid holds
+        # ~kps cells (nmaxdist of the YAML plays this role: 35 px <-> 308 kps); 85 % of the cells hold a tracked kp
+        self.det_cell = max(8, int(np.sqrt(W * H / float(kps))))
+        rng = np.random.default_rng(seed + 5)
+        self.det_cur = [base[rng.uniform(size=len(base)) < 0.85] for _ in range(seqs)]
+        self.det_thresh = np.full(seqs, 0.001, np.float64)
+        self.n_detected = 0
+
+    detect = True
 
     def step(self, kf_every, want_work=False):
         fe, ctx, c = self.fe, self.ctx, self.step_no % self.L
@@ -127,6 +136,9 @@ class Workload:
             self.trk.kltTracking_dev(cur, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
                                      self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, None)
             rp.release()
+            if self.detect:                                                           # 1.FE_createKeyframe (detector)
+                pts = fe.detect_grid_batch(ctx, cur, self.det_cell, 1, self.det_thresh, self.det_cur)
+                self.n_detected += sum(len(p) for p in pts)
         self.step_no += 1
         return is_kf
 
@@ -286,8 +298,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/s16 fixed-point + f32",
         "data": "synthetic",
         "config": {"workload": "synthetic 752x480 stereo streams, CLAHE + 4-level pyramid + 2-stage fwd-bwd KLT "
-                               f"(win 9, 30 it, eps 0.01) on {a.kps} kps/frame, right-image pyramid + stereo KLT every "
-                               f"{a.kf_every}th frame; {a.seqs} sequences per GPU in lock-step",
+                               f"(win 9, 30 it, eps 0.01) on {a.kps} kps/frame; every {a.kf_every}th frame is a keyframe: "
+                               f"right-image pyramid + stereo KLT + grid detector (min-eig, cell {wl.det_cell} px) + "
+                               f"cornerSubPix; {a.seqs} sequences per GPU in lock-step",
                    "sequences_per_gpu": a.seqs, "keypoints_per_frame": a.kps, "kf_every": a.kf_every,
                    "image": [W, H], "parallelism": f"replicas x{world} (one batch of sequences per GPU)"},
         "gpu_stream_ms_per_step": gpu_ms / a.steps,
@@ -334,6 +347,7 @@ def main():
             "level_kernel": a.seqs * float(np.mean(lvl_bytes)),
             "level0_kernel": a.seqs * 2.0 * W * H,
             "clahe_lut_kernel": a.seqs * 1.0 * W * H,
+            "detect_cell_kernels": a.seqs * 2.0 * W * H * 0.15 / 4.0,   # image + mask of the ~15 % free cells, 4 colour launches
         }
         rl = {}
         for k, (ms, cnt) in times.items():

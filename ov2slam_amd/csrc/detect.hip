@@ -78,12 +78,8 @@ __global__ __launch_bounds__(64) void det_mask_kernel(const float2 *__restrict__
     if (k >= n_cur) return;
     const float2 p = cur[k];
     const int bimg = cur_img[k];
-    unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
     unsigned char *mask = mask_all + (size_t)bimg * w * h;
-    if (threadIdx.x == 0) {
-        const int cr = (int)(p.y / (float)cell), cc = (int)(p.x / (float)cell);
-        if (cr >= 0 && cr <= nhcells && cc >= 0 && cc <= nwcells) occ[cr * (nwcells + 1) + cc] = 1;
-    }
+    (void)occ_all; (void)cell; (void)nwcells; (void)nhcells;   // occupancy is computed by the host
     draw_disc(mask, w, h, (int)__builtin_rintf(p.x), (int)__builtin_rintf(p.y), ds);
 }
 
@@ -117,34 +113,28 @@ struct det_out {          // per cell
 // detectSingleScale: one workgroup (256 threads) per cell of the current colour
 __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                          int istride, int w, int h, int cell, int nwcells, int nhcells,
-                                                         int colour, const unsigned char *__restrict__ occ_all,
+                                                         const int2 *__restrict__ work /* (image, cell) of this colour */,
                                                          unsigned char *__restrict__ mask_all, disc_shape ds, int rx,
                                                          int ry, int rw, int rh, const double *__restrict__ quality_all,
                                                          det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
-    const int bimg = blockIdx.y;
+    const int2 item = work[blockIdx.x];   // free, border-valid cells only (the host did :338-350)
+    const int bimg = item.x, i = item.y;
     const unsigned char *img = img0 + img_bstride * bimg;
-    const unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
     unsigned char *mask = mask_all + (size_t)bimg * w * h;
     det_out *out = out_all + (size_t)bimg * nwcells * nhcells;
     const double quality = quality_all[bimg];
-    const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
-    if (((rr & 1) * 2 + (cc & 1)) != colour) return;
-    const int tid = threadIdx.x, n = cell, n2 = cell * cell;
-    if (occ[rr * (nwcells + 1) + cc]) {
-        if (tid == 0) out[i].occupied = 1;
-        return;
-    }
+    const int rr = i / nwcells, cc = i % nwcells;
+    const int tid = threadIdx.x, nth = blockDim.x, n = cell, n2 = cell * cell;
     const int x0 = cc * cell, y0 = rr * cell;
-    if (!(x0 + cell < w - 1 && y0 + cell < h - 1)) return;
     float *dxs = reinterpret_cast<float *>(lds_raw);   // n2
     float *dys = dxs + n2;                              // n2
     float *hmap = dys + n2;                             // n2
     unsigned char *bl = reinterpret_cast<unsigned char *>(hmap + n2);   // n2 blurred cell
     // GaussianBlur 3x3 (fixed point, round half up), parent pixels beyond the cell, REFLECT_101 at the image border
-    for (int p = tid; p < n2; p += 256) {
+    for (int p = tid; p < n2; p += nth) {
         const int y = p / n, x = p - y * n;
         int s = 0;
 #pragma unroll
@@ -158,7 +148,7 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
     __syncthreads();
     const float sc = (float)(1.0 / (4.0 * 3.0 * 255.0)), sc2 = sc * 2.f;
 #define BL(yy, xx) ((float)bl[reflect101((yy), n) * n + reflect101((xx), n)])
-    for (int p = tid; p < n2; p += 256) {
+    for (int p = tid; p < n2; p += nth) {
         const int y = p / n, x = p - y * n;
         const float rm = BL(y - 1, x + 1) - BL(y - 1, x - 1), r0 = BL(y, x + 1) - BL(y, x - 1), rp = BL(y + 1, x + 1) - BL(y + 1, x - 1);
         dxs[p] = sc2 * r0 + sc * (rm + rp);
@@ -168,7 +158,7 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
     }
 #undef BL
     __syncthreads();
-    for (int p = tid; p < n2; p += 256) {
+    for (int p = tid; p < n2; p += nth) {
         const int y = p / n, x = p - y * n;
         double a = 0, b = 0, c = 0;
 #pragma unroll
@@ -187,7 +177,7 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
         unsigned long long key = argmax_key(-3.4028234663852886e38f, 0x7ffffffe);
-        for (int p = tid; p < n2; p += 256) {
+        for (int p = tid; p < n2; p += nth) {
             const int y = p / n, x = p - y * n;
             const float v = mask[(size_t)(y0 + y) * w + x0 + x] ? hmap[p] : 0.f;
             const unsigned long long k2 = argmax_key(v, p);
@@ -255,31 +245,24 @@ __device__ inline int fast_score(const unsigned char *p, int stride, int thresho
 // detectGridFAST: one workgroup per cell of the current colour
 __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                        int istride, int w, int h, int cell, int nwcells, int nhcells,
-                                                       int colour, const unsigned char *__restrict__ occ_all,
+                                                       const int2 *__restrict__ work,
                                                        unsigned char *__restrict__ mask_all, disc_shape ds,
                                                        const double *__restrict__ thresh_all,
                                                        det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
-    const int bimg = blockIdx.y;
+    const int2 item = work[blockIdx.x];
+    const int bimg = item.x, i = item.y;
     const unsigned char *img = img0 + img_bstride * bimg;
-    const unsigned char *occ = occ_all + (size_t)bimg * (nhcells + 1) * (nwcells + 1);
     unsigned char *mask = mask_all + (size_t)bimg * w * h;
     det_out *out = out_all + (size_t)bimg * nwcells * nhcells;
     const int threshold = min(max((int)thresh_all[bimg], 0), 255);
-    const int i = blockIdx.x, rr = i / nwcells, cc = i % nwcells;
-    if (((rr & 1) * 2 + (cc & 1)) != colour) return;
-    const int tid = threadIdx.x, n = cell, n2 = cell * cell;
-    if (occ[rr * (nwcells + 1) + cc]) {
-        if (tid == 0) out[i].occupied = 1;
-        return;
-    }
-    if (tid == 0) out[i].pad = 1;   // counted as "empty" (nbempty++ precedes the border test, :496)
+    const int rr = i / nwcells, cc = i % nwcells;
+    const int tid = threadIdx.x, nth = blockDim.x, n = cell, n2 = cell * cell;
     const int x0 = cc * cell, y0 = rr * cell;
-    if (!(x0 + cell < w - 1 && y0 + cell < h - 1)) return;
     int *score = reinterpret_cast<int *>(lds_raw);
-    for (int p = tid; p < n2; p += 256) {
+    for (int p = tid; p < n2; p += nth) {
         const int y = p / n, x = p - y * n;
         int s = 0;
         if (x >= 3 && x < n - 3 && y >= 3 && y < n - 3) s = fast_score(img + (size_t)(y0 + y) * istride + x0 + x, istride, threshold);
@@ -287,7 +270,7 @@ __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__re
     }
     __syncthreads();
     unsigned long long key = 0ull;   // scores are > 0
-    for (int p = tid; p < n2; p += 256) {
+    for (int p = tid; p < n2; p += nth) {
         const int y = p / n, x = p - y * n;
         const int s = score[p];
         if (s <= 0) continue;
@@ -345,21 +328,25 @@ __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restr
         __syncthreads();
         float nx = cIx, ny = cIy;
         int stop = 0;
-        if (lane == 0) {
+        {
+            // lane t < win*win owns window term t; the five sums are a fixed 64-leaf xor butterfly in double (the order
+            // the oracle uses), after which every lane holds the totals and solves the 2x2 system redundantly
             double A = 0, Bm = 0, C = 0, bb1 = 0, bb2 = 0;
-            for (int i = 0; i < win; ++i) {
-                const double py = i - hw;
-                for (int j = 0; j < win; ++j) {
-                    const float *sp = buf + (i + 1) * bw + (j + 1);
-                    const double m = wmask[i * win + j];
-                    const double tgx = sp[1] - sp[-1];
-                    const double tgy = sp[bw] - sp[-bw];
-                    const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                    const double px = j - hw;
-                    A += gxx; Bm += gxy; C += gyy;
-                    bb1 += gxx * px + gxy * py;
-                    bb2 += gxy * px + gyy * py;
-                }
+            if (lane < win * win) {
+                const int i = lane / win, j = lane - i * win;
+                const float *sp = buf + (i + 1) * bw + (j + 1);
+                const double m = wmask[lane];
+                const double tgx = sp[1] - sp[-1];
+                const double tgy = sp[bw] - sp[-bw];
+                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                const double px = j - hw, py = i - hw;
+                A = gxx; Bm = gxy; C = gyy;
+                bb1 = gxx * px + gxy * py;
+                bb2 = gxy * px + gyy * py;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                A += __shfl_xor(A, o); Bm += __shfl_xor(Bm, o); C += __shfl_xor(C, o);
+                bb1 += __shfl_xor(bb1, o); bb2 += __shfl_xor(bb2, o);
             }
             const double det = A * C - Bm * Bm;
             if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) stop = 1;
@@ -369,9 +356,6 @@ __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restr
                 ny = (float)(cIy - Bm * scale * bb1 + A * scale * bb2);
             }
         }
-        stop = __shfl(stop, 0);
-        nx = __shfl(nx, 0);
-        ny = __shfl(ny, 0);
         __syncthreads();
         if (stop) break;
         err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
@@ -417,8 +401,9 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
     const size_t off_th = off_out + up(sizeof(det_out) * nb * B), off_cur = off_th + up(sizeof(double) * B);
     const size_t off_cimg = off_cur + up((size_t)ncur_tot * 8), off_pts = off_cimg + up((size_t)ncur_tot * 4);
     const size_t off_pimg = off_pts + up((size_t)nb * 2 * 8 * B), off_wm = off_pimg + up((size_t)nb * 2 * 4 * B);
+    const size_t off_work = off_wm + 1024;
     void *scr = nullptr;
-    ov2_status s = ov2_scratch(c, off_wm + 1024, &scr);
+    ov2_status s = ov2_scratch(c, off_work + sizeof(int2) * (size_t)nb * B + 256, &scr);
     if (s != OV2_OK) return s;
     char *base = (char *)scr;
     unsigned char *mask = (unsigned char *)(base + off_mask), *occ = (unsigned char *)(base + off_occ);
@@ -429,27 +414,61 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
     float *dwm = (float *)(base + off_wm);
     hipStream_t st = c->stream;
     OV2_HIP(c, hipMemsetAsync(mask, 1, (size_t)w * h * B, st));
-    OV2_HIP(c, hipMemsetAsync(occ, 0, occ_sz * B, st));
     OV2_HIP(c, hipMemsetAsync(dout, 0, sizeof(det_out) * nb * B, st));
     OV2_HIP(c, hipMemcpyAsync(dth, thresh, sizeof(double) * B, hipMemcpyHostToDevice, st));
     const disc_shape ds = make_disc(cell / 4);
     std::vector<int> cimg(ncur_tot);
-    if (ncur_tot > 0) {
+    // occupancy (voccupcells, :316-320 / :466-470) and the per-colour lists of free, border-valid cells (:338-350)
+    std::vector<unsigned char> hocc(occ_sz * B, 0);
+    {
         int k = 0;
         for (int b = 0; b < B; ++b)
-            for (int q = 0; q < n_cur[b]; ++q) cimg[k++] = b;
+            for (int q = 0; q < n_cur[b]; ++q, ++k) {
+                cimg[k] = b;
+                const float px = cur_xy[2 * k], py = cur_xy[2 * k + 1];
+                const int cr = (int)(py / (float)cell), cc = (int)(px / (float)cell);
+                if (cr >= 0 && cr <= nh && cc >= 0 && cc <= nw) hocc[(size_t)b * occ_sz + cr * (nw + 1) + cc] = 1;
+            }
+    }
+    std::vector<int2> work[4];
+    std::vector<int> h_occupied(B, 0), h_empty(B, 0);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < nb; ++i) {
+            const int rr = i / nw, cc = i % nw;
+            if (hocc[(size_t)b * occ_sz + rr * (nw + 1) + cc]) { h_occupied[b]++; continue; }
+            h_empty[b]++;
+            if (!(cc * cell + cell < w - 1 && rr * cell + cell < h - 1)) continue;
+            work[(rr & 1) * 2 + (cc & 1)].push_back(make_int2(b, i));
+        }
+    int2 *dwork = nullptr;   // the work lists live at the end of the scratch block
+    if (ncur_tot > 0) {
         OV2_HIP(c, hipMemcpyAsync(dcur, cur_xy, (size_t)ncur_tot * 8, hipMemcpyHostToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(dcimg, cimg.data(), (size_t)ncur_tot * 4, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT, det_mask_kernel, dim3(ncur_tot), dim3(64), 0, st, dcur, dcimg, ncur_tot, cell, nw, nh, occ,
+        OV2_LAUNCH(c, OV2_K_DETECT + 1, det_mask_kernel, dim3(ncur_tot), dim3(64), 0, st, dcur, dcimg, ncur_tot, cell, nw, nh, occ,
                    mask, w, h, ds);
     }
+    dwork = (int2 *)(base + off_work);
+    {
+        size_t o = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (!work[k].empty())
+                OV2_HIP(c, hipMemcpyAsync(dwork + o, work[k].data(), work[k].size() * sizeof(int2), hipMemcpyHostToDevice, st));
+            o += work[k].size();
+        }
+    }
+    const int nthreads = (cell * cell <= 256) ? 64 : 256;   // small cells: one wave walks the cell
+    size_t woff = 0;
     for (int colour = 0; colour < 4; ++colour) {
-        if (mode == OV2_DETECT_MINEIG)
-            OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nb, B), dim3(256), (size_t)cell * cell * 13, st, img,
-                       L.img_bstride, L.istride, w, h, cell, nw, nh, colour, occ, mask, ds, rx, ry, rw, rh, dth, dout);
-        else
-            OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nb, B), dim3(256), (size_t)cell * cell * 4, st, img,
-                       L.img_bstride, L.istride, w, h, cell, nw, nh, colour, occ, mask, ds, dth, dout);
+        const int nitems = (int)work[colour].size();
+        if (nitems > 0) {
+            if (mode == OV2_DETECT_MINEIG)
+                OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 13, st, img,
+                           L.img_bstride, L.istride, w, h, cell, nw, nh, dwork + woff, mask, ds, rx, ry, rw, rh, dth, dout);
+            else
+                OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 4, st, img,
+                           L.img_bstride, L.istride, w, h, cell, nw, nh, dwork + woff, mask, ds, dth, dout);
+        }
+        woff += nitems;
     }
     std::vector<det_out> hout((size_t)nb * B);
     OV2_HIP(c, hipMemcpyAsync(hout.data(), dout, sizeof(det_out) * nb * B, hipMemcpyDeviceToHost, st));
@@ -461,9 +480,9 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
         const det_out *ho = hout.data() + (size_t)b * nb;
         float *o = out_xy + (size_t)b * out_cap * 2;
         int n = 0, nboccup = 0, nbempty = 0;
+        nboccup = h_occupied[b];
+        nbempty = h_empty[b];
         for (int i = 0; i < nb; ++i) {
-            nboccup += ho[i].occupied;
-            nbempty += ho[i].pad;
             if (ho[i].has_first) { o[2 * n] = ho[i].fx; o[2 * n + 1] = ho[i].fy; ++n; }
         }
         if (mode == OV2_DETECT_MINEIG) {
@@ -498,7 +517,7 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
         OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(dpts, pts.data(), (size_t)ntot * 8, hipMemcpyHostToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(dpimg, pimg.data(), (size_t)ntot * 4, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT, subpix_kernel, dim3(ntot), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride, w, h, ntot,
+        OV2_LAUNCH(c, OV2_K_DETECT + 2, subpix_kernel, dim3(ntot), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride, w, h, ntot,
                    dpts, hw, 30, 0.01 * 0.01, dwm);
         OV2_HIP(c, hipMemcpyAsync(pts.data(), dpts, (size_t)ntot * 8, hipMemcpyDeviceToHost, st));
         OV2_HIP(c, hipStreamSynchronize(st));
