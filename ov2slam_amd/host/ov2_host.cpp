@@ -257,6 +257,122 @@ bool FeatureTracker::inBorder(const Point2f &pt, int cols, int rows) const
     return B <= pt.x && pt.x < cols - B && B <= pt.y && pt.y < rows - B;
 }
 
+// ---------------------------------------------------------------------------------------------- FeatureExtractor
+std::vector<Point2f> FeatureExtractor::detect(const Pyramid &pyr, int ncellsize, int mode, const std::vector<Point2f> &vcurkps,
+                                              const int roi[4])
+{
+    std::vector<Point2f> out;
+    int w = 0, h = 0;
+    if (pyr.empty() || ov2_pyr_level_size(pyr.h, 0, &w, &h, nullptr) != OV2_OK || ncellsize <= 0) { last_status_ = OV2_ERR_INVALID; return out; }
+    const int cap = 2 * (w / ncellsize) * (h / ncellsize) + 2;
+    out.resize(cap);
+    double th = mode == OV2_DETECT_MINEIG ? dmaxquality_ : (double)nfast_th_;
+    int n = 0;
+    last_status_ = ov2_detect_grid(ctx_, pyr.h, 0, ncellsize, mode, &th, (int)vcurkps.size(),
+                                   vcurkps.empty() ? nullptr : &vcurkps[0].x, roi, 1, &n, &out[0].x);
+    if (last_status_ != OV2_OK) n = 0;
+    else if (mode == OV2_DETECT_MINEIG) dmaxquality_ = th;   // :418-423
+    else nfast_th_ = (int)th;                                 // :546-552
+    out.resize(n);
+    return out;
+}
+
+std::vector<Point2f> FeatureExtractor::detectSingleScale(const Pyramid &pyr, int ncellsize, const std::vector<Point2f> &vcurkps,
+                                                         const int roi[4])
+{
+    return detect(pyr, ncellsize, OV2_DETECT_MINEIG, vcurkps, roi);
+}
+
+std::vector<Point2f> FeatureExtractor::detectGridFAST(const Pyramid &pyr, int ncellsize, const std::vector<Point2f> &vcurkps,
+                                                      const int roi[4])
+{
+    return detect(pyr, ncellsize, OV2_DETECT_FAST, vcurkps, roi);
+}
+
+// ---------------------------------------------------------------------------------------------- stereoMatching
+ov2_status MapManager::stereoMatching(Frame &frame, const Pyramid &vleftpyr, const Pyramid &vrightpyr,
+                                      const FeatureTracker &tracker, const SlamParams &st, bool rectified)
+{
+    std::vector<int> v3dkpids, vkpids;
+    std::vector<Point2f> v3dkps, v3dpriors, vkps, vpriors;
+    const CameraCalibration &cr = *frame.pcalib_rightcam_;
+    const SE3 Trl = cr.Tc0ci_.inverse();
+    for (const auto &it : frame.mapkps_) {   // :385-490 priors
+        const Keypoint &kp = it.second;
+        if (kp.is3d_) {
+            auto plm = getMapPoint(kp.lmid_);
+            if (plm) {   // :398-420 reprojection of the 3D point into the right camera
+                const Vec3 pr = Trl * (frame.getTcw() * plm->getPoint());
+                if (pr.z > 0.1) {
+                    const Vec3 px = cr.projectCamToImage(pr);
+                    const Point2f p{(float)px.x, (float)px.y};
+                    if (p.x >= 0 && p.y >= 0 && p.x < cr.img_w_ && p.y < cr.img_h_) {
+                        v3dkps.push_back(kp.px_); v3dpriors.push_back(p); v3dkpids.push_back(kp.lmid_);
+                        continue;
+                    }
+                }
+            }
+        }
+        vkpids.push_back(kp.lmid_); vkps.push_back(kp.px_); vpriors.push_back(kp.px_);
+    }
+    std::vector<int> vgoodids;
+    std::vector<Point2f> vgoodl, vgoodr;
+    if (!v3dkps.empty()) {   // :505-540, 2 levels
+        std::vector<bool> ok;
+        ov2_status s = tracker.fbKltTracking(vleftpyr, vrightpyr, st.nklt_win_size_, 1, st.nklt_err_, st.fmax_fbklt_dist_,
+                                             v3dkps, v3dpriors, ok);
+        if (s != OV2_OK) return s;
+        for (size_t i = 0; i < v3dkps.size(); ++i) {
+            if (ok[i]) { vgoodids.push_back(v3dkpids[i]); vgoodl.push_back(v3dkps[i]); vgoodr.push_back(v3dpriors[i]); }
+            else { vkpids.push_back(v3dkpids[i]); vkps.push_back(v3dkps[i]); vpriors.push_back(v3dkps[i]); }   // :533-537
+        }
+    }
+    if (!vkps.empty()) {     // :545-580, full pyramid
+        std::vector<bool> ok;
+        ov2_status s = tracker.fbKltTracking(vleftpyr, vrightpyr, st.nklt_win_size_, st.nklt_pyr_lvl_, st.nklt_err_,
+                                             st.fmax_fbklt_dist_, vkps, vpriors, ok);
+        if (s != OV2_OK) return s;
+        for (size_t i = 0; i < vkps.size(); ++i)
+            if (ok[i]) { vgoodids.push_back(vkpids[i]); vgoodl.push_back(vkps[i]); vgoodr.push_back(vpriors[i]); }
+    }
+    // epipolar gate :585-605 (fmax_proj_pxdist = 2 px)
+    const float epi_th = 2.f;
+    double F[9] = {0};
+    if (!rectified) {   // F_rl = K_r^-T [t]x R K_l^-1 from the extrinsic
+        double R[9];
+        Trl.rotation(R);
+        const double t[3] = {Trl.v[0], Trl.v[1], Trl.v[2]};
+        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        double E[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) E[3 * i + j] = tx[3 * i] * R[j] + tx[3 * i + 1] * R[3 + j] + tx[3 * i + 2] * R[6 + j];
+        const CameraCalibration &cl = *frame.pcalib_leftcam_;
+        const double Kli[9] = {1 / cl.fx_, 0, -cl.cx_ / cl.fx_, 0, 1 / cl.fy_, -cl.cy_ / cl.fy_, 0, 0, 1};
+        const double Krit[9] = {1 / cr.fx_, 0, 0, 0, 1 / cr.fy_, 0, -cr.cx_ / cr.fx_, -cr.cy_ / cr.fy_, 1};
+        double T[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) T[3 * i + j] = E[3 * i] * Kli[j] + E[3 * i + 1] * Kli[3 + j] + E[3 * i + 2] * Kli[6 + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) F[3 * i + j] = Krit[3 * i] * T[j] + Krit[3 * i + 1] * T[3 + j] + Krit[3 * i + 2] * T[6 + j];
+    }
+    for (size_t i = 0; i < vgoodids.size(); ++i) {
+        const Point2f l = vgoodl[i], r = vgoodr[i];
+        bool good;
+        if (rectified) good = std::fabs(l.y - r.y) <= epi_th;
+        else {   // distance of the right point to the epipolar line F * x_l
+            const double a = F[0] * l.x + F[1] * l.y + F[2], b = F[3] * l.x + F[4] * l.y + F[5], c = F[6] * l.x + F[7] * l.y + F[8];
+            good = std::fabs(a * r.x + b * r.y + c) / std::sqrt(a * a + b * b) <= epi_th;
+        }
+        auto it = frame.mapkps_.find(vgoodids[i]);
+        if (!good || it == frame.mapkps_.end()) continue;
+        if (!it->second.is_stereo_) frame.nb_stereo_kps_++;   // Frame::updateKeypointStereo
+        it->second.is_stereo_ = true;
+        it->second.rpx_ = r;
+        it->second.runpx_ = r;
+    }
+    return OV2_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- VisualFrontEnd
 ov2_status VisualFrontEnd::preprocessImage(const uint8_t *img_raw, int w, int h, int stride)
 {   // src/visual_front_end.cpp:1143-1177: swap pyramids, CLAHE (tiles w/50 x h/50, src/ov2slam.cpp:85-89), pyramid

@@ -113,6 +113,13 @@ public:
     void removeMapPoint(int lmid);
     void removeObsFromCurFrameById(int lmid);
     void updateFrameCovisibility(Frame &frame);   // src/map_manager.cpp: co-observation counts
+    // src/map_manager.cpp:367-611: left->right KLT of the keyframe's keypoints (3D ones from their reprojection into the
+    // right camera on 2 levels, the rest and the failures on the full pyramid), then the epipolar gate (rectified
+    // rows: |dy| <= 2 px; otherwise distance to the epipolar line of F_rl <= 2 px) -> Frame stereo keypoints.
+    // The SAD line search / neighbour-depth priors of :429-483 are host heuristics outside the kernel path and are
+    // not reproduced: keypoints without a 3D prior start from their left pixel.
+    ov2_status stereoMatching(Frame &frame, const struct Pyramid &vleftpyr, const struct Pyramid &vrightpyr,
+                              const class FeatureTracker &tracker, const struct SlamParams &st, bool rectified);
 };
 
 struct SlamParams {   // the subset of include/slam_params.hpp the path reads (YAML keys of the same name)
@@ -149,6 +156,24 @@ public:
     ov2_ctx *ctx_;
     int nmax_iter_;
     float fmax_px_precision_;
+};
+
+class FeatureExtractor {   // include/feature_extractor.hpp:37-55 (grid detectors + their adaptive thresholds)
+public:
+    FeatureExtractor(ov2_ctx *ctx, size_t nmaxpts, size_t nmaxdist, double dmaxquality, int nfast_th)
+        : ctx_(ctx), nmaxpts_(nmaxpts), nmaxdist_(nmaxdist), dmaxquality_(dmaxquality), nfast_th_(nfast_th) {}
+    // both run on level 0 of `pyr` (the CLAHE'd frame the reference passes as `im`); roi = {x,y,w,h}
+    std::vector<Point2f> detectSingleScale(const Pyramid &pyr, int ncellsize, const std::vector<Point2f> &vcurkps,
+                                           const int roi[4]);   // src/feature_extractor.cpp:288-440
+    std::vector<Point2f> detectGridFAST(const Pyramid &pyr, int ncellsize, const std::vector<Point2f> &vcurkps,
+                                        const int roi[4]);      // :443-570
+    ov2_status last_status_ = OV2_OK;
+    ov2_ctx *ctx_;
+    size_t nmaxpts_, nmaxdist_;
+    double dmaxquality_;
+    int nfast_th_;
+private:
+    std::vector<Point2f> detect(const Pyramid &pyr, int ncellsize, int mode, const std::vector<Point2f> &vcurkps, const int roi[4]);
 };
 
 class VisualFrontEnd {   // src/visual_front_end.cpp (preprocessImage + kltTracking)
