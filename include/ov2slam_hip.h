@@ -232,6 +232,26 @@ void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th);
  * p->pose / p->lm are HOST pointers, updated in place for the non-constant blocks. */
 ov2_status ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Motion-only BA (pose refinement on fixed 3D points).
+ * Replaces MultiViewGeometry::ceresPnP(vunkps, vwpts, vscales, Twc, nmaxiter, chi2th, buse_robust,
+ * bapply_l2_after_robust, fx, fy, cx, cy, voutliersidx)  include/multi_view_geometry.hpp:104,
+ * src/multi_view_geometry.cpp:492-586, called per frame by VisualFrontEnd::computePose
+ * (src/visual_front_end.cpp:791) and by the relocalisation / loop-closure checks.
+ * B independent frames per call (B = 1 reproduces the reference call), frame b owns n_pts[b] consecutive
+ * entries of the point arrays.  All pointers are HOST pointers.
+ *   unpx   sum(n) x 2   undistorted pixel observations        wpts   sum(n) x 3  world points
+ *   scales sum(n)       pyramid octave of each keypoint (sigma = 2^scale), NULL = all 0
+ *   K      B x 4        fx fy cx cy                            Twc    B x 7  [t, qx qy qz qw], updated in place
+ *   outlier sum(n)      1 where chi2 > chi2th or depth <= 0 after the robust solve (voutliersidx as a mask)
+ *   success B           the reference's bool return: 0 if the solver failed or every point was flagged
+ *                       (in the second case Twc[b] is left untouched, :573-575)
+ *   iters  B x 2        (may be NULL) LM iterations of the robust solve and of the L2 re-solve
+ * The reference's 5 ms wall-clock cap (:533-535) is not reproduced (non-deterministic), nmaxiter is. */
+ov2_status ov2_pnp_solve_batch(ov2_ctx *ctx, int B, const int *n_pts, const double *unpx, const double *wpts,
+                               const int *scales, const double *K, double *Twc, int max_iters, float chi2th,
+                               int use_robust, int l2_after_robust, uint8_t *outlier, int *success, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,6 +161,9 @@ def _ba_lib():
         L.ov2o_schur_solve.restype = C.c_int
         L.ov2o_ba_default_options.argtypes = [C.POINTER(T.BaOptionsC), C.c_float]
         L.ov2o_ba_solve.argtypes = [C.POINTER(T.BaProblemC), C.POINTER(T.BaOptionsC), C.POINTER(T.BaResultC)]
+        L.ov2o_pnp_solve.argtypes = [C.c_int, f64p, f64p, i32p, f64p, f64p, C.c_int, C.c_float, C.c_int, C.c_int,
+                                     u8p, i32p]
+        L.ov2o_pnp_solve.restype = C.c_int
         L._ba_bound = True
     return L
 
@@ -233,6 +236,23 @@ def ba_solve(prob, options=None):
     rc = L.ov2o_ba_solve(C.byref(pc), C.byref(o), C.byref(res.c))
     assert rc == 0
     return res
+
+
+def pnp_solve(unpx, wpts, K, Twc, scales=None, max_iters=5, chi2th=5.9915, use_robust=True, l2_after_robust=True):
+    """MultiViewGeometry::ceresPnP on one frame. returns (success, Twc_out, outlier mask, (it_robust, it_l2))."""
+    L = _ba_lib()
+    unpx = np.ascontiguousarray(unpx, np.float64).reshape(-1, 2)
+    wpts = np.ascontiguousarray(wpts, np.float64).reshape(-1, 3)
+    n = len(unpx)
+    K = np.ascontiguousarray(K, np.float64)
+    T = np.array(Twc, np.float64).copy()
+    out = np.zeros(max(n, 1), np.uint8)
+    it = np.zeros(2, np.int32)
+    sc = None if scales is None else np.ascontiguousarray(scales, np.int32)
+    ok = L.ov2o_pnp_solve(n, _p(unpx, f64p), _p(wpts, f64p), None if sc is None else _p(sc, i32p), _p(K, f64p),
+                          _p(T, f64p), max_iters, chi2th, int(use_robust), int(l2_after_robust), _p(out, u8p),
+                          _p(it, i32p))
+    return bool(ok), T, out[:n].astype(bool), (int(it[0]), int(it[1]))
 
 
 # ---------------------------------------------------------------------------------------------------

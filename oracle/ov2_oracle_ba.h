@@ -40,6 +40,10 @@ typedef struct ov2o_bs_problem {
 /* returns 0, -1 (reduced system not positive definite), -2 (E'E singular). S_out (n_f*F)^2, rhs_out optional. */
 int ov2o_schur_solve(const ov2o_bs_problem *p, double *S_out, double *rhs_out, double *x);
 
+/* MultiViewGeometry::ceresPnP (src/multi_view_geometry.cpp:492-586): motion-only LM on one pose. */
+int ov2o_pnp_solve(int n, const double *unpx, const double *wpts, const int *scales, const double K[4], double *Twc,
+                   int max_iters, float chi2th, int use_robust, int l2_after_robust, uint8_t *outlier, int *iters);
+
 void ov2o_ba_default_options(ov2_ba_options *o, float robust_mono_th);
 int ov2o_ba_solve(const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R);
 

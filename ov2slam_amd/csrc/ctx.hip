@@ -51,6 +51,7 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return OV2_ERR_HIP;
@@ -64,7 +65,10 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream_pyr);
     for (ov2_pyr_buf *b : c->pool) {
+        (void)hipEventDestroy(b->ready_ev);
+        (void)hipEventDestroy(b->free_ev);
         (void)hipFree(b->base);
         if (b->lut) (void)hipFree(b->lut);
         delete b;
@@ -77,12 +81,14 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream_pyr);
     delete c;
 }
 
 extern "C" ov2_status ov2_ctx_synchronize(ov2_ctx *c)
 {
     if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     return OV2_OK;
 }
@@ -197,7 +203,8 @@ const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", 
                                            "ba_eval_kernel", "ba_colnorm_kernel", "ba_scale_kernels", "ba_lmdiag_kernel",
                                            "ba_sinit_kernel", "ba_schur_kernel", "ba_chol_kernel", "ba_backsub_kernel",
                                            "ba_plus_kernel", "ba_flag_kernel", "ba_reduce_kernel", "ba_misc_kernels",
-                                           nullptr, nullptr, "detect_cell_kernels", "detect_mask_kernel", "subpix_kernel"};
+                                           nullptr, nullptr, "detect_cell_kernels", "detect_mask_kernel", "subpix_kernel",
+                                           "pnp_kernel"};
 
 static hipEvent_t ktime_event(ov2_ctx *c)
 {
@@ -211,17 +218,17 @@ static hipEvent_t ktime_event(ov2_ctx *c)
     return e;
 }
 
-void ov2_ktime_begin(ov2_ctx *c, int id)
+void ov2_ktime_begin(ov2_ctx *c, int id, hipStream_t st)
 {
     ov2_ktime_rec r;
     r.id = id;
     r.e0 = ktime_event(c);
     r.e1 = ktime_event(c);
-    (void)hipEventRecord(r.e0, c->stream);
+    (void)hipEventRecord(r.e0, st);
     c->ktime_recs.push_back(r);
 }
 
-void ov2_ktime_end(ov2_ctx *c) { (void)hipEventRecord(c->ktime_recs.back().e1, c->stream); }
+void ov2_ktime_end(ov2_ctx *c, hipStream_t st) { (void)hipEventRecord(c->ktime_recs.back().e1, st); }
 
 extern "C" ov2_status ov2_ktime_enable(ov2_ctx *c, int on)
 {
@@ -234,6 +241,7 @@ extern "C" ov2_status ov2_ktime_report(ov2_ctx *c, int max_kernels, const char *
                                        long long *launches, int *n_out)
 {
     if (!c || !n_out || max_kernels < 0) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     double tot[OV2_K_MAX] = {0};
     long long cnt[OV2_K_MAX] = {0};

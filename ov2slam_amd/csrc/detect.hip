@@ -379,6 +379,10 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
         return ov2_set_err(c, OV2_ERR_INVALID, "cell size %d unsupported (8..%d)", cell, DET_MAX_CELL);
     if (mode != OV2_DETECT_FAST && mode != OV2_DETECT_MINEIG) return ov2_set_err(c, OV2_ERR_INVALID, "mode %d", mode);
     OV2_HIP(c, hipSetDevice(c->device));
+    {
+        const ov2_status ws = ov2_pyr_wait_ready(c, pyr);
+        if (ws != OV2_OK) return ws;
+    }
     const ov2_pyr_view &v = pyr->buf->view;
     const ov2_level_desc &L = v.lv[0];
     const int B = pyr->buf->batch, w = L.w, h = L.h;

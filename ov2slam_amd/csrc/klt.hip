@@ -416,6 +416,7 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     ov2_status s = make_params(c, prev, cur, win, nlevels, max_iter, eps, err_th, fb_th, &P);
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
+    if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
 #define KLT_FB(W)                                                                                              \
     OV2_LAUNCH(c, OV2_K_KLT_FB, klt_fb_kernel<W>, dim3((n + 3) / 4), dim3(64), 0, c->stream, prev->buf->view,  \
                cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_priors), \
@@ -470,6 +471,7 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     ov2_status s = make_params(c, prev, cur, win, nlevels_full, max_iter, eps, err_th, fb_th, &P);
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
+    if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
     const int B = prev->buf->batch;
     void *scr = nullptr;
     s = ov2_scratch(c, (size_t)B * 64 * sizeof(unsigned) + 256, &scr);

@@ -40,6 +40,9 @@ struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,ba
     size_t bytes;
     unsigned char *base;
     unsigned char *lut;  // CLAHE LUTs: batch * tiles * 256 (allocated lazily, max tiles 64x64)
+    hipEvent_t ready_ev; // recorded on the ctx pyramid stream when the build is enqueued; consumers wait on it
+    hipEvent_t free_ev;  // recorded on the ctx main stream when the last handle is released; the next build waits on it
+    bool has_free_ev;
     ov2_pyr_view view;
 };
 
@@ -58,7 +61,8 @@ struct ov2_ktime_rec {
 
 struct ov2_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;                  // main stream: KLT, detectors, BA
+    hipStream_t stream_pyr;              // pyramid builds run here so that frame t+1's pyramid overlaps frame t's KLT
     hipEvent_t ev0, ev1;
     std::mutex mu;                       // guards pool + err
     std::vector<ov2_pyr_buf *> pool;     // free pyramid buffers
@@ -101,13 +105,16 @@ ov2_status ov2_scratch(ov2_ctx *ctx, size_t bytes, void **out);
     } while (0)
 
 // bracket a launch with events when kernel timing is enabled
-void ov2_ktime_begin(ov2_ctx *c, int id);
-void ov2_ktime_end(ov2_ctx *c);
-#define OV2_LAUNCH(ctx, id, ...)            \
+void ov2_ktime_begin(ov2_ctx *c, int id, hipStream_t st);
+void ov2_ktime_end(ov2_ctx *c, hipStream_t st);
+// make the ctx main stream wait for the build of `p` (enqueued on the pyramid stream)
+ov2_status ov2_pyr_wait_ready(ov2_ctx *c, const ov2_pyr *p);
+#define OV2_LAUNCH_ON(ctx, id, st, ...)     \
     do {                                    \
-        if ((ctx)->ktime_on) ov2_ktime_begin((ctx), (id)); \
+        if ((ctx)->ktime_on) ov2_ktime_begin((ctx), (id), (st)); \
         hipLaunchKernelGGL(__VA_ARGS__);    \
-        if ((ctx)->ktime_on) ov2_ktime_end((ctx)); \
+        if ((ctx)->ktime_on) ov2_ktime_end((ctx), (st)); \
     } while (0)
+#define OV2_LAUNCH(ctx, id, ...) OV2_LAUNCH_ON(ctx, id, (ctx)->stream, __VA_ARGS__)
 
 static inline int ov2_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -170,11 +170,109 @@ __global__ __launch_bounds__(64) void level0_kernel(const unsigned char *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// level 0, CLAHE path, tiled: one workgroup = 64 x 64 px, the <= (64/tw+3) x (64/th+3) tile LUTs that its pixels
+// interpolate between are staged in LDS once (3 KB for EuRoC geometry) instead of 16 L1/L2 byte gathers per thread.
+// Same arithmetic as level0_kernel (which remains the fallback for exotic tile geometries and the copy path).
+__global__ __launch_bounds__(256) void level0_clahe_tiled_kernel(const unsigned char *__restrict__ src, int w, int h,
+                                                                 int sstride, size_t sbstride,
+                                                                 const unsigned char *__restrict__ lut, int tiles_x,
+                                                                 int tiles_y, float inv_tw, float inv_th, int ncx_max,
+                                                                 ov2_pyr_view pv)
+{
+    // tile = 64 x 64 px; a thread owns 4 px in each of 4 rows (y0+ty, +16, +32, +48) and issues its 4 source loads
+    // back to back: the kernel is bound by the number of memory round trips per resident wave, not by bandwidth.
+    extern __shared__ __attribute__((aligned(16))) unsigned char llds[];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const int xl = min(x0 + 63, w - 1), yl = min(y0 + 63, h - 1);
+    const int cx_lo = max((int)floorf((float)x0 * inv_tw - 0.5f), 0);
+    const int cx_hi = min((int)floorf((float)xl * inv_tw - 0.5f) + 1, tiles_x - 1);
+    const int cy_lo = max((int)floorf((float)y0 * inv_th - 0.5f), 0);
+    const int cy_hi = min((int)floorf((float)yl * inv_th - 0.5f) + 1, tiles_y - 1);
+    const int ncx = cx_hi - cx_lo + 1, ncy = cy_hi - cy_lo + 1;
+    const int x = x0 + 4 * (tid & 15), ty = tid >> 4;
+    const int nvalid = min(4, w - x);
+    const unsigned char *sb = src + sbstride * b;
+    unsigned int raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + ty + 16 * k;
+        raw[k] = 0;
+        if (x < w && y < h) {
+            const unsigned char *srow = sb + (size_t)y * sstride;
+            if (nvalid == 4) raw[k] = *reinterpret_cast<const unsigned int *>(srow + x);
+            else for (int i = 0; i < nvalid; ++i) raw[k] |= (unsigned int)srow[x + i] << (8 * i);
+        }
+    }
+    const unsigned char *lb = lut + (size_t)b * tiles_x * tiles_y * 256;
+    for (int i = tid; i < ncx * ncy * 64; i += 256) {   // dwords
+        const int t = i >> 6, d = i & 63;
+        const int cy = t / ncx, cx = t - cy * ncx;
+        reinterpret_cast<unsigned int *>(llds)[(cy * ncx_max + cx) * 64 + d] =
+            reinterpret_cast<const unsigned int *>(lb + ((size_t)(cy_lo + cy) * tiles_x + cx_lo + cx) * 256)[d];
+    }
+    __syncthreads();
+    if (x >= w) return;
+    const ov2_level_desc L = pv.lv[0];
+    unsigned char *plane = pv.base + L.img_off + L.img_bstride * b;
+    // the x interpolation terms are shared by the 4 rows
+    float xa[4], xa1[4];
+    int o1[4], o2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float txf = (float)(x + i) * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf);
+        int tx2 = tx1 + 1;
+        xa[i] = txf - (float)tx1;
+        xa1[i] = 1.0f - xa[i];
+        tx1 = max(tx1, 0);
+        tx2 = min(tx2, tiles_x - 1);
+        o1[i] = min(max(tx1 - cx_lo, 0), ncx - 1) * 256;
+        o2[i] = min(max(tx2 - cx_lo, 0), ncx - 1) * 256;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = y0 + ty + 16 * k;
+        if (y >= h) break;
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1;
+        const float ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, tiles_y - 1);
+        const unsigned char *p1 = llds + (size_t)(ty1 - cy_lo) * ncx_max * 256;
+        const unsigned char *p2 = llds + (size_t)(ty2 - cy_lo) * ncx_max * 256;
+        unsigned char out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = (raw[k] >> (8 * i)) & 255;
+            const int i1 = o1[i] + v, i2 = o2[i] + v;
+            const float res = ((float)p1[i1] * xa1[i] + (float)p1[i2] * xa[i]) * ya1 + ((float)p2[i1] * xa1[i] + (float)p2[i2] * xa[i]) * ya;
+            out[i] = sat_u8_rn(res);
+        }
+        unsigned char *drow = plane + (size_t)(y + pv.pad) * L.istride + OV2_LM;
+        if (nvalid == 4) {
+            *reinterpret_cast<unsigned int *>(drow + x) =
+                (unsigned int)out[0] | ((unsigned int)out[1] << 8) | ((unsigned int)out[2] << 16) | ((unsigned int)out[3] << 24);
+        } else {
+            for (int i = 0; i < nvalid; ++i) drow[x + i] = out[i];
+        }
+        const bool yedge = (y <= pv.pad) || (y >= h - 1 - pv.pad);
+        const bool xedge = (x <= pv.pad) || (x + 3 >= w - 1 - pv.pad);
+        if (yedge || xedge)
+            for (int i = 0; i < nvalid; ++i) store_reflections(plane, L.istride, pv.pad, w, h, x + i, y, out[i], false);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // level l -> Scharr(l) [+ pyrDown -> level l+1].  Tile 64x16 px of level l, 256 threads.
 // grid (ceil(w/64), ceil(h/16), batch).
 #define TILE_W 64
+// 64 rows per workgroup: a thread owns 4 Scharr groups and 4 pyrDown outputs, so each resident wave carries several
+// memory round trips' worth of work (with 16-row tiles the kernel was bound by round trips per wave, not bandwidth)
 #define TILE_H 16
-#define LDS_ROWS (TILE_H + 4)  // rows y0-2 .. y0+17
+#define LDS_ROWS (TILE_H + 4)  // rows y0-2 .. y0+TILE_H+1
 #define LDS_DW 18              // dwords per row: cols x0-4 .. x0+67
 
 __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int has_next)
@@ -199,8 +297,8 @@ __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int 
     __syncthreads();
 
     // ---- Scharr: 4 px per thread ------------------------------------------------------------------
-    {
-        const int tx = tid & 15, ty = tid >> 4;
+    for (int rr = 0; rr < TILE_H / 16; ++rr) {
+        const int tx = tid & 15, ty = (tid >> 4) + 16 * rr;
         const int x = x0 + 4 * tx, y = y0 + ty;
         if (y < L.h && x < L.w) {
             // bytes x-4 .. x+7 of rows y-1,y,y+1  ->  need cols x-1 .. x+4
@@ -242,10 +340,11 @@ __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int 
         }
     }
 
-    // ---- pyrDown: one output px per thread (32x8 outputs per tile) -----------------------------------
-    if (has_next) {
+    // ---- pyrDown: 32 x (TILE_H/2) outputs per tile, TILE_H/16 per thread -----------------------------------
+    if (has_next)
+    for (int rr = 0; rr < TILE_H / 16; ++rr) {
         const ov2_level_desc N = pv.lv[l + 1];
-        const int lx = tid & 31, ly = tid >> 5;
+        const int lx = tid & 31, ly = (tid >> 5) + 8 * rr;
         const int xo = (x0 >> 1) + lx, yo = (y0 >> 1) + ly;
         const int c0 = 2 + 2 * lx;  // first byte (col 2xo-2) inside the LDS row
         int acc = 0;
@@ -286,14 +385,27 @@ __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int 
 ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int batch, ov2_pyr_buf **out)
 {
     {
+        // prefer a pooled buffer whose last consumers have already finished: taking the one released a moment ago
+        // would chain the new build behind the KLT that still reads it and defeat the two-stream overlap.  Up to
+        // OV2_PYR_RING buffers per geometry are kept so that a finished one is normally available.
         std::lock_guard<std::mutex> g(c->mu);
+        int pending = -1, same = 0;
         for (size_t i = 0; i < c->pool.size(); ++i) {
             ov2_pyr_buf *b = c->pool[i];
-            if (b->w == w && b->h == h && b->pad == pad && b->max_level == max_level && b->batch == batch) {
+            if (!(b->w == w && b->h == h && b->pad == pad && b->max_level == max_level && b->batch == batch)) continue;
+            ++same;
+            if (!b->has_free_ev || hipEventQuery(b->free_ev) == hipSuccess) {
                 c->pool.erase(c->pool.begin() + i);
                 *out = b;
                 return OV2_OK;
             }
+            if (pending < 0) pending = (int)i;
+        }
+        if (pending >= 0 && same >= 2) {   // two idle-but-pending buffers already exist: reuse rather than grow
+            ov2_pyr_buf *b = c->pool[pending];
+            c->pool.erase(c->pool.begin() + pending);
+            *out = b;
+            return OV2_OK;
         }
     }
     ov2_pyr_buf *b = new ov2_pyr_buf();
@@ -326,12 +438,19 @@ ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int bat
         delete b;
         return ov2_set_err(c, OV2_ERR_NOMEM, "pyramid hipMalloc(%zu): %s", off, hipGetErrorString(e));
     }
-    e = hipMemsetAsync(b->base, 0, b->bytes, c->stream);  // gradient padding = 0 for the lifetime of the buffer
+    e = hipMemsetAsync(b->base, 0, b->bytes, c->stream_pyr);  // gradient padding = 0 for the lifetime of the buffer
     if (e != hipSuccess) {
         (void)hipFree(b->base);
         delete b;
         return ov2_set_err(c, OV2_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
+    if (hipEventCreateWithFlags(&b->ready_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->free_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(b->base);
+        delete b;
+        return ov2_set_err(c, OV2_ERR_HIP, "hipEventCreate failed");
+    }
+    b->has_free_ev = false;
     v.base = b->base;
     *out = b;
     return OV2_OK;
@@ -356,6 +475,9 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
     if (s != OV2_OK) return s;
     const ov2_pyr_view &v = buf->view;
     const int B = im->batch;
+    hipStream_t sp = c->stream_pyr;
+    // a pooled buffer may still be read by kernels of the main stream (its last consumers): wait for their release mark
+    if (buf->has_free_ev) OV2_HIP(c, hipStreamWaitEvent(sp, buf->free_ev, 0));
 
     float inv_tw = 0.f, inv_th = 0.f;
     if (use_clahe) {
@@ -382,15 +504,29 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
         }
         inv_tw = 1.0f / (float)tw;
         inv_th = 1.0f / (float)th;
-        OV2_LAUNCH(c, OV2_K_CLAHE_LUT, clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, c->stream, im->base, im->w,
+        OV2_LAUNCH_ON(c, OV2_K_CLAHE_LUT, sp, clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, sp, im->base, im->w,
                            im->h, im->stride, im->bstride, tiles_x, tiles_y, tw, th, clip_limit, lut_scale, buf->lut);
     }
-    OV2_LAUNCH(c, OV2_K_LEVEL0, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, c->stream, im->base, im->w,
+    int ncx_max = 0, ncy_max = 0;
+    size_t l0_lds = 0;
+    if (use_clahe) {
+        // upper bound of the LUT window of a 64 x 16 px tile; tw/th = 1 / inv
+        const float tw = 1.0f / inv_tw, th = 1.0f / inv_th;
+        ncx_max = (int)(64.0f / tw) + 3;
+        ncy_max = (int)(64.0f / th) + 3;
+        l0_lds = (size_t)ncx_max * ncy_max * 256;
+    }
+    if (use_clahe && l0_lds <= 48 * 1024)
+        OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_clahe_tiled_kernel, dim3((im->w + 63) / 64, (im->h + 63) / 64, B), dim3(256), l0_lds,
+                   sp, im->base, im->w, im->h, im->stride, im->bstride, buf->lut, tiles_x, tiles_y, inv_tw, inv_th,
+                   ncx_max, v);
+    else
+    OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, sp, im->base, im->w,
                        im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
     for (int l = 0; l < v.nlevels; ++l) {
         const ov2_level_desc &L = v.lv[l];
-        OV2_LAUNCH(c, OV2_K_LEVEL, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
-                           0, c->stream, v, l, (l + 1 < v.nlevels) ? 1 : 0);
+        OV2_LAUNCH_ON(c, OV2_K_LEVEL, sp, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
+                           0, sp, v, l, (l + 1 < v.nlevels) ? 1 : 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -398,6 +534,7 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
         c->pool.push_back(buf);
         return ov2_set_err(c, OV2_ERR_HIP, "pyramid launch: %s", hipGetErrorString(e));
     }
+    OV2_HIP(c, hipEventRecord(buf->ready_ev, sp));
     ov2_pyr *p = new ov2_pyr();
     p->refs.store(1);
     p->ctx = c;
@@ -424,7 +561,7 @@ extern "C" ov2_status ov2_pyramid_build(ov2_ctx *c, const uint8_t *img, int w, i
     if (s != OV2_OK) return s;
     s = ov2_pyramid_build_images(c, c->tmp_img, win, max_level, use_clahe, clip, tiles_x, tiles_y, out);
     if (s != OV2_OK) return s;
-    OV2_HIP(c, hipStreamSynchronize(c->stream));  // the staging image may be overwritten by the next call
+    OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));  // the staging image may be overwritten by the next call
     return OV2_OK;
 }
 
@@ -439,6 +576,8 @@ extern "C" void ov2_pyr_release(ov2_pyr *p)
     if (p->refs.fetch_sub(1) == 1) {
         // stream-ordered reuse: later builds on the same ctx stream run after every kernel that reads this buffer
         // when those readers were enqueued on the same ctx.  Cross-ctx readers must synchronise before release.
+        // every consumer of this pyramid was enqueued on the main stream before this release: mark that point
+        if (hipEventRecord(p->buf->free_ev, p->ctx->stream) == hipSuccess) p->buf->has_free_ev = true;
         std::lock_guard<std::mutex> g(p->ctx->mu);
         p->ctx->pool.push_back(p->buf);
         delete p;
@@ -465,6 +604,7 @@ extern "C" ov2_status ov2_pyr_download_level(ov2_ctx *c, const ov2_pyr *p, int b
     const ov2_level_desc &L = v.lv[level];
     const int pw = L.w + 2 * v.pad, ph = L.h + 2 * v.pad;
     const int x_off = OV2_LM - v.pad;
+    OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     if (img)
         OV2_HIP(c, hipMemcpy2D(img, pw, v.base + L.img_off + L.img_bstride * b + x_off, L.istride, pw, ph,
@@ -472,5 +612,12 @@ extern "C" ov2_status ov2_pyr_download_level(ov2_ctx *c, const ov2_pyr *p, int b
     if (grad)
         OV2_HIP(c, hipMemcpy2D(grad, (size_t)pw * 4, v.base + L.grad_off + L.grad_bstride * b + (size_t)x_off * 4,
                                (size_t)L.gstride * 4, (size_t)pw * 4, ph, hipMemcpyDeviceToHost));
+    return OV2_OK;
+}
+
+ov2_status ov2_pyr_wait_ready(ov2_ctx *c, const ov2_pyr *p)
+{
+    if (!p) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipStreamWaitEvent(c->stream, p->buf->ready_ev, 0));
     return OV2_OK;
 }

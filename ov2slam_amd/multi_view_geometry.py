@@ -1,0 +1,54 @@
+"""Host-side mirror of MultiViewGeometry::ceresPnP (reference include/multi_view_geometry.hpp:104,
+src/multi_view_geometry.cpp:492-586) over the C ABI.  The LM loop, the chi2 flags and the L2 re-solve run inside one
+HIP kernel (csrc/pnp.hip); this file only marshals arrays.  No arithmetic happens here."""
+import numpy as np
+
+from .frontend import _check
+
+
+def _vp(a):
+    return a.ctypes.data
+
+
+class MultiViewGeometry:
+    """mirror of the reference's static MultiViewGeometry helpers for the pose-refinement path."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def ceresPnP(self, vunkps, vwpts, Twc, nmaxiter, chi2th, buse_robust, bapply_l2_after_robust, fx, fy, cx, cy,
+                 vscales=None):
+        """one frame.  returns (success, Twc (7,) [t, qx qy qz qw], voutliersidx (sorted int array))."""
+        ok, T, out, _ = self.ceresPnP_batch([vunkps], [vwpts], np.asarray(Twc, np.float64).reshape(1, 7), nmaxiter,
+                                            chi2th, buse_robust, bapply_l2_after_robust,
+                                            np.array([[fx, fy, cx, cy]], np.float64),
+                                            None if vscales is None else [vscales])
+        return bool(ok[0]), T[0], np.flatnonzero(out[0]).astype(np.int32)
+
+    def ceresPnP_batch(self, unpx_list, wpts_list, Twc, nmaxiter, chi2th, buse_robust, bapply_l2_after_robust, K,
+                       scales_list=None):
+        """B independent frames in one launch (one workgroup each).
+        returns (success (B,) bool, Twc (B,7), [outlier mask per frame], iters (B,2))."""
+        B = len(unpx_list)
+        n_pts = np.array([len(u) for u in unpx_list], np.int32)
+        cat = lambda xs, k, dt: (np.concatenate([np.asarray(x, dt).reshape(-1, k) for x in xs]) if B and n_pts.sum()
+                                 else np.zeros((0, k), dt))
+        unpx = np.ascontiguousarray(cat(unpx_list, 2, np.float64))
+        wpts = np.ascontiguousarray(cat(wpts_list, 3, np.float64))
+        if len(wpts) != len(unpx):
+            raise ValueError("vunkps.size() != vwpts.size()")       # the reference asserts (:500)
+        sc = None if scales_list is None else np.ascontiguousarray(cat(scales_list, 1, np.int32).ravel())
+        K = np.ascontiguousarray(np.asarray(K, np.float64).reshape(B, 4))
+        T = np.ascontiguousarray(np.array(Twc, np.float64).reshape(B, 7))
+        n = int(n_pts.sum())
+        outl = np.zeros(max(n, 1), np.uint8)
+        ok = np.zeros(max(B, 1), np.int32)
+        it = np.zeros((max(B, 1), 2), np.int32)
+        c = self.ctx
+        _check(c.h, c.lib.ov2_pnp_solve_batch(c.h, B, _vp(n_pts) if B else None, _vp(unpx) if n else None,
+                                              _vp(wpts) if n else None, None if sc is None or not n else _vp(sc),
+                                              _vp(K) if B else None, _vp(T) if B else None, int(nmaxiter),
+                                              float(chi2th), int(bool(buse_robust)),
+                                              int(bool(bapply_l2_after_robust)), _vp(outl), _vp(ok), _vp(it)))
+        off = np.concatenate([[0], np.cumsum(n_pts)])
+        return ok[:B].astype(bool), T, [outl[off[b]:off[b + 1]].astype(bool) for b in range(B)], it[:B]

@@ -176,3 +176,32 @@ def make_window(n_kf=20, n_lm=2000, inv_depth=True, seed=SEED_BA, max_obs=12, px
     if return_gt:
         return prob, dict(poses=poses_gt, lm=lm_gt, xyz=lm_xyz)
     return prob
+
+
+def make_pnp(n=300, seed=SEED_BA, px_noise=0.5, outlier_frac=0.1, rot_pert=0.02, trans_pert=0.05, behind=0,
+             with_scales=False):
+    """one pose-refinement problem of VisualFrontEnd::computePose (reference src/visual_front_end.cpp:716-830):
+    n world points in front of a camera at a random pose, undistorted pixels with noise + gross outliers, `behind`
+    points placed behind the camera, and a perturbed initial pose (the constant-velocity prediction).
+    returns dict(unpx (n,2), wpts (n,3), K (4,), Twc0 (7,), Twc_gt (7,), gt_outlier (n,) bool, scales or None)."""
+    rng = np.random.default_rng(seed)
+    R, t = se3_exp(np.concatenate([rng.uniform(-2, 2, 3), rng.uniform(-0.6, 0.6, 3)]))
+    px = np.stack([rng.uniform(10, W - 10, n), rng.uniform(10, H - 10, n)], 1)
+    z = rng.uniform(1.5, 12.0, n)
+    Xc = np.stack([(px[:, 0] - K_L[2]) / K_L[0] * z, (px[:, 1] - K_L[3]) / K_L[1] * z, z], 1)
+    if behind:
+        Xc[:behind, 2] *= -1.0
+    wpts = Xc @ R.T + t
+    scales = rng.integers(0, 3, n).astype(np.int32) if with_scales else None
+    sig = np.ones(n) if scales is None else 2.0 ** scales
+    unpx = px + rng.normal(0, px_noise, (n, 2)) * sig[:, None]
+    gt_out = np.zeros(n, bool)
+    n_out = int(round(outlier_frac * n))
+    if n_out:
+        idx = rng.choice(n, n_out, replace=False)
+        unpx[idx] += rng.uniform(15, 60, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))
+        gt_out[idx] = True
+    gt_out[:behind] = True
+    dR, dt = se3_exp(np.concatenate([rng.normal(0, trans_pert, 3), rng.normal(0, rot_pert, 3)]))
+    return dict(unpx=unpx, wpts=wpts, K=K_L.copy(), Twc0=pose7(dR @ R, dR @ t + dt), Twc_gt=pose7(R, t),
+                gt_outlier=gt_out, scales=scales)
