@@ -81,6 +81,23 @@ __device__ __forceinline__ unsigned ld_u16(const unsigned char *p)
     return r;
 }
 
+typedef short ov2_s16x2 __attribute__((ext_vector_type(2)));
+
+// v_dot2_i32_i16: a.lo * b.lo + a.hi * b.hi + c (signed 16-bit halves, 32-bit accumulate, no clamp)
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(ov2_s16x2, a), __builtin_bit_cast(ov2_s16x2, b), c, false);
+}
+// v_perm_b32 byte shuffles: (byte0, byte1) of a two-pixel load -> two zero-extended 16-bit halves
+__device__ __forceinline__ unsigned spread_u8x2(unsigned t) { return __builtin_amdgcn_perm(0u, t, 0x0c010c00u); }
+// (a.lo16, b.lo16) and (a.hi16, b.hi16)
+__device__ __forceinline__ unsigned pack_lo16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (ov2_s16x2)(__builtin_bit_cast(ov2_s16x2, a) - __builtin_bit_cast(ov2_s16x2, b)));
+}
+
 struct level_ptrs {
     const unsigned char *img;
     const int *grad;   // (Ix,Iy) int16 pair per pixel
@@ -124,34 +141,47 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
     int w00, w01, w10, w11;
     lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
 
-    // template of this lane's column: WIN pixels (I, Ix, Iy); lanes >= WIN and idle rows hold zeros
+    // template of this lane's column: WIN pixels (I, Ix, Iy), two rows per register as int16 pairs; lanes >= WIN and
+    // idle rows hold zero gradients, so whatever they compute below drops out of the sums
     const bool col = sub < WIN;
     const int sc = col ? sub : 0;
-    int Iv[WIN], Ixy[WIN];   // Ixy = Ix | Iy << 16 (both fit int16)
+    constexpr int NP = (WIN + 1) / 2;
+    unsigned Iv2[NP], Ix2[NP], Iy2[NP];
     int sA11 = 0, sA12 = 0, sA22 = 0;
     {
+        // bilinear taps as two v_dot2_i32_i16: (p[x], p[x+1]) . (w00, w01) + (p[x], p[x+1])' . (w10, w11); the weights
+        // fit int16 (w11 can be -1 after rounding), pixels and Scharr gradients too
+        const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         const int bx = run ? (OV2_LM + ipx + sc) : OV2_LM, by = run ? (ipy + pad) : pad;
         const unsigned char *ip = I.img + (size_t)by * I.istride + bx;
         const int *gp = I.grad + (size_t)by * I.gstride + bx;
-        unsigned t = ld_u16(ip);
-        int g0 = gp[0], g1 = gp[1];
+        unsigned T = spread_u8x2(ld_u16(ip));
+        unsigned GX, GY;
+        {
+            const unsigned g0 = (unsigned)gp[0], g1 = (unsigned)gp[1];
+            GX = pack_lo16(g0, g1); GY = pack_hi16(g0, g1);
+        }
+        const bool on = run && col;
+        unsigned piv = 0, pix = 0, piy = 0;
 #pragma unroll
         for (int y = 0; y < WIN; ++y) {
             ip += I.istride; gp += I.gstride;
-            const unsigned bb = ld_u16(ip);
-            const int h0 = gp[0], h1 = gp[1];
-            // signed 24-bit taps: w11 = 2^14 - w00 - w01 - w10 can be -1 after rounding
-            const int iv = (__mul24((int)(t & 255u), w00) + __mul24((int)(t >> 8), w01) + __mul24((int)(bb & 255u), w10) +
-                            __mul24((int)(bb >> 8), w11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            const int ix = (__mul24((short)(g0 & 0xffff), w00) + __mul24((short)(g1 & 0xffff), w01) +
-                            __mul24((short)(h0 & 0xffff), w10) + __mul24((short)(h1 & 0xffff), w11) + (1 << (W_BITS - 1))) >> W_BITS;
-            const int iy = (__mul24(g0 >> 16, w00) + __mul24(g1 >> 16, w01) + __mul24(h0 >> 16, w10) +
-                            __mul24(h1 >> 16, w11) + (1 << (W_BITS - 1))) >> W_BITS;
-            const bool on = run && col;
-            Iv[y] = on ? iv : 0;
-            Ixy[y] = on ? ((ix & 0xffff) | (iy << 16)) : 0;
-            if (on) { sA11 += ix * ix; sA12 += ix * iy; sA22 += iy * iy; }
-            t = bb; g0 = h0; g1 = h1;
+            const unsigned B = spread_u8x2(ld_u16(ip));
+            const unsigned h0 = (unsigned)gp[0], h1 = (unsigned)gp[1];
+            const unsigned HX = pack_lo16(h0, h1), HY = pack_hi16(h0, h1);
+            const unsigned iv = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            int ix = dot2(HX, W23, dot2(GX, W01, 1 << (W_BITS - 1))) >> W_BITS;
+            int iy = dot2(HY, W23, dot2(GY, W01, 1 << (W_BITS - 1))) >> W_BITS;
+            if (!on) { ix = 0; iy = 0; }
+            sA11 += __mul24(ix, ix); sA12 += __mul24(ix, iy); sA22 += __mul24(iy, iy);
+            if (y & 1) {
+                Iv2[y >> 1] = pack_lo16(piv, iv); Ix2[y >> 1] = pack_lo16(pix, (unsigned)ix); Iy2[y >> 1] = pack_lo16(piy, (unsigned)iy);
+            } else if (y == WIN - 1) {   // odd window: the phantom last row has zero gradients
+                Iv2[y >> 1] = iv; Ix2[y >> 1] = (unsigned)ix & 0xffffu; Iy2[y >> 1] = (unsigned)iy & 0xffffu;
+            } else {
+                piv = iv; pix = (unsigned)ix; piy = (unsigned)iy;
+            }
+            T = B; GX = HX; GY = HY;
         }
     }
     // |Ix|,|Iy| <= 4080 for u8 images: WIN*WIN <= 121 products stay below 2^31 -> exact in int32
@@ -182,18 +212,27 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
         }
         lk_weights(nx - (float)inx, ny - (float)iny, w00, w01, w10, w11);
         const unsigned char *jp = J.img + (size_t)((run ? iny : 0) + pad) * J.istride + OV2_LM + (run ? inx + sc : 0);
+        const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         int pb1 = 0, pb2 = 0;
-        unsigned t = ld_u16(jp);
+        unsigned T = spread_u8x2(ld_u16(jp));
 #pragma unroll
-        for (int y = 0; y < WIN; ++y) {
+        for (int q = 0; q < NP; ++q) {
             jp += J.istride;
-            const unsigned bb = ld_u16(jp);
-            const int jv = (__mul24((int)(t & 255u), w00) + __mul24((int)(t >> 8), w01) + __mul24((int)(bb & 255u), w10) +
-                            __mul24((int)(bb >> 8), w11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            const int diff = jv - Iv[y];
-            pb1 += __mul24(diff, (short)(Ixy[y] & 0xffff));   // |diff| <= 8160, |Ix| <= 4080
-            pb2 += __mul24(diff, Ixy[y] >> 16);
-            t = bb;
+            unsigned B = spread_u8x2(ld_u16(jp));
+            // taps + rounding >= 1 (w11 >= -1), so the logical shift is the arithmetic one
+            const unsigned j0 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            T = B;
+            unsigned j1 = 0;
+            if (2 * q + 1 < WIN) {
+                jp += J.istride;
+                B = spread_u8x2(ld_u16(jp));
+                j1 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                T = B;
+            }
+            // |jv - I| <= 8160 fits int16: v_pk_sub_i16 on the row pair, then one dot2 per gradient component
+            const unsigned d2 = pk_sub16(j0 | (j1 << 16), Iv2[q]);
+            pb1 = dot2(d2, Ix2[q], pb1);   // |diff| <= 8160, |Ix| <= 4080
+            pb2 = dot2(d2, Iy2[q], pb2);
         }
         // a lane holds <= 11 products of <= 3.4e7: fits int32; the row total may not, so sum exactly in f64
         const float b1 = (float)row_sum_f64((double)pb1) * FLT_SCALE;

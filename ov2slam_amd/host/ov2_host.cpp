@@ -429,6 +429,63 @@ ov2_status VisualFrontEnd::kltTracking()
     return OV2_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- pose refinement
+bool MultiViewGeometry::ceresPnP(ov2_ctx *ctx, const std::vector<Vec2> &vunkps, const std::vector<Vec3> &vwpts,
+                                 const std::vector<int> &vscales, SE3 &Twc, int nmaxiter, float chi2th,
+                                 bool buse_robust, bool bapply_l2_after_robust, float fx, float fy, float cx, float cy,
+                                 std::vector<int> &voutliersidx)
+{   // src/multi_view_geometry.cpp:492-586; the solve, the chi2 flags and the L2 re-solve are one kernel launch
+    if (vunkps.size() != vwpts.size() || (!vscales.empty() && vscales.size() != vunkps.size())) return false;   // :500
+    const int n = (int)vunkps.size();
+    static_assert(sizeof(Vec2) == 16 && sizeof(Vec3) == 24, "packed doubles");
+    const double K[4] = {fx, fy, cx, cy};
+    std::vector<uint8_t> out((size_t)n + 1);
+    int ok = 0;
+    const ov2_status s = ov2_pnp_solve_batch(ctx, 1, &n, n ? &vunkps[0].x : nullptr, n ? &vwpts[0].x : nullptr,
+                                             vscales.empty() ? nullptr : vscales.data(), K, Twc.v.data(), nmaxiter,
+                                             chi2th, buse_robust, bapply_l2_after_robust, out.data(), &ok, nullptr);
+    if (s != OV2_OK) return false;
+    for (int i = 0; i < n; ++i)
+        if (out[i]) voutliersidx.push_back(i);
+    return ok != 0;
+}
+
+ov2_status VisualFrontEnd::computePose()
+{   // src/visual_front_end.cpp:657-830
+    const size_t nb3dkps = pcurframe_->nb3dkps_;
+    if (nb3dkps < 4) return OV2_OK;                                        // :665-669
+    if (bp3preq_ || pslamstate_->dop3p_) return OV2_ERR_UNSUPPORTED;       // P3P-RANSAC branch :722-785 (OpenGV)
+    std::vector<Vec2> vkps;
+    std::vector<Vec3> vwpts;
+    std::vector<int> vkpids, voutliersidx, vscales;
+    for (const auto &it : pcurframe_->mapkps_) {                           // :688-708
+        const Keypoint &kp = it.second;
+        if (!kp.is3d_) continue;
+        auto plm = pmap_->getMapPoint(kp.lmid_);
+        if (!plm) continue;
+        vkps.push_back({kp.unpx_.x, kp.unpx_.y});
+        vwpts.push_back(plm->getPoint());
+        vscales.push_back(kp.scale_);
+        vkpids.push_back(kp.lmid_);
+    }
+    SE3 Twc = pcurframe_->getTwc();
+    const CameraCalibration &c = *pcurframe_->pcalib_leftcam_;
+    const bool success = MultiViewGeometry::ceresPnP(ctx_, vkps, vwpts, vscales, Twc, 5, pslamstate_->robust_mono_th_, true,
+                                                     pslamstate_->apply_l2_after_robust_, (float)c.fx_, (float)c.fy_,
+                                                     (float)c.cx_, (float)c.cy_, voutliersidx);   // :788-803
+    const size_t nbinliers = vwpts.size() - voutliersidx.size();
+    bool bad_t = false;
+    for (int i = 0; i < 3; ++i) bad_t = bad_t || !std::isfinite(Twc.v[i]);
+    if (!success || nbinliers < 5 || voutliersidx.size() > 0.5 * vwpts.size() || bad_t) {   // :806-826
+        bp3preq_ = true;   // "weird results, skipping here and applying p3p next"
+        return OV2_OK;
+    }
+    pcurframe_->setTwc(Twc);                                              // :831
+    bp3preq_ = false;
+    for (const int idx : voutliersidx) pmap_->removeObsFromCurFrameById(vkpids.at(idx));   // :838-841
+    return OV2_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- Optimizer::localBA
 ov2_ba_problem LocalBAProblem::view(const SlamParams &st, const Frame &newframe)
 {

@@ -4,7 +4,8 @@
 //   Keypoint            include/frame.hpp:46-76          Frame        include/frame.hpp:78-237, src/frame.cpp
 //   MapPoint            include/map_point.hpp:37-97      MapManager   include/map_manager.hpp:41-129 (subset)
 //   FeatureTracker      include/feature_tracker.hpp:32-56, src/feature_tracker.cpp:35-137
-//   VisualFrontEnd      src/visual_front_end.cpp:132-275 (kltTracking), :1143-1177 (preprocessImage)
+//   VisualFrontEnd      src/visual_front_end.cpp:132-275 (kltTracking), :657-830 (computePose), :1143-1177 (preprocessImage)
+//   MultiViewGeometry::ceresPnP  src/multi_view_geometry.cpp:492-586
 //   MapManager::stereoMatching  src/map_manager.cpp:367-611 (KLT part + epipolar gate for rectified / row check)
 //   Optimizer::localBA  src/optimizer.cpp:34-897         Estimator::applyLocalBA  src/estimator.cpp:67-98
 // All arithmetic of the path runs behind the ABI on the GPU; this file is graph walking and bookkeeping.
@@ -131,6 +132,20 @@ struct SlamParams {   // the subset of include/slam_params.hpp the path reads (Y
     bool use_clahe_ = true;
     float fclahe_val_ = 3.f;
     bool blocalba_is_on_ = false, bforce_realtime_ = true;
+    bool dop3p_ = false;
+};
+
+struct Vec2 {
+    double x = 0, y = 0;
+};
+
+class MultiViewGeometry {   // include/multi_view_geometry.hpp:104, src/multi_view_geometry.cpp:492-586
+public:
+    // motion-only BA on the GPU (ov2_pnp_solve_batch, B = 1); same arguments and return value as the reference
+    static bool ceresPnP(ov2_ctx *ctx, const std::vector<Vec2> &vunkps, const std::vector<Vec3> &vwpts,
+                         const std::vector<int> &vscales, SE3 &Twc, int nmaxiter, float chi2th, bool buse_robust,
+                         bool bapply_l2_after_robust, float fx, float fy, float cx, float cy,
+                         std::vector<int> &voutliersidx);
 };
 
 // owning handle of an ov2_pyr (the std::vector<cv::Mat> pyramid of the reference)
@@ -183,6 +198,9 @@ public:
         : ctx_(ctx), pslamstate_(pstate), pcurframe_(pframe), pmap_(pmap), ptracker_(ptracker) {}
     ov2_status preprocessImage(const uint8_t *img_raw, int w, int h, int stride);   // :1143-1177
     ov2_status kltTracking();                                                        // :132-275
+    // :657-830 without the P3P-RANSAC branch (OpenGV, out of scope): when P3P is required (bp3preq_ or dop3p_) the
+    // call returns OV2_ERR_UNSUPPORTED and leaves the frame untouched.
+    ov2_status computePose();
     bool bp3preq_ = false;
     Pyramid prev_pyr_, cur_pyr_;
     ov2_ctx *ctx_;

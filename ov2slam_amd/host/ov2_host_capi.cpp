@@ -127,6 +127,22 @@ int ov2h_apply_local_ba(void *p, void *ctx, int newkf, int *n_outliers1, int *n_
     return s;
 }
 
+// VisualFrontEnd::computePose on keyframe `kfid` taken as the current frame, starting from pose Twc7_init
+int ov2h_compute_pose(void *p, void *ctx, int kfid, const double *Twc7_init, int *p3p_req)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(kfid);
+    if (!f) return -1;
+    SE3 T0;
+    for (int i = 0; i < 7; ++i) T0.v[i] = Twc7_init[i];
+    f->setTwc(T0);
+    m->map->pcurframe_ = f;
+    VisualFrontEnd fe((ov2_ctx *)ctx, m->st, f, m->map, nullptr);
+    const ov2_status s = fe.computePose();
+    if (p3p_req) *p3p_req = fe.bp3preq_ ? 1 : 0;
+    return s;
+}
+
 int ov2h_get_pose(void *p, int kfid, double *Twc7)
 {
     auto f = ((HostMap *)p)->map->getKeyframe(kfid);

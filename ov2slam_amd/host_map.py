@@ -27,6 +27,7 @@ def lib():
         L.ov2h_local_ba_setup.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
+        L.ov2h_compute_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, ip]
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
         L.ov2h_count_keypoints.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
@@ -118,6 +119,12 @@ class HostMap:
         n1, n2, fc = C.c_int(), C.c_int(), C.c_double()
         st = lib().ov2h_apply_local_ba(self.h, ctx.h, self.newkf, C.byref(n1), C.byref(n2), C.byref(fc))
         return st, n1.value, n2.value, fc.value
+
+    def compute_pose(self, ctx, kfid, Twc_init):
+        """VisualFrontEnd::computePose with keyframe `kfid` as the current frame. returns (status, p3p requested)."""
+        req = C.c_int()
+        st = lib().ov2h_compute_pose(self.h, ctx.h, kfid, _dp(np.ascontiguousarray(Twc_init, np.float64)), C.byref(req))
+        return st, bool(req.value)
 
     def pose(self, kfid):
         out = np.zeros(7)

@@ -89,3 +89,33 @@ def test_apply_local_ba_equals_flat_solve(ctx, inv_depth):
         assert np.allclose(xyz, want, atol=1e-6)
         moved += 1
     assert moved > 20
+
+
+@pytest.mark.gpu
+def test_compute_pose_equals_flat_pnp(ctx):
+    """VisualFrontEnd::computePose (C++ mirror: gather 3D keypoints -> ceresPnP -> pose + outlier removal) against the
+    flat ov2_pnp_solve_batch call on the same observations."""
+    from ov2slam_amd.multi_view_geometry import MultiViewGeometry
+    P = synth_ba.make_window(10, 600, inv_depth=False, seed=8)
+    hm = host_map.HostMap(P)
+    k = 6
+    obs = {}
+    for i in range(P.n_res):
+        if P.res_type[i] == T.L_XYZ and P.res_pose[i] == k:
+            obs[int(P.res_lm[i])] = P.res_uv[i].astype(np.float32).astype(np.float64)
+    lmids = sorted(obs)
+    unpx = np.stack([obs[l] for l in lmids])
+    wpts = np.stack([hm.xyz0[l] for l in lmids])
+    dR, dt = synth_ba.se3_exp(np.array([0.03, -0.02, 0.04, 0.01, -0.015, 0.02]))
+    R0 = synth_ba.quat_to_rot(P.pose[k, 3:])
+    T0 = synth_ba.pose7(dR @ R0, dR @ P.pose[k, :3] + dt)
+    Kf = P.calib_l.astype(np.float32).astype(np.float64)      # the reference passes fx..cy as float
+    ok, Te, idx = MultiViewGeometry(ctx).ceresPnP(unpx, wpts, T0, 5, 5.9915, True, True, *Kf)
+    nb_before, nb3d_before, _ = hm.counts(k)
+    assert nb3d_before == len(lmids)
+    st, p3p = hm.compute_pose(ctx, k, T0)
+    assert st == 0 and ok and not p3p
+    assert np.abs(hm.pose(k) - Te).max() < 1e-8
+    nb_after, nb3d_after, _ = hm.counts(k)
+    assert nb_before - nb_after == len(idx) and nb3d_before - nb3d_after == len(idx)
+    assert 0 < len(idx) < 0.5 * len(lmids)
