@@ -20,7 +20,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -159,59 +158,40 @@ class Workload:
         return is_kf
 
 
-class BaWorker(threading.Thread):
+class BaWorker:
     """the Estimator thread of the reference (src/estimator.cpp:32-98): runs Optimizer::localBA on the newest pending
-    keyframe of any sequence, on its own HIP context/stream, concurrently with the front-end; a keyframe that arrives
-    while its sequence still has one pending replaces it (src/estimator.cpp:185-210 keeps only the newest)."""
+    keyframe of any sequence, on its own high-priority HIP context/stream, concurrently with the front-end; a keyframe
+    that arrives while its sequence still has one pending replaces it (src/estimator.cpp:185-210 keeps only the
+    newest).  The loop is a NATIVE thread of libov2host.so (ov2slam_amd/host/ov2_host_capi.cpp): a Python thread here
+    fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
     def __init__(self, device, seqs, n_kf, n_lm, seed):
-        super().__init__(daemon=True)
-        from ov2slam_amd import frontend as fe, local_ba, synth_ba
-        self.ctx = fe.Context(device, high_priority=True)   # small latency-critical grids next to the front-end
-        self.opt = local_ba.Optimizer(self.ctx)
+        from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
-        self.opt.localBA(self.P0.copy())          # warm-up (allocations, code objects)
-        self.pending = [False] * seqs
-        self.lock = threading.Lock()
-        self.wake = threading.Event()
-        self.stop_flag = False
-        self.counting = False
+        self.w = host_map.EstimatorWorker(device, self.P0, seqs)
+        self.w.submit_all()                       # warm-up (allocations, code objects); not counted
+        t0 = time.perf_counter()
+        while self.w.stats()["last_status"] != 0 and time.perf_counter() - t0 < 5.0:
+            time.sleep(0.001)
         self.solves = self.iters = self.dropped = self.submitted = 0
         self.busy_s = 0.0
 
     def submit_all(self):
-        with self.lock:
-            for b in range(len(self.pending)):
-                if self.pending[b] and self.counting:
-                    self.dropped += 1
-                self.pending[b] = True
-                if self.counting:
-                    self.submitted += 1
-        self.wake.set()
+        self.w.submit_all()
 
-    def run(self):
-        rr = 0
-        while not self.stop_flag:
-            job = None
-            with self.lock:
-                n = len(self.pending)
-                for k in range(n):
-                    b = (rr + k) % n
-                    if self.pending[b]:
-                        self.pending[b] = False
-                        job, rr = b, b + 1
-                        break
-            if job is None:
-                self.wake.wait(0.002)
-                self.wake.clear()
-                continue
-            t0 = time.perf_counter()
-            R = self.opt.localBA(self.P0.copy())
-            dt = time.perf_counter() - t0
-            if self.counting:
-                self.solves += 1
-                self.iters += sum(R.summary()["iterations"])
-                self.busy_s += dt
+    def set_counting(self, on):
+        self.w.set_counting(on)
+
+    def refresh(self):
+        st = self.w.stats()
+        if st["last_status"] != 0:
+            raise RuntimeError(f"ov2_ba_solve failed in the worker (status {st['last_status']})")
+        self.solves, self.iters, self.dropped = st["solves"], st["iters"], st["dropped"]
+        self.submitted, self.busy_s = st["submitted"], st["busy_s"]
+        return st
+
+    def stop(self):
+        self.w.close()
 
 
 def cpu_baseline(workload, kf_every, budget_s):
@@ -269,14 +249,13 @@ def main():
     ba = None
     if not a.no_ba:
         ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank)
-        ba.start()
     for _ in range(a.warmup):
         if wl.step(a.kf_every) and ba:
             ba.submit_all()
     ctx.synchronize()
     barrier()
     if ba:
-        ba.counting = True
+        ba.set_counting(True)
     t0 = time.perf_counter()
     ctx.timer_start()
     nkf = 0
@@ -285,6 +264,7 @@ def main():
         nkf += kf
         if kf and ba:
             ba.submit_all()                     # Mapper::run -> Estimator::addNewKf
+    t_enq = time.perf_counter() - t0   # host time to enqueue the K steps (the detector's D2H syncs included)
     gpu_ms = ctx.timer_stop()     # synchronises the ctx stream
     barrier()
     el = time.perf_counter() - t0
@@ -292,16 +272,16 @@ def main():
         # a timed region shorter than one solve completes none: let the worker finish ONE job after the region and
         # report its rate over its own busy time instead (flagged as such); the frames/s above is unaffected
         ba_post_region = False
+        ba.refresh()
         if ba.solves == 0:
             ba_post_region = True
             ba.submit_all()
             t_wait = time.perf_counter()
-            while ba.solves == 0 and time.perf_counter() - t_wait < 60.0:
+            while ba.refresh()["solves"] == 0 and time.perf_counter() - t_wait < 60.0:
                 time.sleep(0.002)
-        ba.counting = False
-        ba.stop_flag = True
-        ba.wake.set()
-        ba.join(timeout=60)
+        ba.set_counting(False)
+        ba.refresh()
+        ba.stop()
 
     # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
     el_max, cnt = dist_util.aggregate(el, [a.steps * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
@@ -320,6 +300,7 @@ def main():
                    "sequences_per_gpu": a.seqs, "keypoints_per_frame": a.kps, "kf_every": a.kf_every,
                    "image": [W, H], "parallelism": f"replicas x{world} (one batch of sequences per GPU)"},
         "gpu_stream_ms_per_step": gpu_ms / a.steps,
+        "host_enqueue_ms_per_step": 1e3 * t_enq / a.steps,
         "keyframes_per_step": nkf / a.steps,
     }
     if ba:

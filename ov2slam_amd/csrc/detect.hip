@@ -110,7 +110,33 @@ struct det_out {          // per cell
     int has_first, has_second, occupied, pad;
 };
 
-// detectSingleScale: one workgroup (256 threads) per cell of the current colour
+// p / n for 0 <= p < 2^13 and 2 <= n <= 66 without the ~35-instruction integer division: (p + 0.5) / n is at least
+// 1/(2n) away from every integer, far more than the fp32 error of the product
+__device__ __forceinline__ int div_small(int p, float inv_n) { return (int)(((float)p + 0.5f) * inv_n); }
+
+// zero the disc around (cx, cy) in the global mask and in the cell-local copy mk (cell origin x0,y0, side n)
+__device__ __forceinline__ void draw_disc_both(unsigned char *mask, int w, int h, unsigned char *mk, int x0, int y0, int n,
+                                               int cx, int cy, const disc_shape &ds)
+{
+    const int side = 2 * ds.r + 1;
+    const float inv_side = 1.f / (float)side;
+    for (int i = threadIdx.x; i < side * side; i += blockDim.x) {
+        const int q = div_small(i, inv_side);
+        const int oy = q - ds.r, ox = i - q * side - ds.r;
+        const int hw = ds.hw[ds.r + oy];
+        const int x = cx + ox, y = cy + oy;
+        if (hw >= 0 && ox >= -hw && ox <= hw && x >= 0 && x < w && y >= 0 && y < h) {
+            mask[(size_t)y * w + x] = 0;
+            const int lx = x - x0, ly = y - y0;
+            if (lx >= 0 && lx < n && ly >= 0 && ly < n) mk[ly * n + lx] = 0;
+        }
+    }
+}
+
+// detectSingleScale: one workgroup per free cell of the current colour.  Everything after the first touch of the
+// image runs out of LDS: the (cell+2)^2 source patch (the padded plane already holds the image-border REFLECT_101),
+// the blurred cell and the Sobel responses stored WITH their per-cell REFLECT_101 ring (so the 3x3 stencils carry no
+// border logic), the response map and a local copy of the mask that also receives this cell's own disc.
 __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                          int istride, int w, int h, int cell, int nwcells, int nhcells,
                                                          const int2 *__restrict__ work /* (image, cell) of this colour */,
@@ -126,47 +152,58 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
     unsigned char *mask = mask_all + (size_t)bimg * w * h;
     det_out *out = out_all + (size_t)bimg * nwcells * nhcells;
     const double quality = quality_all[bimg];
-    const int rr = i / nwcells, cc = i % nwcells;
-    const int tid = threadIdx.x, nth = blockDim.x, n = cell, n2 = cell * cell;
+    const int rr = i / nwcells, cc = i - rr * nwcells;
+    const int tid = threadIdx.x, nth = blockDim.x, n = cell, n2 = cell * cell, m = cell + 2, m2 = m * m;
     const int x0 = cc * cell, y0 = rr * cell;
-    float *dxs = reinterpret_cast<float *>(lds_raw);   // n2
-    float *dys = dxs + n2;                              // n2
-    float *hmap = dys + n2;                             // n2
-    unsigned char *bl = reinterpret_cast<unsigned char *>(hmap + n2);   // n2 blurred cell
-    // GaussianBlur 3x3 (fixed point, round half up), parent pixels beyond the cell, REFLECT_101 at the image border
+    const float inv_n = 1.f / (float)n, inv_m = 1.f / (float)m;
+    float *dxs = reinterpret_cast<float *>(lds_raw);   // m2, ring = per-cell reflection
+    float *dys = dxs + m2;                              // m2
+    float *hmap = dys + m2;                             // n2
+    unsigned char *src = reinterpret_cast<unsigned char *>(hmap + n2);   // m2: parent pixels, rows/cols -1 .. n
+    unsigned char *bl = src + m2;                                        // m2: blurred cell + reflected ring
+    unsigned char *mk = bl + m2;                                         // n2: mask of the cell
+    for (int p = tid; p < m2; p += nth) {
+        const int y = div_small(p, inv_m), x = p - y * m;
+        src[p] = img[(ptrdiff_t)(y0 + y - 1) * istride + (x0 + x - 1)];
+    }
     for (int p = tid; p < n2; p += nth) {
-        const int y = p / n, x = p - y * n;
-        int s = 0;
-#pragma unroll
-        for (int j = -1; j <= 1; ++j) {
-            const unsigned char *row = img + (size_t)reflect101(y0 + y + j, h) * istride;
-            const int kj = j == 0 ? 2 : 1;
-            s += kj * (row[reflect101(x0 + x - 1, w)] + 2 * row[x0 + x] + row[reflect101(x0 + x + 1, w)]);
-        }
+        const int y = div_small(p, inv_n), x = p - y * n;
+        mk[p] = mask[(size_t)(y0 + y) * w + x0 + x];
+    }
+    __syncthreads();
+    // GaussianBlur 3x3 (fixed point, round half up) on parent pixels beyond the cell; ring entry (y,x) = value of the
+    // cell pixel (reflect101(y), reflect101(x)), which is what the per-cell REFLECT_101 Sobel reads there
+    for (int p = tid; p < m2; p += nth) {
+        const int y = div_small(p, inv_m), x = p - y * m;
+        const int q = (reflect101(y - 1, n) + 1) * m + reflect101(x - 1, n) + 1;
+        const int s = (src[q - m - 1] + 2 * src[q - m] + src[q - m + 1]) + 2 * (src[q - 1] + 2 * src[q] + src[q + 1]) +
+                      (src[q + m - 1] + 2 * src[q + m] + src[q + m + 1]);
         bl[p] = (unsigned char)((s + 8) >> 4);
     }
     __syncthreads();
     const float sc = (float)(1.0 / (4.0 * 3.0 * 255.0)), sc2 = sc * 2.f;
-#define BL(yy, xx) ((float)bl[reflect101((yy), n) * n + reflect101((xx), n)])
-    for (int p = tid; p < n2; p += nth) {
-        const int y = p / n, x = p - y * n;
-        const float rm = BL(y - 1, x + 1) - BL(y - 1, x - 1), r0 = BL(y, x + 1) - BL(y, x - 1), rp = BL(y + 1, x + 1) - BL(y + 1, x - 1);
+    for (int p = tid; p < m2; p += nth) {
+        const int y = div_small(p, inv_m), x = p - y * m;
+        const int q = (reflect101(y - 1, n) + 1) * m + reflect101(x - 1, n) + 1;
+        const float a00 = (float)bl[q - m - 1], a01 = (float)bl[q - m], a02 = (float)bl[q - m + 1];
+        const float a10 = (float)bl[q - 1], a12 = (float)bl[q + 1];
+        const float a20 = (float)bl[q + m - 1], a21 = (float)bl[q + m], a22 = (float)bl[q + m + 1];
+        const float rm = a02 - a00, r0 = a12 - a10, rp = a22 - a20;
         dxs[p] = sc2 * r0 + sc * (rm + rp);
-        const float tm = (BL(y - 1, x - 1) + BL(y - 1, x + 1)) * sc + BL(y - 1, x) * sc2;
-        const float tp = (BL(y + 1, x - 1) + BL(y + 1, x + 1)) * sc + BL(y + 1, x) * sc2;
+        const float tm = (a00 + a02) * sc + a01 * sc2;
+        const float tp = (a20 + a22) * sc + a21 * sc2;
         dys[p] = tp - tm;
     }
-#undef BL
     __syncthreads();
     for (int p = tid; p < n2; p += nth) {
-        const int y = p / n, x = p - y * n;
+        const int y = div_small(p, inv_n), x = p - y * n;
+        const int q0 = (y + 1) * m + x + 1;
         double a = 0, b = 0, c = 0;
 #pragma unroll
         for (int j = -1; j <= 1; ++j)
 #pragma unroll
             for (int ii = -1; ii <= 1; ++ii) {
-                const int q = reflect101(y + j, n) * n + reflect101(x + ii, n);
-                const float gx = dxs[q], gy = dys[q];
+                const float gx = dxs[q0 + j * m + ii], gy = dys[q0 + j * m + ii];
                 a += (double)(gx * gx);
                 b += (double)(gx * gy);
                 c += (double)(gy * gy);
@@ -178,8 +215,7 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
     for (int pass = 0; pass < 2; ++pass) {
         unsigned long long key = argmax_key(-3.4028234663852886e38f, 0x7ffffffe);
         for (int p = tid; p < n2; p += nth) {
-            const int y = p / n, x = p - y * n;
-            const float v = mask[(size_t)(y0 + y) * w + x0 + x] ? hmap[p] : 0.f;
+            const float v = mk[p] ? hmap[p] : 0.f;
             const unsigned long long k2 = argmax_key(v, p);
             key = k2 > key ? k2 : key;
         }
@@ -188,15 +224,15 @@ __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__
         unsigned kb = (unsigned)(key >> 32);
         kb = (kb & 0x80000000u) ? (kb & 0x7fffffffu) : ~kb;
         const float best = __uint_as_float(kb);
-        const int bx = x0 + idx % n, by = y0 + idx / n;
+        const int iy = div_small(idx, inv_n);
+        const int bx = x0 + idx - iy * n, by = y0 + iy;
         if (bx < rx || by < ry || bx >= rx + rw || by >= ry + rh) return;   // `continue` of the reference: cell done
         if ((double)best >= quality) {
             if (tid == 0) {
                 if (pass == 0) { out[i].fx = (float)bx; out[i].fy = (float)by; out[i].has_first = 1; }
                 else { out[i].sx = (float)bx; out[i].sy = (float)by; out[i].has_second = 1; }
             }
-            draw_disc(mask, w, h, bx, by, ds);
-            __threadfence();
+            draw_disc_both(mask, w, h, mk, x0, y0, n, bx, by, ds);
         }
         __syncthreads();
     }
@@ -461,12 +497,13 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
         }
     }
     const int nthreads = (cell * cell <= 256) ? 64 : 256;   // small cells: one wave walks the cell
+    const size_t mineig_lds = (size_t)(cell + 2) * (cell + 2) * 10 + (size_t)cell * cell * 5;
     size_t woff = 0;
     for (int colour = 0; colour < 4; ++colour) {
         const int nitems = (int)work[colour].size();
         if (nitems > 0) {
             if (mode == OV2_DETECT_MINEIG)
-                OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 13, st, img,
+                OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nitems), dim3(nthreads), mineig_lds, st, img,
                            L.img_bstride, L.istride, w, h, cell, nw, nh, dwork + woff, mask, ds, rx, ry, rw, rh, dth, dout);
             else
                 OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 4, st, img,

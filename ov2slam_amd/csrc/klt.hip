@@ -235,8 +235,17 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
             pb2 = dot2(d2, Iy2[q], pb2);
         }
         // a lane holds <= 11 products of <= 3.4e7: fits int32; the row total may not, so sum exactly in f64
-        const float b1 = (float)row_sum_f64((double)pb1) * FLT_SCALE;
-        const float b2 = (float)row_sum_f64((double)pb2) * FLT_SCALE;
+        // Usual case (wave-uniform test): every lane's partial is below 2^27, the 16-lane total fits int32 and
+        // v_cvt_f32_i32 rounds it once, exactly like (float)(double)total -- 8 DPP adds instead of 16 DPP moves + 8
+        // f64 adds.
+        float b1, b2;
+        if (__all((unsigned)(pb1 + (1 << 27)) < (1u << 28) && (unsigned)(pb2 + (1 << 27)) < (1u << 28))) {
+            b1 = (float)row_sum_i32(pb1) * FLT_SCALE;
+            b2 = (float)row_sum_i32(pb2) * FLT_SCALE;
+        } else {
+            b1 = (float)row_sum_f64((double)pb1) * FLT_SCALE;
+            b2 = (float)row_sum_f64((double)pb2) * FLT_SCALE;
+        }
         const float dx = (A12 * b2 - A22 * b1) * D;
         const float dy = (A12 * b1 - A11 * b2) * D;
         if (run) {

@@ -1,7 +1,12 @@
 // ov2_host_capi.cpp -- flat C hooks around the C++ host mirror so that pytest can build a Frame/MapPoint graph,
 // run Optimizer::setupLocalBA (CPU only) or the whole Estimator::applyLocalBA (GPU) and read the map back.
 // Test/bring-up surface only; a real integration uses the C++ classes of ov2_host.hpp directly.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "ov2_host.hpp"
 
@@ -166,6 +171,138 @@ int ov2h_count_keypoints(void *p, int kfid, int *nbkps, int *nb3d, int *nbstereo
     if (!f) return -1;
     *nbkps = (int)f->nbkps_; *nb3d = (int)f->nb3dkps_; *nbstereo = (int)f->nb_stereo_kps_;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Estimator thread (reference src/estimator.cpp:32-98 run(): wait for a keyframe -> applyLocalBA -> next), native so
+// that it runs beside a Python front-end loop without sharing the interpreter lock.  One worker serves `nseq`
+// sequences: a keyframe that arrives while its sequence still has one pending replaces it (the reference keeps only
+// the newest, src/estimator.cpp:185-210).  Every job solves a fresh copy of the window it was created with.
+struct BaWorkerNative {
+    ov2_ctx *ctx = nullptr;
+    std::vector<double> pose0, lm0, lm_auv, res_uv, res_sigma, pose, lm;
+    std::vector<uint8_t> pose_const, res_type;
+    std::vector<int32_t> lm_anchor, res_pose, res_lm;
+    ov2_ba_problem P{};
+    ov2_ba_options opt{};
+    std::vector<uint8_t> pending;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread th;
+    bool stop = false, counting = false;
+    long long solves = 0, iters = 0, dropped = 0, submitted = 0;
+    double busy_s = 0.0;
+    int last_status = 0;
+
+    void loop()
+    {
+        size_t rr = 0;
+        for (;;) {
+            int job = -1;
+            bool counted = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (stop) return;
+                    for (size_t k = 0; k < pending.size(); ++k) {
+                        const size_t b = (rr + k) % pending.size();
+                        if (pending[b]) { pending[b] = 0; job = (int)b; rr = b + 1; break; }
+                    }
+                    if (job >= 0) break;
+                    cv.wait_for(lk, std::chrono::milliseconds(2));
+                }
+                counted = counting;   // a job counts only if it started inside the counted region
+            }
+            pose = pose0; lm = lm0;
+            P.pose = pose.data(); P.lm = lm.data();
+            ov2_ba_result R;
+            std::memset(&R, 0, sizeof(R));
+            const auto t0 = std::chrono::steady_clock::now();
+            const ov2_status s = ov2_ba_solve(ctx, &P, &opt, &R);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> lk(mu);
+            last_status = s;
+            if (counted && counting && s == OV2_OK) {
+                ++solves;
+                const int it = R.n_log - 1 - (R.l2_done ? 1 : 0);   // the log holds one iteration-0 record per solve
+                iters += it > 0 ? it : 0;
+                busy_s += dt;
+            }
+        }
+    }
+};
+
+void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq)
+{
+    BaWorkerNative *w = new BaWorkerNative();
+    if (ov2_ctx_create_ex(device, 1, &w->ctx) != OV2_OK) { delete w; return nullptr; }   // high-priority stream
+    const int e = P->inv_depth ? 1 : 3;
+    w->pose0.assign(P->pose, P->pose + 7 * (size_t)P->n_pose);
+    w->lm0.assign(P->lm, P->lm + (size_t)e * P->n_lm);
+    w->pose_const.assign(P->pose_const, P->pose_const + P->n_pose);
+    if (P->inv_depth) {
+        w->lm_anchor.assign(P->lm_anchor_pose, P->lm_anchor_pose + P->n_lm);
+        w->lm_auv.assign(P->lm_anchor_uv, P->lm_anchor_uv + 2 * (size_t)P->n_lm);
+    }
+    w->res_type.assign(P->res_type, P->res_type + P->n_res);
+    w->res_pose.assign(P->res_pose, P->res_pose + P->n_res);
+    w->res_lm.assign(P->res_lm, P->res_lm + P->n_res);
+    w->res_uv.assign(P->res_uv, P->res_uv + 2 * (size_t)P->n_res);
+    if (P->res_sigma) w->res_sigma.assign(P->res_sigma, P->res_sigma + P->n_res);
+    w->P = *P;
+    w->P.pose_const = w->pose_const.data();
+    w->P.lm_anchor_pose = P->inv_depth ? w->lm_anchor.data() : nullptr;
+    w->P.lm_anchor_uv = P->inv_depth ? w->lm_auv.data() : nullptr;
+    w->P.res_type = w->res_type.data(); w->P.res_pose = w->res_pose.data(); w->P.res_lm = w->res_lm.data();
+    w->P.res_uv = w->res_uv.data(); w->P.res_sigma = P->res_sigma ? w->res_sigma.data() : nullptr;
+    ov2_ba_default_options(&w->opt, robust_mono_th);
+    w->pending.assign((size_t)(nseq > 0 ? nseq : 1), 0);
+    w->th = std::thread([w] { w->loop(); });
+    return w;
+}
+
+// Mapper::run -> Estimator::addNewKf for every sequence of the batch
+void ov2h_ba_worker_submit_all(void *p)
+{
+    BaWorkerNative *w = (BaWorkerNative *)p;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        for (auto &f : w->pending) {
+            if (f && w->counting) ++w->dropped;
+            f = 1;
+            if (w->counting) ++w->submitted;
+        }
+    }
+    w->cv.notify_one();
+}
+
+void ov2h_ba_worker_set_counting(void *p, int on)
+{
+    BaWorkerNative *w = (BaWorkerNative *)p;
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->counting = on != 0;
+}
+
+// out[6] = solves, LM iterations, jobs replaced by a newer keyframe, jobs submitted, busy seconds, last status
+void ov2h_ba_worker_stats(void *p, double *out)
+{
+    BaWorkerNative *w = (BaWorkerNative *)p;
+    std::lock_guard<std::mutex> lk(w->mu);
+    out[0] = (double)w->solves; out[1] = (double)w->iters; out[2] = (double)w->dropped; out[3] = (double)w->submitted;
+    out[4] = w->busy_s; out[5] = (double)w->last_status;
+}
+
+void ov2h_ba_worker_destroy(void *p)
+{
+    BaWorkerNative *w = (BaWorkerNative *)p;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    ov2_ctx_destroy(w->ctx);
+    delete w;
 }
 
 }  // extern "C"

@@ -27,6 +27,16 @@ def lib():
         L.ov2h_local_ba_setup.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
+        L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int]
+        L.ov2h_ba_worker_create.restype = C.c_void_p
+        L.ov2h_ba_worker_submit_all.argtypes = [C.c_void_p]
+        L.ov2h_ba_worker_submit_all.restype = None
+        L.ov2h_ba_worker_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_ba_worker_set_counting.restype = None
+        L.ov2h_ba_worker_stats.argtypes = [C.c_void_p, dp]
+        L.ov2h_ba_worker_stats.restype = None
+        L.ov2h_ba_worker_destroy.argtypes = [C.c_void_p]
+        L.ov2h_ba_worker_destroy.restype = None
         L.ov2h_compute_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, ip]
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
@@ -140,3 +150,36 @@ class HostMap:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         lib().ov2h_count_keypoints(self.h, kfid, C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
+
+
+class EstimatorWorker:
+    """the reference's Estimator thread (src/estimator.cpp:32-98) as a NATIVE thread of libov2host.so with its own
+    high-priority HIP context: waits for keyframes, runs localBA on the newest pending one of any sequence.  Python only
+    submits keyframes and reads the counters, so the worker never competes for the interpreter lock."""
+
+    def __init__(self, device, problem, nseq, robust_mono_th=5.9915):
+        self.problem = problem              # keeps the arrays alive during the deep copy
+        pc = problem.as_c()
+        self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq)
+        if not self.h:
+            raise RuntimeError("ov2h_ba_worker_create failed (no GPU?)")
+
+    def submit_all(self):
+        lib().ov2h_ba_worker_submit_all(self.h)
+
+    def set_counting(self, on):
+        lib().ov2h_ba_worker_set_counting(self.h, int(bool(on)))
+
+    def stats(self):
+        out = np.zeros(6)
+        lib().ov2h_ba_worker_stats(self.h, _dp(out))
+        return dict(solves=int(out[0]), iters=int(out[1]), dropped=int(out[2]), submitted=int(out[3]), busy_s=float(out[4]),
+                    last_status=int(out[5]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ov2h_ba_worker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

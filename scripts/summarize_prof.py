@@ -21,8 +21,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"(\w+)\(", name.replace("(anonymous namespace)::", ""))
-    return m.group(1) if m else name.strip('"')
+    """'void (anonymous namespace)::klt_stage2_kernel<9>(ov2_pyr_view, ...)' -> 'klt_stage2_kernel' (the name
+    bench.py's hipEvent table uses); template arguments are dropped, instantiations of one kernel are pooled."""
+    n = name.strip('"').replace("(anonymous namespace)::", "")
+    head = n.split("(", 1)[0]
+    while True:
+        t = re.sub(r"<[^<>]*>", "", head)
+        if t == head:
+            break
+        head = t
+    m = re.search(r"(\w+)\s*$", head)
+    return m.group(1) if m else n
 
 
 def main():

@@ -109,6 +109,37 @@ def test_fb_klt_edge_cases(ctx, oracle, stream):
     assert out.shape == (0, 2) and st.shape == (0,)
 
 
+@pytest.mark.parametrize("win", [9, 11])
+def test_fb_klt_saturated_images(ctx, oracle, win):
+    """range limits of the packed int16 arithmetic (dot2 taps, pk_sub, w11 = -1 weights) and of the int32 fast path of
+    the b1/b2 row sums.  Left third: binary 0/255 block noise with a real 1-px shift.  Middle: unrelated block noise.
+    Right third: 0/255 vertical stripes (+ a grey line every 12 rows so that the 2x2 system is regular) tracked into a
+    constant 255 image: in a stripe-edge column every row has diff = +8160 and Ix = +4080, so one lane's partial sum is
+    ~2.7e8 > 2^27 and the kernel must take the exact wide-sum path."""
+    rng = np.random.default_rng(42 + win)
+    def blocks(k):
+        return np.kron(rng.integers(0, 2, (480 // k + 1, 752 // k + 1)), np.ones((k, k)))[:480, :752].astype(np.uint8) * 255
+    I0, I1 = blocks(3), blocks(3)
+    I1[:, :250] = np.roll(I0, 1, axis=1)[:, :250]
+    xs = np.arange(752)
+    stripes = np.where((xs // 3) % 2 == 1, 255, 0).astype(np.uint8)
+    I0[:, 500:] = stripes[None, 500:]
+    I0[::12, 500:] = 128
+    I1[:, 500:] = 255
+    g0 = fe.preprocess_image(ctx, I0, use_clahe=False, klt_win_size=11)
+    g1 = fe.preprocess_image(ctx, I1, use_clahe=False, klt_win_size=11)
+    o0, o1 = oracle.Pyramid(I0, 11, 3), oracle.Pyramid(I1, 11, 3)
+    kps = synth.grid_keypoints(900, seed=9)
+    kps = (kps + rng.uniform(-0.5, 0.5, kps.shape)).astype(np.float32)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for nl in (0, 3):
+        out, st = trk.fbKltTracking(g0, g1, win, nl, 30.0, 0.5, kps, kps)
+        eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, kps, win, nl, 30.0, 0.5, 30, 0.01)
+        assert np.array_equal(st, est.astype(bool)), nl
+        assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), nl
+    assert st[kps[:, 0] < 230].mean() > 0.5
+
+
 @pytest.mark.parametrize("win,max_iter,eps,fb", [(7, 30, 0.01, 0.5), (11, 10, 0.03, 1.0), (5, 3, 0.01, 0.25), (9, 0, 0.01, 0.5)])
 def test_fb_klt_other_parameters(ctx, oracle, stream, win, max_iter, eps, fb):
     I0, I1 = stream.left(2), stream.left(9)
