@@ -166,32 +166,31 @@ void ov2o_corner_subpix(const uint8_t *img, int w, int h, int stride, int n, flo
             for (int i = 0; i < bw; ++i)
                 for (int j = 0; j < bw; ++j) buf[i * bw + j] = rect_subpix(img, w, h, stride, ipx, ipy, a11, a12, a21, a22, i, j);
             /* the five sums over the window: cv::cornerSubPix adds the terms row-major in double; the canonical order
-             * here is a fixed 64-leaf butterfly (term t = i*win + j in leaf t, zeros above) so that a 64-lane wave
-             * reproduces it bit for bit -- the two orders differ at the 1e-16 level only */
-            double acc[5][256];
-            int leaves = 64;
-            while (leaves < win * win) leaves <<= 1;
-            for (int t = 0; t < leaves; ++t) for (int q = 0; q < 5; ++q) acc[q][t] = 0.0;
+             * here is the one a 16-lane DPP row produces -- leaf l = terms l, l+16, l+32, ... added in that order
+             * (term t = i*win + j), then the 16-leaf pairwise tree ((l0+l1)+(l2+l3))+... -- so that the GPU
+             * reproduces it bit for bit; the two orders differ at the 1e-16 level only */
+            double acc[5][16];
+            for (int t = 0; t < 16; ++t) for (int q = 0; q < 5; ++q) acc[q][t] = 0.0;
             for (int i = 0; i < win; ++i) {
                 const double py = i - hw;
-                for (int j = 0; j < win; ++j) {
+                for (int j = 0; j < win; ++j) {   /* row-major t ascending == ascending k within every leaf */
                     const float *sp = buf + (i + 1) * bw + (j + 1);
                     const double m = mask[i * win + j];
                     const double tgx = sp[1] - sp[-1];
                     const double tgy = sp[bw] - sp[-bw];
                     const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
                     const double px = j - hw;
-                    const int t = i * win + j;
-                    acc[0][t] = gxx; acc[1][t] = gxy; acc[2][t] = gyy;
-                    acc[3][t] = gxx * px + gxy * py;
-                    acc[4][t] = gxy * px + gyy * py;
+                    const int l = (i * win + j) & 15;
+                    acc[0][l] += gxx; acc[1][l] += gxy; acc[2][l] += gyy;
+                    acc[3][l] += gxx * px + gxy * py;
+                    acc[4][l] += gxy * px + gyy * py;
                 }
             }
-            for (int o = leaves >> 1; o > 0; o >>= 1)
+            for (int o = 1; o < 16; o <<= 1)
                 for (int q = 0; q < 5; ++q) {
-                    double tmp[256];
-                    for (int t = 0; t < leaves; ++t) tmp[t] = acc[q][t] + acc[q][t ^ o];
-                    for (int t = 0; t < leaves; ++t) acc[q][t] = tmp[t];
+                    double tmp[16];
+                    for (int t = 0; t < 16; ++t) tmp[t] = acc[q][t] + acc[q][t ^ o];
+                    for (int t = 0; t < 16; ++t) acc[q][t] = tmp[t];
                 }
             const double A = acc[0][0], Bm = acc[1][0], C = acc[2][0], bb1 = acc[3][0], bb2 = acc[4][0];
             const double det = A * C - Bm * Bm;

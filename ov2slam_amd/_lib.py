@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libov2hip.so")
+# OV2SLAM_HIP_LIB selects another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("OV2SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libov2hip.so")
 
 vp = C.c_void_p
 vpp = C.POINTER(C.c_void_p)

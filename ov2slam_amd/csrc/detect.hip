@@ -332,75 +332,112 @@ __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__re
     }
 }
 
-// cv::cornerSubPix, one wave per point: the (2hw+3)^2 bilinear samples are computed by the lanes, the 2x2 normal
-// equations are then accumulated by lane 0 in the row-major order of the oracle (double), so results are bit-equal.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// 16-leaf pairwise tree ((l0+l1)+(l2+l3))+... over a DPP row, total in every lane of the row.  After the two quad steps
+// all lanes of a quad agree, so the mirror steps pair equal partial sums exactly like xor 4 / xor 8 would.
+__device__ __forceinline__ double row_tree_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return v;
+}
+
+// cv::cornerSubPix (win = (HW,HW), zeroZone none): FOUR points per wave, one per DPP row of 16 lanes.
+// Per iteration: the (2HW+4)^2 source pixels are fetched once (clamped = getRectSubPix's BORDER_REPLICATE) into LDS,
+// the (2HW+3)^2 bilinear samples are formed from LDS, window term t is owned by lane t % 16 (terms t, t+16, ... added
+// in that order), the five sums are closed by the 16-leaf tree above (the oracle uses the same order => bit-equal)
+// and every lane of the row solves the 2x2 system, so the scalar work of an iteration is shared by four points.
+template <int HW>
 __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                     const int *__restrict__ pt_img, int istride, int w, int h, int n,
-                                                    float2 *__restrict__ pts, int hw, int max_iter, double eps2,
+                                                    float2 *__restrict__ pts, int max_iter, double eps2,
                                                     const float *__restrict__ wmask)
 {
-    __shared__ float buf[17 * 17];
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (p >= n) return;
-    const unsigned char *img = img0 + img_bstride * pt_img[p];
-    const int win = 2 * hw + 1, bw = win + 2;
-    const float cTx = pts[p].x, cTy = pts[p].y;
+    constexpr int WIN = 2 * HW + 1, BW = WIN + 2, SW = BW + 1, NT = WIN * WIN, NK = (NT + 15) / 16;
+    __shared__ unsigned char src[4][(SW * SW + 3) & ~3];
+    __shared__ float buf[4][BW * BW];
+    const int lane = threadIdx.x, sub = lane & 15, row = lane >> 4;
+    const int p = blockIdx.x * 4 + row;
+    const bool act = p < n;
+    const int pp = act ? p : n - 1;
+    const unsigned char *img = img0 + img_bstride * pt_img[pp];
+    const float cTx = pts[pp].x, cTy = pts[pp].y;
     float cIx = cTx, cIy = cTy;
     int iter = 0;
-    double err = 0;
-    bool go = true;
-    while (go) {
-        const float cx = cIx - (float)(bw - 1) * 0.5f, cy = cIy - (float)(bw - 1) * 0.5f;
+    bool go = act;
+    double wm[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) wm[k] = (sub + 16 * k < NT) ? (double)wmask[sub + 16 * k] : 0.0;
+    while (__any(go)) {
+        const float cx = cIx - (float)(BW - 1) * 0.5f, cy = cIy - (float)(BW - 1) * 0.5f;
         const int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
         const float a = cx - (float)ipx, b = cy - (float)ipy;
         const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
-        for (int q = lane; q < bw * bw; q += 64) {
-            const int i = q / bw, j = q - i * bw;
-            const int xa = min(max(ipx + j, 0), w - 1), xb = min(max(ipx + j + 1, 0), w - 1);
-            const int ya = min(max(ipy + i, 0), h - 1), yb = min(max(ipy + i + 1, 0), h - 1);
-            buf[q] = (float)img[(size_t)ya * istride + xa] * a11 + (float)img[(size_t)ya * istride + xb] * a12 +
-                     (float)img[(size_t)yb * istride + xa] * a21 + (float)img[(size_t)yb * istride + xb] * a22;
+        if (go) {
+#pragma unroll
+            for (int q = sub; q < SW * SW; q += 16) {
+                const int i = q / SW, j = q - i * SW;
+                const int xa = min(max(ipx + j, 0), w - 1), ya = min(max(ipy + i, 0), h - 1);
+                src[row][q] = img[(size_t)ya * istride + xa];
+            }
         }
         __syncthreads();
-        float nx = cIx, ny = cIy;
-        int stop = 0;
-        {
-            // lane t < win*win owns window term t; the five sums are a fixed 64-leaf xor butterfly in double (the order
-            // the oracle uses), after which every lane holds the totals and solves the 2x2 system redundantly
-            double A = 0, Bm = 0, C = 0, bb1 = 0, bb2 = 0;
-            if (lane < win * win) {
-                const int i = lane / win, j = lane - i * win;
-                const float *sp = buf + (i + 1) * bw + (j + 1);
-                const double m = wmask[lane];
-                const double tgx = sp[1] - sp[-1];
-                const double tgy = sp[bw] - sp[-bw];
-                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
-                const double px = j - hw, py = i - hw;
-                A = gxx; Bm = gxy; C = gyy;
-                bb1 = gxx * px + gxy * py;
-                bb2 = gxy * px + gyy * py;
+        if (go) {
+#pragma unroll
+            for (int q = sub; q < BW * BW; q += 16) {
+                const int i = q / BW, j = q - i * BW;
+                const unsigned char *sp = &src[row][i * SW + j];
+                buf[row][q] = (float)sp[0] * a11 + (float)sp[1] * a12 + (float)sp[SW] * a21 + (float)sp[SW + 1] * a22;
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                A += __shfl_xor(A, o); Bm += __shfl_xor(Bm, o); C += __shfl_xor(C, o);
-                bb1 += __shfl_xor(bb1, o); bb2 += __shfl_xor(bb2, o);
+        }
+        __syncthreads();
+        double A = 0, Bm = 0, C = 0, bb1 = 0, bb2 = 0;
+        if (go) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int t = sub + 16 * k;
+                if (t < NT) {
+                    const int i = t / WIN, j = t - i * WIN;
+                    const float *sp = &buf[row][(i + 1) * BW + (j + 1)];
+                    const double m = wm[k];
+                    const double tgx = sp[1] - sp[-1];
+                    const double tgy = sp[BW] - sp[-BW];
+                    const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                    const double px = j - HW, py = i - HW;
+                    A += gxx; Bm += gxy; C += gyy;
+                    bb1 += gxx * px + gxy * py;
+                    bb2 += gxy * px + gyy * py;
+                }
             }
+        }
+        A = row_tree_f64(A); Bm = row_tree_f64(Bm); C = row_tree_f64(C);
+        bb1 = row_tree_f64(bb1); bb2 = row_tree_f64(bb2);
+        if (go) {
             const double det = A * C - Bm * Bm;
-            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) stop = 1;
+            if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) go = false;
             else {
                 const double scale = 1.0 / det;
-                nx = (float)(cIx + C * scale * bb1 - Bm * scale * bb2);
-                ny = (float)(cIy - Bm * scale * bb1 + A * scale * bb2);
+                const float nx = (float)(cIx + C * scale * bb1 - Bm * scale * bb2);
+                const float ny = (float)(cIy - Bm * scale * bb1 + A * scale * bb2);
+                const double err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
+                cIx = nx; cIy = ny;
+                if (cIx < 0 || cIx >= (float)w || cIy < 0 || cIy >= (float)h) go = false;
+                else go = (++iter < max_iter) && (err > eps2);
             }
         }
-        __syncthreads();
-        if (stop) break;
-        err = (double)((nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy));
-        cIx = nx; cIy = ny;
-        if (cIx < 0 || cIx >= (float)w || cIy < 0 || cIy >= (float)h) break;
-        go = (++iter < max_iter) && (err > eps2);
     }
-    if (fabsf(cIx - cTx) > (float)hw || fabsf(cIy - cTy) > (float)hw) { cIx = cTx; cIy = cTy; }
-    if (lane == 0) pts[p] = make_float2(cIx, cIy);
+    if (fabsf(cIx - cTx) > (float)HW || fabsf(cIy - cTy) > (float)HW) { cIx = cTx; cIy = cTy; }
+    if (act && sub == 0) pts[p] = make_float2(cIx, cIy);
 }
 
 }  // namespace
@@ -558,8 +595,8 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
         OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(dpts, pts.data(), (size_t)ntot * 8, hipMemcpyHostToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(dpimg, pimg.data(), (size_t)ntot * 4, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT + 2, subpix_kernel, dim3(ntot), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride, w, h, ntot,
-                   dpts, hw, 30, 0.01 * 0.01, dwm);
+        OV2_LAUNCH(c, OV2_K_DETECT + 2, subpix_kernel<3>, dim3((ntot + 3) / 4), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride,
+                   w, h, ntot, dpts, 30, 0.01 * 0.01, dwm);
         OV2_HIP(c, hipMemcpyAsync(pts.data(), dpts, (size_t)ntot * 8, hipMemcpyDeviceToHost, st));
         OV2_HIP(c, hipStreamSynchronize(st));
         int k = 0;

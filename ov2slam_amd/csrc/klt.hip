@@ -328,7 +328,10 @@ __global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_vie
 // failures in stage 2).  A workgroup of 8 waves owns a window of 32 consecutive keypoints; every wave ballots the
 // same 32 liveness flags and the j-th live keypoint goes to DPP row j of the workgroup, so the launched waves are
 // full (instead of 30-70 % idle rows) and waves beyond the live count retire at once.  No atomics, no LDS.
-#define KLT_WINDOW 32
+#ifndef KLT_WINDOW
+#define KLT_WINDOW 32   // keypoints per workgroup (16 or 32); 4 per wave
+#endif
+#define KLT_WMASK ((KLT_WINDOW == 32) ? 0xffffffffu : 0xffffu)
 
 __device__ __forceinline__ int nth_set_bit(unsigned m, int idx)
 {
@@ -338,7 +341,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned m, int idx)
 
 // stage 1: keypoints with a prior, 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190)
 template <int WIN>
-__global__ __launch_bounds__(512) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+__global__ __launch_bounds__(KLT_WINDOW * 16) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                          const float2 *__restrict__ kps,
                                                          const float2 *__restrict__ prior,
                                                          const unsigned char *__restrict__ has_prior,
@@ -349,14 +352,14 @@ __global__ __launch_bounds__(512) void klt_stage1_kernel(ov2_pyr_view pv, ov2_py
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
     const int base = blockIdx.x * KLT_WINDOW;
-    const int f = base + (lane & 31);
+    const int f = base + (lane & (KLT_WINDOW - 1));
     const bool live = f < n && has_prior[f] != 0;
-    if (wv == 0 && lane < 32 && f < n && !live) {   // no prior: stage 2 starts from the keypoint itself
+    if (wv == 0 && lane < KLT_WINDOW && f < n && !live) {   // no prior: stage 2 starts from the keypoint itself
         out_xy[f] = kps[f];
         out_status[f] = 0;
         if (iters) iters[f] = 0;
     }
-    const unsigned m32 = (unsigned)(__ballot(live) & 0xffffffffull);
+    const unsigned m32 = (unsigned)(__ballot(live) & (unsigned long long)KLT_WMASK);
     const int total = __popc(m32);
     if (wv * 4 >= total) return;
     const int idx = wv * 4 + row;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(512) void klt_stage1_kernel(ov2_pyr_view pv, ov2_py
 
 // stage 2: keypoints without prior + stage-1 failures, full pyramid (src/visual_front_end.cpp:237-270)
 template <int WIN>
-__global__ __launch_bounds__(512) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+__global__ __launch_bounds__(KLT_WINDOW * 16) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                          const float2 *__restrict__ kps,
                                                          const unsigned char *__restrict__ has_prior,
                                                          const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
@@ -391,11 +394,11 @@ __global__ __launch_bounds__(512) void klt_stage2_kernel(ov2_pyr_view pv, ov2_py
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
     const int base = blockIdx.x * KLT_WINDOW;
-    const int f = base + (lane & 31);
+    const int f = base + (lane & (KLT_WINDOW - 1));
     const bool hpf = f < n && has_prior[f] != 0;
     const bool live = f < n && !(hpf && out_status[f] != 0);   // not already tracked in stage 1
-    if (wv == 0 && lane < 32 && f < n && !live && iters) iters[n + f] = 0;
-    const unsigned m32 = (unsigned)(__ballot(live) & 0xffffffffull);
+    if (wv == 0 && lane < KLT_WINDOW && f < n && !live && iters) iters[n + f] = 0;
+    const unsigned m32 = (unsigned)(__ballot(live) & (unsigned long long)KLT_WMASK);
     const int total = __popc(m32);
     if (wv * 4 >= total) return;
     const int idx = wv * 4 + row;
@@ -529,11 +532,11 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     if (d_p3p_req) OV2_HIP(c, hipMemsetAsync(d_p3p_req, 0, (size_t)B * sizeof(int), c->stream));
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \
-        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(512), 0, c->stream,        \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(KLT_WINDOW * 16), 0, c->stream,        \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),             \
                    reinterpret_cast<const float2 *>(d_prior), d_has_prior, d_img_idx,                          \
                    reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters);                       \
-        OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(512), 0, c->stream,        \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(KLT_WINDOW * 16), 0, c->stream,        \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_has_prior, \
                    d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters);  \
     } while (0)
