@@ -1,4 +1,4 @@
-// klt.hip -- forward-backward pyramidal Lucas-Kanade, FOUR keypoints per 64-lane wavefront (gfx950).
+// klt.hip -- forward-backward pyramidal Lucas-Kanade, EIGHT keypoints per 64-lane wavefront (gfx950).
 //
 // Replaces (reference, /root/reference): FeatureTracker::fbKltTracking src/feature_tracker.cpp:35-137
 // (= 2x cv::calcOpticalFlowPyrLK + the status / err / inBorder / forward-backward gates) and the two-stage
@@ -37,13 +37,14 @@ __device__ __forceinline__ int dpp_i32(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
 
-// sum over the 16 lanes of a DPP row, result in every lane of the row
+// sum over the GL (8 or 16) lanes of a keypoint's lane group, result in every lane of the group
+template <int GL>
 __device__ __forceinline__ int row_sum_i32(int v)
 {
     v += dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_i32<0x141>(v);   // row_half_mirror
-    v += dpp_i32<0x140>(v);   // row_mirror
+    v += dpp_i32<0x141>(v);   // row_half_mirror: lane l <-> 7 - l of its half row
+    if (GL == 16) v += dpp_i32<0x140>(v);   // row_mirror
     return v;
 }
 
@@ -57,12 +58,13 @@ __device__ __forceinline__ double dpp_f64k(double v)
 }
 
 // exact: the addends are integers below 2^32, every partial sum is an integer below 2^53
+template <int GL>
 __device__ __forceinline__ double row_sum_f64(double v)
 {
     v += dpp_f64k<0xB1>(v);
     v += dpp_f64k<0x4E>(v);
     v += dpp_f64k<0x141>(v);
-    v += dpp_f64k<0x140>(v);
+    if (GL == 16) v += dpp_f64k<0x140>(v);
     return v;
 }
 
@@ -114,13 +116,21 @@ __device__ __forceinline__ level_ptrs level_of(const ov2_pyr_view &v, int l, int
     return p;
 }
 
-// One LKTrackerInvoker pass (one pyramid level) for the keypoint of this DPP row.  `run` (row-uniform) says whether
-// the row takes part; everything below is row-uniform except the window column `sub`.  Returns iterations executed.
-template <int WIN>
-__device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
-                                          bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
-                                          float &err, const klt_params &P, int sub, unsigned &passes)
+// One LKTrackerInvoker pass (one pyramid level) for the keypoint of this lane group (GL = 8 or 16 lanes).  `run`
+// (group-uniform) says whether the group takes part; everything below is group-uniform except the lane's share of the
+// window.  Lane `sub` < OC owns window column `sub` and walks its WIN rows (row y+1's load is row y's lower
+// neighbours).  With GL = 8 a 9- or 11-wide window has EC = WIN - 8 columns left: their EC*WIN pixels are dealt out one
+// per lane and round (pixel e = sub + GL*round), each with its own four taps.  Returns iterations executed.
+template <int WIN, int GL>
+__device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
+                                        bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
+                                        float &err, const klt_params &P, int sub, unsigned &passes)
 {
+    constexpr int OC = WIN < GL ? WIN : GL;        // columns with an owner lane
+    constexpr int NE = (WIN - OC) * WIN;           // pixels of the remaining columns
+    constexpr int NR = (NE + GL - 1) / GL;         // rounds to deal them out
+    constexpr int NRP = (NR + 1) / 2;
+    constexpr int NP = (WIN + 1) / 2;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const float half = (float)(WIN - 1) * 0.5f;
     const float lscale = 1.f / (float)(1 << level);
@@ -141,20 +151,21 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
     int w00, w01, w10, w11;
     lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
 
-    // template of this lane's column: WIN pixels (I, Ix, Iy), two rows per register as int16 pairs; lanes >= WIN and
-    // idle rows hold zero gradients, so whatever they compute below drops out of the sums
-    const bool col = sub < WIN;
+    // template (I, Ix, Iy per window pixel), two pixels per register as int16 pairs; idle lanes / groups hold zero
+    // gradients, so whatever they compute below drops out of the sums
+    const bool col = sub < OC;
     const int sc = col ? sub : 0;
-    constexpr int NP = (WIN + 1) / 2;
     unsigned Iv2[NP], Ix2[NP], Iy2[NP];
+    unsigned IvE[NRP > 0 ? NRP : 1], IxE[NRP > 0 ? NRP : 1], IyE[NRP > 0 ? NRP : 1];
+    int eoff[NR > 0 ? NR : 1];   // byte offset of the lane's round-r pixel inside a u8 plane (rows * stride + column)
     int sA11 = 0, sA12 = 0, sA22 = 0;
     {
         // bilinear taps as two v_dot2_i32_i16: (p[x], p[x+1]) . (w00, w01) + (p[x], p[x+1])' . (w10, w11); the weights
         // fit int16 (w11 can be -1 after rounding), pixels and Scharr gradients too
         const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
-        const int bx = run ? (OV2_LM + ipx + sc) : OV2_LM, by = run ? (ipy + pad) : pad;
-        const unsigned char *ip = I.img + (size_t)by * I.istride + bx;
-        const int *gp = I.grad + (size_t)by * I.gstride + bx;
+        const int bx0 = run ? (OV2_LM + ipx) : OV2_LM, by = run ? (ipy + pad) : pad;
+        const unsigned char *ip = I.img + (size_t)by * I.istride + bx0 + sc;
+        const int *gp = I.grad + (size_t)by * I.gstride + bx0 + sc;
         unsigned T = spread_u8x2(ld_u16(ip));
         unsigned GX, GY;
         {
@@ -183,11 +194,39 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
             }
             T = B; GX = HX; GY = HY;
         }
+        // pixels of the columns without an owner lane
+        const unsigned char *ib = I.img + (size_t)by * I.istride + bx0;
+        const int *gb = I.grad + (size_t)by * I.gstride + bx0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = sub + GL * r;
+            const bool ev = e < NE;
+            const int ec = ev ? e : 0;
+            const int ecol = OC + ec / WIN, erow = ec - (ec / WIN) * WIN;
+            eoff[r] = erow * J.istride + ecol;
+            const unsigned char *ipe = ib + erow * I.istride + ecol;
+            const int *gpe = gb + erow * I.gstride + ecol;
+            const unsigned T0 = spread_u8x2(ld_u16(ipe)), T1 = spread_u8x2(ld_u16(ipe + I.istride));
+            const unsigned g0 = (unsigned)gpe[0], g1 = (unsigned)gpe[1];
+            const unsigned h0 = (unsigned)gpe[I.gstride], h1 = (unsigned)gpe[I.gstride + 1];
+            const unsigned iv = (unsigned)dot2(T1, W23, dot2(T0, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            int ix = dot2(pack_lo16(h0, h1), W23, dot2(pack_lo16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
+            int iy = dot2(pack_hi16(h0, h1), W23, dot2(pack_hi16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
+            if (!(run && ev)) { ix = 0; iy = 0; }
+            sA11 += __mul24(ix, ix); sA12 += __mul24(ix, iy); sA22 += __mul24(iy, iy);
+            if (r & 1) {
+                IvE[r >> 1] = pack_lo16(piv, iv); IxE[r >> 1] = pack_lo16(pix, (unsigned)ix); IyE[r >> 1] = pack_lo16(piy, (unsigned)iy);
+            } else if (r == NR - 1) {
+                IvE[r >> 1] = iv; IxE[r >> 1] = (unsigned)ix & 0xffffu; IyE[r >> 1] = (unsigned)iy & 0xffffu;
+            } else {
+                piv = iv; pix = (unsigned)ix; piy = (unsigned)iy;
+            }
+        }
     }
     // |Ix|,|Iy| <= 4080 for u8 images: WIN*WIN <= 121 products stay below 2^31 -> exact in int32
-    const float A11 = (float)(double)row_sum_i32(sA11) * FLT_SCALE;
-    const float A12 = (float)(double)row_sum_i32(sA12) * FLT_SCALE;
-    const float A22 = (float)(double)row_sum_i32(sA22) * FLT_SCALE;
+    const float A11 = (float)(double)row_sum_i32<GL>(sA11) * FLT_SCALE;
+    const float A12 = (float)(double)row_sum_i32<GL>(sA12) * FLT_SCALE;
+    const float A22 = (float)(double)row_sum_i32<GL>(sA22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float min_eig = __fdiv_rn(A22 + A11 - __fsqrt_rn((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
                                     (float)(2 * WIN * WIN));
@@ -211,7 +250,8 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
             run = false;
         }
         lk_weights(nx - (float)inx, ny - (float)iny, w00, w01, w10, w11);
-        const unsigned char *jp = J.img + (size_t)((run ? iny : 0) + pad) * J.istride + OV2_LM + (run ? inx + sc : 0);
+        const unsigned char *jb = J.img + (size_t)((run ? iny : 0) + pad) * J.istride + OV2_LM + (run ? inx : 0);
+        const unsigned char *jp = jb + sc;
         const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         int pb1 = 0, pb2 = 0;
         unsigned T = spread_u8x2(ld_u16(jp));
@@ -234,17 +274,32 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
             pb1 = dot2(d2, Ix2[q], pb1);   // |diff| <= 8160, |Ix| <= 4080
             pb2 = dot2(d2, Iy2[q], pb2);
         }
-        // a lane holds <= 11 products of <= 3.4e7: fits int32; the row total may not, so sum exactly in f64
-        // Usual case (wave-uniform test): every lane's partial is below 2^27, the 16-lane total fits int32 and
-        // v_cvt_f32_i32 rounds it once, exactly like (float)(double)total -- 8 DPP adds instead of 16 DPP moves + 8
-        // f64 adds.
+#pragma unroll
+        for (int q = 0; q < NRP; ++q) {   // the lane's pixels of the ownerless columns, two rounds per register
+            const unsigned char *pe = jb + eoff[2 * q];
+            const unsigned j0 = (unsigned)dot2(spread_u8x2(ld_u16(pe + J.istride)), W23,
+                                               dot2(spread_u8x2(ld_u16(pe)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            unsigned j1 = 0;
+            if (2 * q + 1 < NR) {
+                const unsigned char *pf = jb + eoff[2 * q + 1];
+                j1 = (unsigned)dot2(spread_u8x2(ld_u16(pf + J.istride)), W23,
+                                    dot2(spread_u8x2(ld_u16(pf)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            }
+            const unsigned d2 = pk_sub16(j0 | (j1 << 16), IvE[q]);
+            pb1 = dot2(d2, IxE[q], pb1);
+            pb2 = dot2(d2, IyE[q], pb2);
+        }
+        // a lane holds <= 16 products of <= 3.4e7: fits int32; the group total may not, so sum exactly in f64.
+        // Usual case (wave-uniform test): every lane's partial is below 2^27, the group total fits int32 and
+        // v_cvt_f32_i32 rounds it once, exactly like (float)(double)total -- DPP-fused integer adds instead of DPP
+        // moves + f64 adds.
         float b1, b2;
         if (__all((unsigned)(pb1 + (1 << 27)) < (1u << 28) && (unsigned)(pb2 + (1 << 27)) < (1u << 28))) {
-            b1 = (float)row_sum_i32(pb1) * FLT_SCALE;
-            b2 = (float)row_sum_i32(pb2) * FLT_SCALE;
+            b1 = (float)row_sum_i32<GL>(pb1) * FLT_SCALE;
+            b2 = (float)row_sum_i32<GL>(pb2) * FLT_SCALE;
         } else {
-            b1 = (float)row_sum_f64((double)pb1) * FLT_SCALE;
-            b2 = (float)row_sum_f64((double)pb2) * FLT_SCALE;
+            b1 = (float)row_sum_f64<GL>((double)pb1) * FLT_SCALE;
+            b2 = (float)row_sum_f64<GL>((double)pb2) * FLT_SCALE;
         }
         const float dx = (A12 * b2 - A22 * b1) * D;
         const float dy = (A12 * b1 - A11 * b2) * D;
@@ -266,8 +321,8 @@ __device__ __forceinline__ int lk_level16(const level_ptrs &I, const level_ptrs 
 
 // FeatureTracker::fbKltTracking for the keypoint of this DPP row (act = row has a keypoint).
 // returns status (0/1); fx,fy = forward result; work = iterations | level passes << 16.
-template <int WIN>
-__device__ __forceinline__ int fb_track16(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx,
+template <int WIN, int GL>
+__device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx,
                                           float ky, float &fx, float &fy, const klt_params &P, int nlevels, int sub,
                                           unsigned &work)
 {
@@ -276,7 +331,7 @@ __device__ __forceinline__ int fb_track16(const ov2_pyr_view &pv, const ov2_pyr_
     unsigned it = 0, passes = 0;
     for (int l = nlevels; l >= 0; --l) {
         const level_ptrs I = level_of(pv, l, b), J = level_of(cv, l, b);
-        it += lk_level16<WIN>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes);
+        it += lk_level<WIN, GL>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes);
     }
     // gates of src/feature_tracker.cpp:79-101
     const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
@@ -287,7 +342,7 @@ __device__ __forceinline__ int fb_track16(const ov2_pyr_view &pv, const ov2_pyr_
     float e2 = 0.f, bx = kx, by = ky;
     {
         const level_ptrs I = level_of(cv, 0, b), J = level_of(pv, 0, b);
-        it += lk_level16<WIN>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes);
+        it += lk_level<WIN, GL>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes);
     }
     if (ok) {
         if (!st2) ok = 0;
@@ -301,21 +356,28 @@ __device__ __forceinline__ int fb_track16(const ov2_pyr_view &pv, const ov2_pyr_
     return ok;
 }
 
-// 64 threads = 4 keypoints.  grid = ceil(n / 4)
-template <int WIN>
+// Lanes per keypoint, chosen per call: 8 lanes (eight keypoints per wave) halve the wave-instructions per keypoint and
+// win once the launch holds several rounds of waves (measured: 106k vs 103k frames/s at 64 x 2048 keypoints per call);
+// 16 lanes (four per wave) give twice as many, shorter waves and win while the launch is latency-bound (68k vs 60k
+// frames/s at 16 x 2048).
+#define KLT_GL8_MIN_KPS 65536
+
+// 64 threads = 64 / GL keypoints.  grid = ceil(n / (64 / GL))
+template <int WIN, int KLT_GL>
 __global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                     const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                     unsigned char *__restrict__ status,
                                                     const int *__restrict__ img_idx, unsigned *__restrict__ iters)
 {
-    const int sub = threadIdx.x & 15, i = blockIdx.x * 4 + (threadIdx.x >> 4);
+    constexpr int KLT_KPW = 64 / KLT_GL;
+    const int sub = threadIdx.x & (KLT_GL - 1), i = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
     const bool act = i < n;
     const int ii = act ? i : 0;
     const int b = img_idx ? img_idx[ii] : 0;
     const float2 kp = kps[ii];
     float2 pr = priors[ii];
     unsigned work = 0;
-    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
     if (act && sub == 0) {
         priors[i] = pr;
         status[i] = (unsigned char)ok;
@@ -325,53 +387,78 @@ __global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_vie
 
 // ---- VisualFrontEnd::kltTracking, two stages without a host round trip -------------------------------
 // Only a fraction of the keypoints is live in each stage (those with a prior in stage 1; the rest + the stage-1
-// failures in stage 2).  A workgroup of 8 waves owns a window of 32 consecutive keypoints; every wave ballots the
-// same 32 liveness flags and the j-th live keypoint goes to DPP row j of the workgroup, so the launched waves are
-// full (instead of 30-70 % idle rows) and waves beyond the live count retire at once.  No atomics, no LDS.
-#ifndef KLT_WINDOW
-#define KLT_WINDOW 32   // keypoints per workgroup (16 or 32); 4 per wave
-#endif
-#define KLT_WMASK ((KLT_WINDOW == 32) ? 0xffffffffu : 0xffffu)
+// failures in stage 2).  A small compaction pass writes the indices of the live keypoints (order irrelevant: every
+// keypoint is tracked independently) and their count; the tracking kernels are single-wave workgroups, workgroup g
+// takes live keypoints [g*KPW, (g+1)*KPW) and workgroups beyond the count retire at once.  So every launched wave is
+// full, there is no intra-workgroup imbalance, and the grid needs no host-side knowledge of the live count.
 
-__device__ __forceinline__ int nth_set_bit(unsigned m, int idx)
+// stage = 1: live = has a prior (the others are initialised for stage 2: position = the keypoint itself, status 0);
+// stage = 2: live = not already tracked in stage 1.
+__global__ __launch_bounds__(256) void klt_compact_kernel(int n, int stage, const unsigned char *__restrict__ has_prior,
+                                                          const float2 *__restrict__ kps, float2 *__restrict__ out_xy,
+                                                          unsigned char *__restrict__ out_status,
+                                                          unsigned *__restrict__ iters, int *__restrict__ live_idx,
+                                                          unsigned *__restrict__ live_cnt, int *__restrict__ p3p_req,
+                                                          int batch)
 {
-    for (int t = 0; t < idx; ++t) m &= m - 1u;
-    return __ffs(m) - 1;
+    __shared__ int wsum[4];
+    __shared__ int wbase;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    bool live = false;
+    if (f < n) {
+        const bool hp = has_prior[f] != 0;
+        if (stage == 1) {
+            live = hp;
+            if (!live) {   // no prior: stage 2 starts from the keypoint itself
+                out_xy[f] = kps[f];
+                out_status[f] = 0;
+                if (iters) iters[f] = 0;
+            }
+        } else {
+            live = !(hp && out_status[f] != 0);
+            if (!live && iters) iters[n + f] = 0;
+        }
+    }
+    if (stage == 1 && p3p_req)
+        for (int k = f; k < batch; k += gridDim.x * 256) p3p_req[k] = 0;
+    const unsigned long long m = __ballot(live);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        wbase = tot ? (int)atomicAdd(live_cnt, (unsigned)tot) : 0;
+    }
+    __syncthreads();
+    int off = wbase;
+    for (int k = 0; k < wv; ++k) off += wsum[k];
+    if (live) live_idx[off + rank] = f;
 }
 
 // stage 1: keypoints with a prior, 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190)
-template <int WIN>
-__global__ __launch_bounds__(KLT_WINDOW * 16) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
-                                                         const float2 *__restrict__ kps,
-                                                         const float2 *__restrict__ prior,
-                                                         const unsigned char *__restrict__ has_prior,
-                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
-                                                         unsigned char *__restrict__ out_status,
-                                                         unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
-                                                         unsigned *__restrict__ iters)
+template <int WIN, int KLT_GL>
+__global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+                                                        const float2 *__restrict__ kps,
+                                                        const float2 *__restrict__ prior,
+                                                        const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
+                                                        unsigned char *__restrict__ out_status,
+                                                        unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
+                                                        unsigned *__restrict__ iters, const int *__restrict__ live_idx,
+                                                        const unsigned *__restrict__ live_cnt)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
-    const int base = blockIdx.x * KLT_WINDOW;
-    const int f = base + (lane & (KLT_WINDOW - 1));
-    const bool live = f < n && has_prior[f] != 0;
-    if (wv == 0 && lane < KLT_WINDOW && f < n && !live) {   // no prior: stage 2 starts from the keypoint itself
-        out_xy[f] = kps[f];
-        out_status[f] = 0;
-        if (iters) iters[f] = 0;
-    }
-    const unsigned m32 = (unsigned)(__ballot(live) & (unsigned long long)KLT_WMASK);
-    const int total = __popc(m32);
-    if (wv * 4 >= total) return;
-    const int idx = wv * 4 + row;
+    constexpr int KLT_KPW = 64 / KLT_GL;
+    const int total = (int)*live_cnt;
+    if ((int)blockIdx.x * KLT_KPW >= total) return;
+    const int sub = threadIdx.x & (KLT_GL - 1), idx = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
     const bool act = idx < total;
-    const int i = base + (act ? nth_set_bit(m32, idx) : 0);
-    const int ii = min(i, n - 1);
-    const float2 kp = kps[ii];
-    const int b = img_idx ? img_idx[ii] : 0;
-    float2 pr = prior[ii];
+    const int i = live_idx[act ? idx : total - 1];
+    const float2 kp = kps[i];
+    const int b = img_idx ? img_idx[i] : 0;
+    float2 pr = prior[i];
     unsigned work = 0;
     const int nl = min(1, pv.nlevels - 1);
-    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work);
     if (act && sub == 0) {
         out_xy[i] = pr;   // tracked position, or the failed forward result that seeds stage 2 (:217-219)
         out_status[i] = (unsigned char)ok;
@@ -383,43 +470,37 @@ __global__ __launch_bounds__(KLT_WINDOW * 16) void klt_stage1_kernel(ov2_pyr_vie
 }
 
 // stage 2: keypoints without prior + stage-1 failures, full pyramid (src/visual_front_end.cpp:237-270)
-template <int WIN>
-__global__ __launch_bounds__(KLT_WINDOW * 16) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
-                                                         const float2 *__restrict__ kps,
-                                                         const unsigned char *__restrict__ has_prior,
-                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
-                                                         unsigned char *__restrict__ out_status,
-                                                         const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
-                                                         unsigned *__restrict__ iters)
+template <int WIN, int KLT_GL>
+__global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+                                                        const float2 *__restrict__ kps,
+                                                        const unsigned char *__restrict__ has_prior,
+                                                        const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
+                                                        unsigned char *__restrict__ out_status,
+                                                        const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
+                                                        unsigned *__restrict__ iters, const int *__restrict__ live_idx,
+                                                        const unsigned *__restrict__ live_cnt)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 15, row = lane >> 4;
-    const int base = blockIdx.x * KLT_WINDOW;
-    const int f = base + (lane & (KLT_WINDOW - 1));
-    const bool hpf = f < n && has_prior[f] != 0;
-    const bool live = f < n && !(hpf && out_status[f] != 0);   // not already tracked in stage 1
-    if (wv == 0 && lane < KLT_WINDOW && f < n && !live && iters) iters[n + f] = 0;
-    const unsigned m32 = (unsigned)(__ballot(live) & (unsigned long long)KLT_WMASK);
-    const int total = __popc(m32);
-    if (wv * 4 >= total) return;
-    const int idx = wv * 4 + row;
+    constexpr int KLT_KPW = 64 / KLT_GL;
+    const int total = (int)*live_cnt;
+    if ((int)blockIdx.x * KLT_KPW >= total) return;
+    const int sub = threadIdx.x & (KLT_GL - 1), idx = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
     const bool act = idx < total;
-    const int i = base + (act ? nth_set_bit(m32, idx) : 0);
-    const int ii = min(i, n - 1);
-    const int b = img_idx ? img_idx[ii] : 0;
-    // per-image stage-1 tally: 64 slots, 4 per lane of the row
+    const int i = live_idx[act ? idx : total - 1];
+    const int b = img_idx ? img_idx[i] : 0;
+    // per-image stage-1 tally: 64 slots shared out over the lanes of the group
     int n3 = 0, good = 0;
-    for (int q = 0; q < 4; ++q) {
-        const unsigned cw = counts[64 * b + sub * 4 + q];
+    for (int q = 0; q < 64 / KLT_GL; ++q) {
+        const unsigned cw = counts[64 * b + sub * (64 / KLT_GL) + q];
         n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
     }
-    n3 = row_sum_i32(n3); good = row_sum_i32(good);
+    n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
     const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
     if (act && sub == 0 && p3p_req && drop) p3p_req[b] = 1;
-    const bool hp = has_prior[ii] != 0;
-    const float2 kp = kps[ii];
-    float2 pr = (hp && !drop) ? out_xy[ii] : kp;
+    const bool hp = has_prior[i] != 0;
+    const float2 kp = kps[i];
+    float2 pr = (hp && !drop) ? out_xy[i] : kp;
     unsigned work = 0;
-    const int ok = fb_track16<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
     if (act && sub == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
@@ -468,10 +549,15 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
+#define KLT_FB_GL(W, G)                                                                                        \
+    OV2_LAUNCH(c, OV2_K_KLT_FB, (klt_fb_kernel<W, G>), dim3((n + 64 / G - 1) / (64 / G)), dim3(64), 0, c->stream,    \
+               prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),                 \
+               reinterpret_cast<float2 *>(d_priors), d_status, d_img_idx, d_iters)
 #define KLT_FB(W)                                                                                              \
-    OV2_LAUNCH(c, OV2_K_KLT_FB, klt_fb_kernel<W>, dim3((n + 3) / 4), dim3(64), 0, c->stream, prev->buf->view,  \
-               cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_priors), \
-               d_status, d_img_idx, d_iters)
+    do {                                                                                                       \
+        if (n >= KLT_GL8_MIN_KPS) KLT_FB_GL(W, 8);                                                             \
+        else KLT_FB_GL(W, 16);                                                                                 \
+    } while (0)
     switch (win) {
     case 3: KLT_FB(3); break;
     case 5: KLT_FB(5); break;
@@ -480,6 +566,7 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     default: KLT_FB(11); break;
     }
 #undef KLT_FB
+#undef KLT_FB_GL
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
 }
@@ -524,21 +611,37 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
     const int B = prev->buf->batch;
+    // scratch: [stage-1 tallies B x 64 | live counts (2) ] zeroed per call, then the two live-index lists
+    const size_t cnt_bytes = ((size_t)B * 64 + 16) * sizeof(unsigned);
     void *scr = nullptr;
-    s = ov2_scratch(c, (size_t)B * 64 * sizeof(unsigned) + 256, &scr);
+    s = ov2_scratch(c, cnt_bytes + 2 * (size_t)n * sizeof(int) + 256, &scr);
     if (s != OV2_OK) return s;
-    unsigned *counts = (unsigned *)scr;
-    OV2_HIP(c, hipMemsetAsync(counts, 0, (size_t)B * 64 * sizeof(unsigned), c->stream));
-    if (d_p3p_req) OV2_HIP(c, hipMemsetAsync(d_p3p_req, 0, (size_t)B * sizeof(int), c->stream));
+    unsigned *counts = (unsigned *)scr, *live_cnt = counts + (size_t)B * 64;
+    int *live1 = (int *)((char *)scr + cnt_bytes), *live2 = live1 + n;
+    OV2_HIP(c, hipMemsetAsync(counts, 0, cnt_bytes, c->stream));
+    const dim3 cgrid((n + 255) / 256);
+#define KLT_STAGES_GL(W, G)                                                                                     \
+    do {                                                                                                        \
+        const dim3 tgrid((n + 64 / G - 1) / (64 / G));                                                          \
+        OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 1, d_has_prior,  \
+                   reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_out_xy), d_out_status, \
+                   d_iters, live1, live_cnt, d_p3p_req, B);                                                     \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
+                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),              \
+                   reinterpret_cast<const float2 *>(d_prior), d_img_idx, reinterpret_cast<float2 *>(d_out_xy),  \
+                   d_out_status, counts, d_iters, live1, live_cnt);                                             \
+        OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 2, d_has_prior,  \
+                   reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_out_xy), d_out_status, \
+                   d_iters, live2, live_cnt + 1, d_p3p_req, B);                                                 \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE2, (klt_stage2_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
+                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_has_prior, \
+                   d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters,   \
+                   live2, live_cnt + 1);                                                                        \
+    } while (0)
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \
-        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, klt_stage1_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(KLT_WINDOW * 16), 0, c->stream,        \
-                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),             \
-                   reinterpret_cast<const float2 *>(d_prior), d_has_prior, d_img_idx,                          \
-                   reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters);                       \
-        OV2_LAUNCH(c, OV2_K_KLT_STAGE2, klt_stage2_kernel<W>, dim3((n + KLT_WINDOW - 1) / KLT_WINDOW), dim3(KLT_WINDOW * 16), 0, c->stream,        \
-                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_has_prior, \
-                   d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters);  \
+        if (n >= KLT_GL8_MIN_KPS) KLT_STAGES_GL(W, 8);                                                          \
+        else KLT_STAGES_GL(W, 16);                                                                              \
     } while (0)
     switch (win) {
     case 3: KLT_STAGES(3); break;
@@ -548,6 +651,7 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     default: KLT_STAGES(11); break;
     }
 #undef KLT_STAGES
+#undef KLT_STAGES_GL
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
 }

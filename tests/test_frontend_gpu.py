@@ -185,3 +185,35 @@ def test_fb_klt_full_size_properties(ctx, stream):
     # idempotence of the call itself (deterministic reductions)
     out3, st3 = trk.fbKltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, kps)
     assert np.array_equal(out3.view(np.uint32), out.view(np.uint32)) and np.array_equal(st3, st)
+
+
+@pytest.mark.parametrize("win", [7, 9, 11])
+def test_klt_large_call_eight_lane_path(ctx, oracle, stream, win):
+    """calls with >= 65536 keypoints switch the kernels to 8 lanes per keypoint (eight keypoints per wave; for
+    win 9 / 11 the columns beyond the eighth are dealt out pixel by pixel): bit parity with the oracle on 66k keypoints,
+    through both entry points, incl. the saturated stripe images that force the wide b-sum path."""
+    rng = np.random.default_rng(win)
+    n = 66000
+    kps = np.stack([rng.uniform(4, 748, n), rng.uniform(4, 476, n)], 1).astype(np.float32)
+    I0, I1 = stream.left(0).copy(), stream.left(5).copy()
+    xs = np.arange(752)
+    I0[300:, 500:] = np.where((xs // 3) % 2 == 1, 255, 0).astype(np.uint8)[None, 500:]
+    I0[300::12, 500:] = 128
+    I1[300:, 500:] = 255
+    g0 = fe.preprocess_image(ctx, I0, use_clahe=False, klt_win_size=11)
+    g1 = fe.preprocess_image(ctx, I1, use_clahe=False, klt_win_size=11)
+    o0, o1 = oracle.Pyramid(I0, 11, 3), oracle.Pyramid(I1, 11, 3)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    out, st = trk.fbKltTracking(g0, g1, win, 3, 30.0, 0.5, kps, kps)
+    eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, kps, win, 3, 30.0, 0.5, 30, 0.01)
+    assert np.array_equal(st, est.astype(bool))
+    assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+    assert st[(kps[:, 0] < 480) | (kps[:, 1] < 280)].mean() > 0.9
+    if win == 9:
+        gt = stream.flow(0, 5, kps)
+        pri, has = synth.make_priors(kps, gt, sigma=1.0)
+        out, st, p3p = trk.kltTracking(g0, g1, win, 3, 30.0, 0.5, kps, pri, has)
+        eout, est, ep3p = oracle.klt_tracking_frame(o0, o1, kps, pri, has, win)
+        assert p3p == ep3p
+        assert np.array_equal(st, est.astype(bool))
+        assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
