@@ -58,30 +58,52 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__r
                                                         int tw, int th, int clip_limit, float lut_scale,
                                                         unsigned char *__restrict__ lut)
 {
-    __shared__ int hist[256];
-    __shared__ int scan[256];
+    // 16 interleaved copies of the histogram (copy = lane & 15, fastest index): neighbouring pixels of a natural image
+    // share grey levels, and same-address LDS atomics serialise -- with the copies at most 4 lanes of a wave can meet
+    __shared__ int hist[256][16];
     __shared__ int wsum[4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = blockIdx.x, b = blockIdx.y;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const unsigned char *img = src + sbstride * b;
-    hist[tid] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hist[tid][k] = 0;
     __syncthreads();
-    const int npx = tw * th;
-    for (int i = tid; i < npx; i += 256) {
-        const int yy = i / tw, xx = i - yy * tw;
-        const int y = reflect101(ty * th + yy, h), x = reflect101(tx * tw + xx, w);
-        atomicAdd(&hist[img[(size_t)y * sstride + x]], 1);
+    {
+        // pixel i = tid, tid + 256, ... of the tile in row-major order, kept as (yy, xx) without per-pixel divisions
+        const int q = 256 / tw, r = 256 - q * tw;
+        int yy = tid / tw, xx = tid - yy * tw;
+        const int copy = lane & 15;
+        // chunks of 8 pixels per thread: all loads of a chunk are issued before its atomics, so a thread pays the
+        // memory latency once per chunk instead of once per pixel (measured: the kernel was a chain of ~10 round trips)
+        while (yy < th) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = -1;
+                if (yy < th) {
+                    const int y = reflect101(ty * th + yy, h), x = reflect101(tx * tw + xx, w);
+                    v[k] = img[(size_t)y * sstride + x];
+                }
+                yy += q; xx += r;
+                if (xx >= tw) { xx -= tw; ++yy; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k] >= 0) atomicAdd(&hist[v[k]][copy], 1);
+        }
     }
     __syncthreads();
-    int hv = hist[tid];
+    int hv = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv += hist[tid][(k + tid) & 15];   // rotated start: conflict-free banks
     if (clip_limit > 0) {
         int over = hv > clip_limit ? hv - clip_limit : 0;
         if (over) hv = clip_limit;
         // block sum of `over`
         int s = over;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if ((tid & 63) == 0) wsum[tid >> 6] = s;
+        if (lane == 0) wsum[wv] = s;
         __syncthreads();
         const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         const int batch = clipped / 256;
@@ -92,18 +114,18 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__r
             if (step < 1) step = 1;
             if (tid % step == 0 && tid / step < residual) hv += 1;
         }
+        __syncthreads();
     }
-    // inclusive scan over 256 bins
-    scan[tid] = hv;
+    // inclusive scan over the 256 bins: in-wave shuffle scan, then the totals of the lower waves
+    int v = hv;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) wsum[wv] = v;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int v = scan[tid];
-        if (tid >= o) v += scan[tid - o];
-        __syncthreads();
-        scan[tid] = v;
-        __syncthreads();
-    }
-    lut[((size_t)b * tiles_x * tiles_y + tile) * 256 + tid] = sat_u8_rn((float)scan[tid] * lut_scale);
+    for (int k = 0; k < wv; ++k) v += wsum[k];
+    lut[((size_t)b * tiles_x * tiles_y + tile) * 256 + tid] = sat_u8_rn((float)v * lut_scale);
 }
 
 // ---------------------------------------------------------------------------------------------------
