@@ -23,6 +23,9 @@
 // No MFMA: the dense contractions are 6x6 / 6x1 / 6x3 blocks (latency- and atomics-bound).
 #include "ov2_internal.h"
 
+#include <chrono>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -256,7 +259,7 @@ __device__ inline double block_sum_256(double v, double *sh)
 // ------------------------------------------------------------------------------------------------------
 // K_EVAL: residual (+ jacobian), loss, corrector, Jacobi scaling; cost partial per workgroup
 
-template <bool JAC>
+template <bool JAC, int E>
 __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
                                                       const double *__restrict__ lms, int use_loss, double huber_a,
                                                       int apply_scale, double *__restrict__ part)
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
                 rs = sqrt_rho1 / (1 - alpha);
                 asn = alpha / ev.chi2;
             }
-            const int e = d.e;
+            constexpr int e = E;   // compile-time: the Jl accesses below must not become scratch-backed dynamic indexing
             if (use_loss) {
                 if (asn == 0.0) {
                     for (int i = 0; i < 12; ++i) { ev.Jk[i] *= sqrt_rho1; ev.Ja[i] *= sqrt_rho1; }
@@ -919,8 +922,12 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
 // columns held in LDS; the right-hand side rides along as row m, so the forward substitution is free; the backward
 // substitution is done panel by panel afterwards.  z (solution) overwrites rhs.
 
+// 512 threads: 256 VGPRs per lane, so the register-blocked phases need no scratch (with 1024 threads / 128 VGPRs the
+// kernel spilled ~100 registers, and every dispatch that needs scratch stalled for milliseconds in the runtime's
+// queue-scratch management -- measured: 12-30 ms per minimize() instead of 3)
+#define CHOL_THREADS 512
 template <int NB>
-__global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, double *__restrict__ rhs, int m,
+__global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restrict__ A, double *__restrict__ rhs, int m,
                                                        int *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // the only LDS object of this kernel
@@ -962,20 +969,23 @@ __global__ __launch_bounds__(1024) void ba_chol_kernel(double *__restrict__ A, d
                     // row m (rhs) of previous columns lives in rhs[] after their panel was written back
                     const double *src = (gi < m) ? (A + (size_t)k0 * m + gi) : (rhs + k0);
                     const size_t sstep = (gi < m) ? (size_t)m : 1;
-                    // register double buffer of 16 L[i][k] values: the next batch is in flight while this one is used
-                    double cur[16], nxt[16];
+                    // register double buffer of UB L[i][k] values: the next batch is in flight while this one is used
+                    // (sized for the 256-VGPR budget of a 512-thread workgroup: a dispatch that needs
+                    // scratch costs milliseconds of queue-scratch management on this runtime, see CHOL_THREADS)
+                    constexpr int UB = 16;
+                    double cur[UB], nxt[UB];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) cur[u] = (u < kc) ? src[(size_t)u * sstep] : 0.0;
-                    for (int kk0 = 0; kk0 < kc; kk0 += 16) {
+                    for (int u = 0; u < UB; ++u) cur[u] = (u < kc) ? src[(size_t)u * sstep] : 0.0;
+                    for (int kk0 = 0; kk0 < kc; kk0 += UB) {
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) nxt[u] = (kk0 + 16 + u < kc) ? src[(size_t)(kk0 + 16 + u) * sstep] : 0.0;
+                        for (int u = 0; u < UB; ++u) nxt[u] = (kk0 + UB + u < kc) ? src[(size_t)(kk0 + UB + u) * sstep] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
+                        for (int u = 0; u < UB; ++u) {
 #pragma unroll
                             for (int c = 0; c < HALF; ++c) acc[c] += cur[u] * Lj[(kk0 + u) * NB + c0 + c];
                         }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
+                        for (int u = 0; u < UB; ++u) cur[u] = nxt[u];
                     }
 #pragma unroll
                     for (int c = 0; c < HALF; ++c)
@@ -1220,6 +1230,21 @@ ov2_status dupload(ov2_ctx *c, size_t &off, const T **out, const std::vector<T> 
     return OV2_OK;
 }
 
+// upload path: host arrays are built in a PINNED mirror of the arena at the same offsets and sent with one
+// hipMemcpyAsync.  (Measured: the same data in pageable std::vectors, ~15 copies of 0.5-2 MB, took 10-30 ms to arrive
+// on this runtime; the pinned single copy takes ~0.3 ms.)
+template <typename T>
+ov2_status hcarve(ov2_ctx *c, size_t &off, T **host, const T **dev, size_t n)
+{
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) / 256 * 256;
+    if (off + bytes > c->ba_arena_cap || off + bytes > c->ba_host_cap)
+        return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena exhausted (%zu + %zu > %zu)", off, bytes, c->ba_arena_cap);
+    *host = (T *)((char *)c->ba_host + off);
+    *dev = (const T *)((char *)c->ba_arena + off);
+    off += bytes;
+    return OV2_OK;
+}
+
 struct ba_solver {
     ov2_ctx *c;
     const ov2_ba_problem *P;
@@ -1291,9 +1316,20 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     }
     S.order = rows;
     const int n = d.n_rows;
-    std::vector<unsigned char> type(n);
-    std::vector<int> pose(n), lm(n), anch(n), eb(n), fk(n), fa(n), row_ptr(d.n_e + 1, 0);
-    std::vector<double> uv(2 * (size_t)n), isg(n), auv(2 * (size_t)n, 0.0);
+    ov2_status s;
+    const size_t up0 = S.arena_off;   // start of the uploaded region (host mirror and device arena share offsets)
+    unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa, *row_ptr, *h_lm_of_e, *h_pose_of_f, *pose_ptr, *pose_ent;
+    double *uv, *isg, *auv;
+#define HC(field, hostp, count) if ((s = hcarve(c, S.arena_off, &hostp, &d.field, (size_t)(count))) != OV2_OK) return s
+    HC(type, type, n); HC(pose, pose, n); HC(lm, lm, n); HC(anch, anch, n); HC(eb, eb, n); HC(fk, fk, n); HC(fa, fa, n);
+    HC(uv, uv, 2 * (size_t)n); HC(inv_sigma, isg, n); HC(auv, auv, 2 * (size_t)n); HC(row_ptr, row_ptr, d.n_e + 1);
+    HC(lm_of_e, h_lm_of_e, d.n_e); HC(pose_of_f, h_pose_of_f, d.n_f);
+#undef HC
+    if ((s = hcarve(c, S.arena_off, &pose_ptr, &S.pose_ptr, (size_t)d.n_f + 1)) != OV2_OK) return s;
+    std::copy(lm_of_e.begin(), lm_of_e.end(), h_lm_of_e);
+    std::copy(pose_of_f.begin(), pose_of_f.end(), h_pose_of_f);
+    std::fill(row_ptr, row_ptr + d.n_e + 1, 0);
+    std::fill(pose_ptr, pose_ptr + d.n_f + 1, 0);
     int max_runs = 0;
     for (int r = 0; r < n; ++r) {
         const int i = rows[r], t = P->res_type[i], l = P->res_lm[i];
@@ -1306,7 +1342,8 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
         fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[P->lm_anchor_pose[l]] : -1;
         uv[2 * r] = P->res_uv[2 * i]; uv[2 * r + 1] = P->res_uv[2 * i + 1];
         isg[r] = 1.0 / (P->res_sigma ? P->res_sigma[i] : 1.0);
-        if (P->inv_depth) { auv[2 * r] = P->lm_anchor_uv[2 * l]; auv[2 * r + 1] = P->lm_anchor_uv[2 * l + 1]; }
+        auv[2 * r] = P->inv_depth ? P->lm_anchor_uv[2 * l] : 0.0;
+        auv[2 * r + 1] = P->inv_depth ? P->lm_anchor_uv[2 * l + 1] : 0.0;
         row_ptr[eb[r] + 1]++;
     }
     for (int k = 0; k < d.n_e; ++k) row_ptr[k + 1] += row_ptr[k];
@@ -1319,24 +1356,18 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     if (max_runs > BA_MAX_RUNS)
         return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "a landmark is observed by %d free keyframes (max %d)", max_runs, BA_MAX_RUNS);
     S.wstride = max_runs + 1;
-    std::vector<int> pose_ptr(d.n_f + 1, 0), pose_ent;
     {
         for (int r = 0; r < n; ++r) { if (fk[r] >= 0) pose_ptr[fk[r] + 1]++; if (fa[r] >= 0) pose_ptr[fa[r] + 1]++; }
         for (int k = 0; k < d.n_f; ++k) pose_ptr[k + 1] += pose_ptr[k];
-        pose_ent.resize(pose_ptr[d.n_f]);
-        std::vector<int> pos(pose_ptr.begin(), pose_ptr.end() - 1);
+        if ((s = hcarve(c, S.arena_off, &pose_ent, &S.pose_ent, (size_t)pose_ptr[d.n_f])) != OV2_OK) return s;
+        std::vector<int> pos(pose_ptr, pose_ptr + d.n_f);
         for (int r = 0; r < n; ++r) {
             if (fk[r] >= 0) pose_ent[pos[fk[r]]++] = 2 * r;
             if (fa[r] >= 0) pose_ent[pos[fa[r]]++] = 2 * r + 1;
         }
     }
-    ov2_status s;
-#define UP(field, vec) if ((s = dupload(c, S.arena_off, &d.field, vec)) != OV2_OK) return s
-    UP(type, type); UP(pose, pose); UP(lm, lm); UP(anch, anch); UP(eb, eb); UP(fk, fk); UP(fa, fa);
-    UP(uv, uv); UP(inv_sigma, isg); UP(auv, auv); UP(row_ptr, row_ptr); UP(lm_of_e, lm_of_e); UP(pose_of_f, pose_of_f);
-#undef UP
-    if ((s = dupload(c, S.arena_off, &S.pose_ptr, pose_ptr)) != OV2_OK) return s;
-    if ((s = dupload(c, S.arena_off, &S.pose_ent, pose_ent)) != OV2_OK) return s;
+    OV2_HIP(c, hipMemcpyAsync((char *)c->ba_arena + up0, (const char *)c->ba_host + up0, S.arena_off - up0,
+                              hipMemcpyHostToDevice, c->stream));
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
     AL(res, 2 * (size_t)n); AL(Je, 2 * (size_t)e * n); AL(Jf, 24 * (size_t)n);
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
@@ -1370,8 +1401,12 @@ ov2_status eval_jacobian(ba_solver &S, int use_loss, bool first)
     ov2_ctx *c = S.c;
     ba_dev &d = S.d;
     hipStream_t st = c->stream;
-    BA_LAUNCH(S, K_EVAL, ba_eval_kernel<true>, dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
-              S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
+    if (d.e == 1)
+        BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
+                  S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
+    else
+        BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
+                  S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
     BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_COST, 1.0);
     auto colnorm = [&]() {
         BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d);
@@ -1436,9 +1471,17 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
     OV2_HIP(c, hipMemcpyAsync(S.cl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
 
     double sc[SC_N];
+    const bool trc0 = getenv("OV2_BA_TRACE") != nullptr;
+    const auto tz0 = std::chrono::steady_clock::now();
     // IterationZero
     if ((s = eval_jacobian(S, use_loss, true)) != OV2_OK) return s;
+    const auto tz1 = std::chrono::steady_clock::now();
     if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+    const auto tz2 = std::chrono::steady_clock::now();
+    if (trc0)
+        fprintf(stderr, "   [minimize] iteration zero: enqueue %.3f ms, sync %.3f ms\n",
+                std::chrono::duration<double, std::milli>(tz1 - tz0).count(),
+                std::chrono::duration<double, std::milli>(tz2 - tz1).count());
     double x_cost = sc[SC_COST];
     // gradient max norm: landmarks from the device, poses via Plus on the host (n_f is small)
     auto grad_max = [&](double lm_part, double *out) -> ov2_status {
@@ -1472,6 +1515,12 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
         if (last_ok && gmax <= o->gradient_tolerance) { *termination = OV2_BA_TERM_GTOL; break; }
         if (radius <= o->min_radius) { *termination = OV2_BA_TERM_MIN_RADIUS; break; }
         ++iteration;
+        const bool trc = getenv("OV2_BA_TRACE") != nullptr;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto ta = tnow();
         // ---- ComputeTrustRegionStep + candidate evaluation, all enqueued, one sync
         BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, reuse_diagonal ? 0 : 1,
                   o->min_lm_diagonal, o->max_lm_diagonal, radius);
@@ -1491,16 +1540,18 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             if (e == 1) BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<1>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
             else BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<3>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
         }
+        const auto tb = tnow();
         if (d.m > 0) {
             // panel width by LDS budget: (m+1) x (NB+1) + NB x 32 doubles <= 150 KiB
             const size_t lds32 = ((size_t)(d.m + 1) * 33 + 32 * 64 + 4) * 8, lds16 = ((size_t)(d.m + 1) * 17 + 16 * 64 + 4) * 8,
                          lds8 = ((size_t)(d.m + 1) * 9 + 8 * 64 + 4) * 8;
-            if (lds32 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(1024), lds32, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(1024), lds16, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(1024), lds8, st, d.S, d.rhs, d.m, d.flags);
+            if (lds32 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(CHOL_THREADS), lds32, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(CHOL_THREADS), lds16, st, d.S, d.rhs, d.m, d.flags);
+            else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(CHOL_THREADS), lds8, st, d.S, d.rhs, d.m, d.flags);
             else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", d.m);
             BA_LAUNCH(S, K_MISC, ba_zstep_kernel, dim3((d.m + 255) / 256), dim3(256), 0, st, d);
         }
+        const auto tc = tnow();
         if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
         else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
         BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, d.n_e, d.scal + SC_MODEL, -1.0);
@@ -1510,12 +1561,22 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
                   o->jacobi_scaling ? 1 : 0, part_step, part_norm);
         BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_step, nb, d.scal + SC_STEP2, 1.0);
         BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_norm, nb, d.scal + SC_XNORM2, 1.0);
-        BA_LAUNCH(S, K_EVAL, ba_eval_kernel<false>, dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
-                  o->huber_delta, 0, d.part);
+        if (e == 1)
+            BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
+                      o->huber_delta, 0, d.part);
+        else
+            BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
+                      o->huber_delta, 0, d.part);
         BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_CAND_COST, 1.0);
         int h_flags[1];
         OV2_HIP(c, hipMemcpyAsync(h_flags, d.flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        const auto tq0 = std::chrono::steady_clock::now();
+        if (trc) fprintf(stderr, "   [minimize] it %d enqueue: lmdiag+sinit+schur %.3f | chol+zstep %.3f | rest %.3f ms\n", iteration,
+                         tms(ta, tb), tms(tb, tc), tms(tc, tq0));
         if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+        if (getenv("OV2_BA_TRACE"))
+            fprintf(stderr, "   [minimize] it %d: step+candidate sync %.3f ms\n", iteration,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
         const double model_change = sc[SC_MODEL], cand_cost = sc[SC_CAND_COST];
         const bool finite = !h_flags[0] && std::isfinite(model_change) && std::isfinite(sc[SC_STEP2]);
         const bool valid = finite && model_change > 0.0;
@@ -1543,8 +1604,12 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, np * sizeof(double), hipMemcpyDeviceToDevice, st));
             OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, nl * sizeof(double), hipMemcpyDeviceToDevice, st));
             x_norm = std::sqrt(sc[SC_XNORM2]);
+            const auto tq1 = std::chrono::steady_clock::now();
             if ((s = eval_jacobian(S, use_loss, false)) != OV2_OK) return s;
             if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
+            if (getenv("OV2_BA_TRACE"))
+                fprintf(stderr, "   [minimize] it %d: jacobian enqueue+sync %.3f ms\n", iteration,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
             x_cost = sc[SC_COST];
             if ((s = grad_max(sc[SC_GMAX_LM], &gmax)) != OV2_OK) return s;
             radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
@@ -1709,26 +1774,54 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
             if (he != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena hipMalloc(%zu): %s", want, hipGetErrorString(he));
             c->ba_arena_cap = want;
         }
+        // pinned mirror of the uploaded head of the arena: per row 69 B of records + 8 B of pose-CSR entries
+        const size_t hneed = n * 128 + (L + (size_t)P->n_pose) * 64 + (1u << 20);
+        if (hneed > c->ba_host_cap) {
+            OV2_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->ba_host) OV2_HIP(c, hipHostFree(c->ba_host));
+            c->ba_host = nullptr; c->ba_host_cap = 0;
+            const size_t want = hneed + hneed / 4;
+            hipError_t he = hipHostMalloc(&c->ba_host, want, hipHostMallocDefault);
+            if (he != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA pinned mirror hipHostMalloc(%zu): %s", want, hipGetErrorString(he));
+            c->ba_host_cap = want;
+        }
     }
+    // OV2_BA_TRACE=1: host-side wall time of the phases on stderr (diagnostics)
+    static const bool trace = getenv("OV2_BA_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     ov2_status s = build_program(S, active);
     if (s != OV2_OK) return s;
+    const auto t1 = now();
     s = minimize(S, active, use_loss, o->max_iters, R, &R->initial_cost, &R->final_cost, &R->termination);
     if (s != OV2_OK) return s;
+    const auto t2 = now();
     R->n_log_robust = R->n_log;
     int nbad, nl, nr;
     if ((s = flag_outliers(S, active, R, 1, &nbad, &nl, &nr)) != OV2_OK) return s;
     R->n_outliers_pass1 = nbad;
+    const auto t3 = now();
+    auto t4 = t3, t5 = t3, t6 = t3;
     if (o->l2_refine && use_loss && nbad > 0) {
         const int keep_loss = !(nl > 0 && nr > 0);   // src/optimizer.cpp:606-608
         OV2_HIP(c, hipStreamSynchronize(c->stream));
         S.arena_off = 0;                                   // re-carve the arena for the reduced program
         if ((s = build_program(S, active)) != OV2_OK) return s;
+        t4 = now();
         s = minimize(S, active, keep_loss, o->l2_max_iters, R, &R->l2_initial_cost, &R->l2_final_cost, &R->l2_termination);
         if (s != OV2_OK) return s;
+        t5 = now();
         R->l2_done = 1;
         if ((s = flag_outliers(S, active, R, 2, &nbad, &nl, &nr)) != OV2_OK) return s;
         R->n_outliers_pass2 = nbad;
+        t6 = now();
     }
+    if (trace)
+        fprintf(stderr, "[ov2_ba_solve] build %.2f | minimize %.2f (%d log) | flag %.2f | rebuild %.2f | minimize %.2f (%d log) | flag %.2f ms\n",
+                ms(t0, t1), ms(t1, t2), R->n_log_robust, ms(t2, t3), ms(t3, t4), ms(t4, t5), R->n_log - R->n_log_robust, ms(t5, t6));
     // write back the non-constant blocks ("parameters_")
     memcpy(P->pose, S.h_pose.data(), sizeof(double) * (size_t)P->n_pose * 7);
     memcpy(P->lm, S.h_lm.data(), sizeof(double) * (size_t)P->n_lm * e);

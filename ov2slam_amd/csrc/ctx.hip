@@ -48,6 +48,8 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->ktime_on = false;
     c->ba_arena = nullptr;
     c->ba_arena_cap = 0;
+    c->ba_host = nullptr;
+    c->ba_host_cap = 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
@@ -78,6 +80,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     for (auto e : c->ktime_free) (void)hipEventDestroy(e);
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     if (c->ba_arena) (void)hipFree(c->ba_arena);
+    if (c->ba_host) (void)hipHostFree(c->ba_host);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);

@@ -73,6 +73,8 @@ struct ov2_ctx {
     ov2_images *tmp_img;                 // staging image for ov2_pyramid_build(host img)
     void *ba_arena;                      // device arena of ov2_ba_solve, grown on demand, kept across solves
     size_t ba_arena_cap;
+    void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
+    size_t ba_host_cap;
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
     bool ktime_on;
     std::vector<ov2_ktime_rec> ktime_recs;   // recorded (kernel id, event pair) since the last report
