@@ -1267,7 +1267,9 @@ struct ba_solver {
 
 #define BA_LAUNCH(S, id, ...) OV2_LAUNCH((S).c, id, __VA_ARGS__)
 
-ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
+// reuse_order: the rows of the previous program, filtered by `active`, are already in (landmark block, pose block) order
+// (block numbers are order-preserving renumberings), so the L2 re-solve skips validation and sorting
+ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active, bool reuse_order = false)
 {
     ov2_ctx *c = S.c;
     const ov2_ba_problem *P = S.P;
@@ -1279,21 +1281,31 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     pose_Rt(P->T_rl, d.Rrl, d.trl);
     // reduced program (program.cc RemoveFixedBlocks): unused / constant blocks leave
     std::vector<int> eidx(P->n_lm, -1), fidx(P->n_pose, -1), rows;
-    for (int i = 0; i < P->n_res; ++i) {
-        if (!active[i]) continue;
+    auto mark = [&](int i) {
         const int t = P->res_type[i], l = P->res_lm[i];
-        if (l < 0 || l >= P->n_lm) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: landmark %d out of range", i, l);
-        if (t > OV2_BA_RANCH_INV) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: unknown type %d", i, t);
-        if ((t >= OV2_BA_L_INV) != (P->inv_depth != 0))
-            return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: type %d does not match inv_depth=%d", i, t, P->inv_depth);
-        if (t != OV2_BA_RANCH_INV && (P->res_pose[i] < 0 || P->res_pose[i] >= P->n_pose))
-            return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: pose out of range", i);
-        if (P->inv_depth && (P->lm_anchor_pose[l] < 0 || P->lm_anchor_pose[l] >= P->n_pose))
-            return ov2_set_err(c, OV2_ERR_INVALID, "landmark %d: anchor pose out of range", l);
         rows.push_back(i);
         eidx[l] = 0;
         if (t != OV2_BA_RANCH_INV && !P->pose_const[P->res_pose[i]]) fidx[P->res_pose[i]] = 0;
         if ((t == OV2_BA_L_INV || t == OV2_BA_R_INV) && !P->pose_const[P->lm_anchor_pose[l]]) fidx[P->lm_anchor_pose[l]] = 0;
+    };
+    if (reuse_order) {
+        rows.reserve(S.order.size());
+        for (int i : S.order) if (active[i]) mark(i);
+    } else {
+        rows.reserve(P->n_res);
+        for (int i = 0; i < P->n_res; ++i) {
+            if (!active[i]) continue;
+            const int t = P->res_type[i], l = P->res_lm[i];
+            if (l < 0 || l >= P->n_lm) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: landmark %d out of range", i, l);
+            if (t > OV2_BA_RANCH_INV) return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: unknown type %d", i, t);
+            if ((t >= OV2_BA_L_INV) != (P->inv_depth != 0))
+                return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: type %d does not match inv_depth=%d", i, t, P->inv_depth);
+            if (t != OV2_BA_RANCH_INV && (P->res_pose[i] < 0 || P->res_pose[i] >= P->n_pose))
+                return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: pose out of range", i);
+            if (P->inv_depth && (P->lm_anchor_pose[l] < 0 || P->lm_anchor_pose[l] >= P->n_pose))
+                return ov2_set_err(c, OV2_ERR_INVALID, "landmark %d: anchor pose out of range", l);
+            mark(i);
+        }
     }
     std::vector<int> lm_of_e, pose_of_f;
     for (int l = 0; l < P->n_lm; ++l) if (eidx[l] == 0) { eidx[l] = (int)lm_of_e.size(); lm_of_e.push_back(l); }
@@ -1303,15 +1315,21 @@ ov2_status build_program(ba_solver &S, const std::vector<uint8_t> &active)
     d.n_rows = (int)rows.size(); d.n_pose = P->n_pose; d.n_lm = P->n_lm;
     d.m = 6 * d.n_f; d.nc = d.n_e * e + d.m;
     // rows sorted by (landmark block, observing pose) -- LexicographicallyOrderResidualBlocks + run aggregation
-    {
+    if (!reuse_order) {
         std::vector<int> cnt(d.n_e + 1, 0), sorted(rows.size());
         for (int i : rows) cnt[eidx[P->res_lm[i]] + 1]++;
         for (int k = 0; k < d.n_e; ++k) cnt[k + 1] += cnt[k];
         std::vector<int> pos(cnt.begin(), cnt.end() - 1);
         for (int i : rows) sorted[pos[eidx[P->res_lm[i]]]++] = i;          // stable counting sort by landmark block
         auto fkey = [&](int i) { return (P->res_type[i] == OV2_BA_RANCH_INV) ? -1 : fidx[P->res_pose[i]]; };
-        for (int k = 0; k < d.n_e; ++k)                                    // a handful of rows per landmark
-            std::stable_sort(sorted.begin() + cnt[k], sorted.begin() + cnt[k + 1], [&](int a, int b) { return fkey(a) < fkey(b); });
+        for (int k = 0; k < d.n_e; ++k) {                                  // a handful of rows per landmark: insertion sort
+            for (int a = cnt[k] + 1; a < cnt[k + 1]; ++a) {
+                const int v = sorted[a], kv = fkey(v);
+                int b = a - 1;
+                while (b >= cnt[k] && fkey(sorted[b]) > kv) { sorted[b + 1] = sorted[b]; --b; }
+                sorted[b + 1] = v;
+            }
+        }
         rows.swap(sorted);
     }
     S.order = rows;
@@ -1809,7 +1827,7 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
         const int keep_loss = !(nl > 0 && nr > 0);   // src/optimizer.cpp:606-608
         OV2_HIP(c, hipStreamSynchronize(c->stream));
         S.arena_off = 0;                                   // re-carve the arena for the reduced program
-        if ((s = build_program(S, active)) != OV2_OK) return s;
+        if ((s = build_program(S, active, true)) != OV2_OK) return s;
         t4 = now();
         s = minimize(S, active, keep_loss, o->l2_max_iters, R, &R->l2_initial_cost, &R->l2_final_cost, &R->l2_termination);
         if (s != OV2_OK) return s;
