@@ -87,6 +87,18 @@ def test_local_ba_edge_cases(ctx, oracle):
         local_ba.Optimizer(ctx).localBA(B)
 
 
+def test_local_ba_multi_workgroup_cholesky_ragged(ctx, oracle):
+    """68 keyframes: the reduced camera system (m = 6 x free poses >= 320) takes the right-looking multi-workgroup
+    Cholesky (MFMA trailing updates) with a ragged last panel and ragged 16 x 16 tiles."""
+    P = synth_ba.make_window(68, 5000, inv_depth=True, seed=61, max_obs=7)
+    m = 6 * int((P.pose_const == 0).sum())
+    assert m >= 320 and m % 32 != 0 and m % 16 != 0
+    Pc = P.copy()
+    Rg = local_ba.Optimizer(ctx).localBA(P)
+    Rc = oracle.ba_solve(Pc)
+    _compare(P, Rg, Pc, Rc, flags_exact=False)
+
+
 @pytest.mark.parametrize("inv_depth", [True, False])
 def test_local_ba_config4_window(ctx, oracle, inv_depth):
     """BASELINE config 4 size: 100 KFs / 20 k landmarks (~240 k residual blocks), parity at full size."""
