@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-ba", action="store_true", help="front-end only (no concurrent localBA worker)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) for the real multi-GPU run; gloo rehearses the N > 1 control flow with "
+                         "several ranks sharing one GPU")
     return ap.parse_args()
 
 
@@ -242,9 +245,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if a.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()   # rehearsal: ranks share the GPUs that exist
     torch.cuda.set_device(local)
     from ov2slam_amd import dist_util
-    dist_util.init_from_env("nccl", torch.device("cuda", local))   # nccl == RCCL on ROCm
+    dist_util.init_from_env(a.dist_backend, torch.device("cuda", local))   # nccl == RCCL on ROCm
 
     def barrier():
         if world > 1:
@@ -294,7 +299,8 @@ def main():
 
     # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
     el_max, cnt = dist_util.aggregate(el, [a.steps * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
-                                           ba.submitted if ba else 0, ba.dropped if ba else 0], device="cuda")
+                                           ba.submitted if ba else 0, ba.dropped if ba else 0],
+                                       device="cuda" if a.dist_backend == "nccl" else "cpu")
     frames_all, ba_iters_all, ba_solves_all, ba_sub_all, ba_drop_all = cnt
 
     out = {
@@ -386,13 +392,14 @@ def main():
         out["kernels"] = rl
         out["ms_per_step_instrumented"] = 1e3 * el_instr / a.steps
 
-    if rank == 0 and not a.no_cpu_baseline:
+    do_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline   # the CPU leg is reported at N = 1 only
+    if do_cpu:
         fps, nfr, sec = cpu_baseline(wl, a.kf_every, a.cpu_seconds)
         out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"{nfr} frames of one sequence of the same workload ({sec:.1f} s), "
                                          "oracle/ C port of the OpenCV path, 1 thread; host has "
                                          f"{os.cpu_count()} logical cores"}
-    if rank == 0 and ba and not a.no_cpu_baseline:
+    if do_cpu and ba:
         from oracle import oracle_py as O
         Pc = ba.P0.copy()
         t1 = time.perf_counter()
