@@ -129,14 +129,15 @@ class Workload:
         self.det_cur = [base[rng.uniform(size=len(base)) < 0.85] for _ in range(seqs)]
         self.det_thresh = np.full(seqs, 0.001, np.float64)
         self.n_detected = 0
-        # pre-marshalled arguments of ov2_detect_grid_batch (the bench must time the library, not numpy glue)
-        import ctypes as C
-        self._C = C
-        self.det_ncur = np.ascontiguousarray([len(c) for c in self.det_cur], np.int32)
-        self.det_curcat = np.ascontiguousarray(np.concatenate(self.det_cur), np.float32)
+        # keyframe detection runs device-resident (ov2_detect_grid_batch_dev): thresholds, existing keypoints, counts and
+        # new corners live in HBM, so a keyframe costs no host synchronisation
+        self.det_ncur = int(sum(len(c) for c in self.det_cur))
+        self.d_det_cur = ctx.to_device(np.ascontiguousarray(np.concatenate(self.det_cur), np.float32))
+        self.d_det_img = ctx.to_device(np.concatenate([np.full(len(c), b, np.int32) for b, c in enumerate(self.det_cur)]))
         self.det_cap = max(1, (W // self.det_cell) * (H // self.det_cell)) * 2
-        self.det_out = np.zeros((seqs, self.det_cap, 2), np.float32)
-        self.det_nout = np.zeros(seqs, np.int32)
+        self.d_det_thresh = ctx.to_device(self.det_thresh)
+        self.d_det_out = ctx.empty((seqs, self.det_cap, 2), np.float32)
+        self.d_det_nout = ctx.empty((seqs,), np.int32)
 
     detect = True
 
@@ -156,16 +157,8 @@ class Workload:
                                      self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, None)
             rp.release()
             if self.detect:                                                           # 1.FE_createKeyframe (detector)
-                C = self._C
-                st = ctx.lib.ov2_detect_grid_batch(ctx.h, cur.h, self.det_cell, 1,
-                                                   self.det_thresh.ctypes.data_as(C.POINTER(C.c_double)),
-                                                   self.det_ncur.ctypes.data_as(C.POINTER(C.c_int)),
-                                                   self.det_curcat.ctypes.data_as(C.c_void_p), None, 1,
-                                                   self.det_nout.ctypes.data_as(C.POINTER(C.c_int)),
-                                                   self.det_out.ctypes.data_as(C.c_void_p), self.det_cap)
-                if st != 0:
-                    raise RuntimeError(ctx.lib.ov2_last_error(ctx.h).decode())
-                self.n_detected += int(self.det_nout.sum())
+                fe.detect_grid_batch_dev(ctx, cur, self.det_cell, 1, self.d_det_thresh, self.det_ncur, self.d_det_cur,
+                                         self.d_det_img, None, self.d_det_nout, self.d_det_out, self.det_cap)
         self.step_no += 1
         return is_kf
 

@@ -144,6 +144,16 @@ ov2_status ov2_detect_grid(ov2_ctx *ctx, const ov2_pyr *pyr, int b, int cell, in
 ov2_status ov2_detect_grid_batch(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, int mode, double *thresh,
                                  const int *n_cur, const float *cur_xy, const int *roi, int do_subpix, int *n_out,
                                  float *out_xy, int out_cap);
+/* Device-resident, fully asynchronous form of the same call (no host synchronisation: a multi-sequence front-end can
+ * enqueue the next frames while keyframe detection runs).  All d_* pointers are DEVICE pointers:
+ *   d_thresh   B doubles, in/out (dmaxquality_ / nfast_th_ per image, adapted on the device)
+ *   n_cur keypoints of all images: d_cur_xy (n_cur x 2 floats), d_cur_img (image index per keypoint),
+ *   d_cur_valid (optional, n_cur bytes: only keypoints with a non-zero byte count, e.g. the tracking status)
+ *   d_n_out    B ints, d_out_xy  B x out_cap x 2 floats (out_cap >= 2 * cells)
+ * roi is a host pointer (4 ints or NULL). */
+ov2_status ov2_detect_grid_batch_dev(ov2_ctx *ctx, const ov2_pyr *pyr, int cell, int mode, double *d_thresh, int n_cur,
+                                     const float *d_cur_xy, const int32_t *d_cur_img, const uint8_t *d_cur_valid,
+                                     const int *roi, int do_subpix, int32_t *d_n_out, float *d_out_xy, int out_cap);
 
 /* ---- local bundle adjustment ------------------------------------------------------------------- */
 /* Flat, POD restatement of the ceres::Problem that Optimizer::localBA assembles (src/optimizer.cpp:76-392).

@@ -52,6 +52,7 @@ SIGNATURES = {
                                              C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ov2_detect_grid": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp, vp, C.c_int, ip, vp]),
     "ov2_detect_grid_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), ip, vp, vp, C.c_int, ip, vp, C.c_int]),
+    "ov2_detect_grid_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]),
     "ov2_ba_default_options": (None, [vp, C.c_float]),
     "ov2_ba_solve": (C.c_int, [vp, vp, vp, vp]),
     "ov2_pnp_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,

@@ -50,6 +50,8 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->ba_arena_cap = 0;
     c->ba_host = nullptr;
     c->ba_host_cap = 0;
+    c->stage_host = c->stage_dev = nullptr;
+    c->stage_cap = 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
@@ -81,6 +83,8 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     if (c->ba_arena) (void)hipFree(c->ba_arena);
     if (c->ba_host) (void)hipHostFree(c->ba_host);
+    if (c->stage_host) (void)hipHostFree(c->stage_host);
+    if (c->stage_dev) (void)hipFree(c->stage_dev);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -160,6 +164,24 @@ ov2_status ov2_scratch(ov2_ctx *c, size_t bytes, void **out)
     return OV2_OK;
 }
 
+ov2_status ov2_staging(ov2_ctx *c, size_t bytes, void **host, void **dev)
+{
+    if (bytes > c->stage_cap) {
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->stage_host) OV2_HIP(c, hipHostFree(c->stage_host));
+        if (c->stage_dev) OV2_HIP(c, hipFree(c->stage_dev));
+        c->stage_host = c->stage_dev = nullptr;
+        c->stage_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&c->stage_host, want, hipHostMallocDefault) != hipSuccess || hipMalloc(&c->stage_dev, want) != hipSuccess)
+            return ov2_set_err(c, OV2_ERR_NOMEM, "staging allocation of %zu bytes", want);
+        c->stage_cap = want;
+    }
+    *host = c->stage_host;
+    *dev = c->stage_dev;
+    return OV2_OK;
+}
+
 // ---- images ---------------------------------------------------------------------------------------
 
 extern "C" ov2_status ov2_images_create(ov2_ctx *c, int batch, int w, int h, ov2_images **out)
@@ -207,7 +229,8 @@ const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", 
                                            "ba_sinit_kernel", "ba_schur_kernel", "ba_chol_kernel", "ba_backsub_kernel",
                                            "ba_plus_kernel", "ba_flag_kernel", "ba_reduce_kernel", "ba_misc_kernels",
                                            nullptr, nullptr, "detect_cell_kernels", "detect_mask_kernel", "subpix_kernel",
-                                           "pnp_kernel", "klt_compact_kernel"};
+                                           "pnp_kernel", "klt_compact_kernel",
+                                           "detect_list_kernels"};
 
 static hipEvent_t ktime_event(ov2_ctx *c)
 {

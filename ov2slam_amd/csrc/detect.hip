@@ -69,18 +69,84 @@ __device__ __forceinline__ void draw_disc(unsigned char *mask, int w, int h, int
     }
 }
 
+// existing keypoints: occupancy of their grid cell (voccupcells, :316-320 / :466-470) + their discs in the mask.
+// One wave per keypoint; `valid` (optional) marks the keypoints that count (e.g. the tracking status).
 __global__ __launch_bounds__(64) void det_mask_kernel(const float2 *__restrict__ cur, const int *__restrict__ cur_img,
-                                                      int n_cur, int cell, int nwcells, int nhcells,
-                                                      unsigned char *__restrict__ occ_all,
+                                                      const unsigned char *__restrict__ valid, int n_cur, int cell,
+                                                      int nwcells, int nhcells, unsigned char *__restrict__ occ_all,
                                                       unsigned char *__restrict__ mask_all, int w, int h, disc_shape ds)
 {
-    const int k = blockIdx.x;
-    if (k >= n_cur) return;
-    const float2 p = cur[k];
-    const int bimg = cur_img[k];
-    unsigned char *mask = mask_all + (size_t)bimg * w * h;
-    (void)occ_all; (void)cell; (void)nwcells; (void)nhcells;   // occupancy is computed by the host
-    draw_disc(mask, w, h, (int)__builtin_rintf(p.x), (int)__builtin_rintf(p.y), ds);
+    for (int k = blockIdx.x; k < n_cur; k += gridDim.x) {
+        if (valid && !valid[k]) continue;
+        const float2 p = cur[k];
+        const int bimg = cur_img[k];
+        if (threadIdx.x == 0) {
+            const int cr = (int)(p.y / (float)cell), cc = (int)(p.x / (float)cell);
+            if (cr >= 0 && cr <= nhcells && cc >= 0 && cc <= nwcells)
+                occ_all[(size_t)bimg * (nhcells + 1) * (nwcells + 1) + cr * (nwcells + 1) + cc] = 1;
+        }
+        draw_disc(mask_all + (size_t)bimg * w * h, w, h, (int)__builtin_rintf(p.x), (int)__builtin_rintf(p.y), ds);
+    }
+}
+
+// block-wide exclusive prefix of one flag per thread (256 threads); returns the rank, *total = count of the block
+__device__ __forceinline__ int block_rank_256(bool flag, int *sh4, int *total)
+{
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sh4[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += sh4[k];
+    *total = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    __syncthreads();
+    return off + rank;
+}
+
+// one workgroup per image: the free, border-valid cells (:338-350) of each colour are appended to the four global
+// work lists (one atomic per image and colour reserves the range; the order inside a colour is irrelevant)
+__global__ __launch_bounds__(256) void det_worklist_kernel(int cell, int nwcells, int nhcells, int w, int h,
+                                                           const unsigned char *__restrict__ occ_all,
+                                                           int2 *__restrict__ work /* 4 lists of list_cap */, int list_cap,
+                                                           unsigned *__restrict__ wcount /* [4] */)
+{
+    __shared__ int sh4[4];
+    __shared__ int base[4];
+    const int b = blockIdx.x, nb = nwcells * nhcells, tid = threadIdx.x;
+    const unsigned char *occ = occ_all + (size_t)b * (nhcells + 1) * (nwcells + 1);
+    for (int colour = 0; colour < 4; ++colour) {
+        int done = 0;   // cells of this colour already placed (block-uniform)
+        // pass 1: count, pass 2: place -- two passes keep the reservation to one atomic per (image, colour)
+        int cnt = 0;
+        for (int i0 = 0; i0 < nb; i0 += 256) {
+            const int i = i0 + tid;
+            bool f = false;
+            if (i < nb) {
+                const int rr = i / nwcells, cc = i - rr * nwcells;
+                f = ((rr & 1) * 2 + (cc & 1)) == colour && !occ[rr * (nwcells + 1) + cc] &&
+                    (cc * cell + cell < w - 1 && rr * cell + cell < h - 1);
+            }
+            int tot;
+            (void)block_rank_256(f, sh4, &tot);
+            cnt += tot;
+        }
+        if (tid == 0) base[colour] = cnt ? (int)atomicAdd(&wcount[colour], (unsigned)cnt) : 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < nb; i0 += 256) {
+            const int i = i0 + tid;
+            bool f = false;
+            if (i < nb) {
+                const int rr = i / nwcells, cc = i - rr * nwcells;
+                f = ((rr & 1) * 2 + (cc & 1)) == colour && !occ[rr * (nwcells + 1) + cc] &&
+                    (cc * cell + cell < w - 1 && rr * cell + cell < h - 1);
+            }
+            int tot;
+            const int rank = block_rank_256(f, sh4, &tot);
+            if (f) work[(size_t)colour * list_cap + base[colour] + done + rank] = make_int2(b, i);
+            done += tot;
+        }
+    }
 }
 
 // ordered key: larger value wins, on ties the smaller index (cv::minMaxLoc returns the first maximum)
@@ -140,13 +206,15 @@ __device__ __forceinline__ void draw_disc_both(unsigned char *mask, int w, int h
 __global__ __launch_bounds__(256) void det_mineig_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                          int istride, int w, int h, int cell, int nwcells, int nhcells,
                                                          const int2 *__restrict__ work /* (image, cell) of this colour */,
+                                                         const unsigned *__restrict__ work_count,
                                                          unsigned char *__restrict__ mask_all, disc_shape ds, int rx,
                                                          int ry, int rw, int rh, const double *__restrict__ quality_all,
                                                          det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
-    const int2 item = work[blockIdx.x];   // free, border-valid cells only (the host did :338-350)
+    if (blockIdx.x >= *work_count) return;   // the grid is an upper bound; the list length lives on the device
+    const int2 item = work[blockIdx.x];   // free, border-valid cells only (det_worklist_kernel did :338-350)
     const int bimg = item.x, i = item.y;
     const unsigned char *img = img0 + img_bstride * bimg;
     unsigned char *mask = mask_all + (size_t)bimg * w * h;
@@ -282,12 +350,14 @@ __device__ inline int fast_score(const unsigned char *p, int stride, int thresho
 __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
                                                        int istride, int w, int h, int cell, int nwcells, int nhcells,
                                                        const int2 *__restrict__ work,
+                                                       const unsigned *__restrict__ work_count,
                                                        unsigned char *__restrict__ mask_all, disc_shape ds,
                                                        const double *__restrict__ thresh_all,
                                                        det_out *__restrict__ out_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long shk[4];
+    if (blockIdx.x >= *work_count) return;
     const int2 item = work[blockIdx.x];
     const int bimg = item.x, i = item.y;
     const unsigned char *img = img0 + img_bstride * bimg;
@@ -332,6 +402,66 @@ __global__ __launch_bounds__(256) void det_fast_kernel(const unsigned char *__re
     }
 }
 
+// one workgroup per image: candidates in cell order (:393-412 / :532-538), the second candidates of detectSingleScale
+// up to the number of still empty cells, the adaptive threshold (:418-423 / :546-552), and the image's points appended
+// to the global list cornerSubPix walks (order across images irrelevant).
+__global__ __launch_bounds__(256) void det_assemble_kernel(int mode, int nwcells, int nhcells,
+                                                           const unsigned char *__restrict__ occ_all,
+                                                           const det_out *__restrict__ out_all, double *__restrict__ thresh,
+                                                           int *__restrict__ n_out, float2 *__restrict__ out_xy, int out_cap,
+                                                           int *__restrict__ pt_ref, int *__restrict__ pt_img,
+                                                           unsigned *__restrict__ npts)
+{
+    __shared__ int sh4[4];
+    __shared__ int gbase;
+    const int b = blockIdx.x, nb = nwcells * nhcells, tid = threadIdx.x;
+    const unsigned char *occ = occ_all + (size_t)b * (nhcells + 1) * (nwcells + 1);
+    const det_out *ho = out_all + (size_t)b * nb;
+    float2 *o = out_xy + (size_t)b * out_cap;
+    int n = 0, nboccup = 0;
+    for (int i0 = 0; i0 < nb; i0 += 256) {
+        const int i = i0 + tid;
+        const bool f = i < nb && ho[i].has_first;
+        bool oc = false;
+        if (i < nb) { const int rr = i / nwcells, cc = i - rr * nwcells; oc = occ[rr * (nwcells + 1) + cc] != 0; }
+        int tot, toc;
+        const int rank = block_rank_256(f, sh4, &tot);
+        (void)block_rank_256(oc, sh4, &toc);
+        if (f) o[n + rank] = make_float2(ho[i].fx, ho[i].fy);
+        n += tot; nboccup += toc;
+    }
+    const int nbempty = nb - nboccup;
+    double th = thresh[b];
+    if (mode == OV2_DETECT_MINEIG) {
+        if (n + nboccup < nb) {
+            const int nbsec = nb - (n + nboccup);
+            int k = 0;
+            for (int i0 = 0; i0 < nb && k < nbsec; i0 += 256) {
+                const int i = i0 + tid;
+                const bool f = i < nb && ho[i].has_second;
+                int tot;
+                const int rank = block_rank_256(f, sh4, &tot);
+                if (f && k + rank < nbsec) o[n + k + rank] = make_float2(ho[i].sx, ho[i].sy);
+                k += tot;
+            }
+            n += min(k, nbsec);
+        }
+        if ((double)n < 0.33 * (double)(nb - nboccup)) th /= 2.;
+        else if ((double)n > 0.9 * (double)(nb - nboccup)) th *= 1.5;
+    } else {
+        const int cur_th = (int)th;
+        if ((double)n < 0.5 * (double)nbempty && nbempty > 10) th = (double)(int)((double)cur_th * 0.66);
+        else if (n == nbempty) th = (double)(int)((double)cur_th * 1.5);
+    }
+    if (tid == 0) {
+        thresh[b] = th;
+        n_out[b] = n;
+        gbase = n ? (int)atomicAdd(npts, (unsigned)n) : 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) { pt_ref[gbase + k] = b * out_cap + k; pt_img[gbase + k] = b; }
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -359,10 +489,13 @@ __device__ __forceinline__ double row_tree_f64(double v)
 // and every lane of the row solves the 2x2 system, so the scalar work of an iteration is shared by four points.
 template <int HW>
 __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restrict__ img0, size_t img_bstride,
-                                                    const int *__restrict__ pt_img, int istride, int w, int h, int n,
+                                                    const int *__restrict__ pt_img, const int *__restrict__ pt_ref,
+                                                    const unsigned *__restrict__ npts, int istride, int w, int h,
                                                     float2 *__restrict__ pts, int max_iter, double eps2,
                                                     const float *__restrict__ wmask)
 {
+    const int n = (int)*npts;                       // the grid is an upper bound; the point count lives on the device
+    if ((int)blockIdx.x * 4 >= n) return;
     constexpr int WIN = 2 * HW + 1, BW = WIN + 2, SW = BW + 1, NT = WIN * WIN, NK = (NT + 15) / 16;
     __shared__ unsigned char src[4][(SW * SW + 3) & ~3];
     __shared__ float buf[4][BW * BW];
@@ -371,7 +504,8 @@ __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restr
     const bool act = p < n;
     const int pp = act ? p : n - 1;
     const unsigned char *img = img0 + img_bstride * pt_img[pp];
-    const float cTx = pts[pp].x, cTy = pts[pp].y;
+    const int ref = pt_ref[pp];                     // where the point lives in the per-image output array
+    const float cTx = pts[ref].x, cTy = pts[ref].y;
     float cIx = cTx, cIy = cTy;
     int iter = 0;
     bool go = act;
@@ -437,17 +571,23 @@ __global__ __launch_bounds__(64) void subpix_kernel(const unsigned char *__restr
         }
     }
     if (fabsf(cIx - cTx) > (float)HW || fabsf(cIy - cTy) > (float)HW) { cIx = cTx; cIy = cTy; }
-    if (act && sub == 0) pts[p] = make_float2(cIx, cIy);
+    if (act && sub == 0) pts[ref] = make_float2(cIx, cIy);
 }
 
 }  // namespace
 
-extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int cell, int mode, double *thresh,
-                                            const int *n_cur, const float *cur_xy, const int *roi, int do_subpix,
-                                            int *n_out, float *out_xy, int out_cap)
+// Everything on the device, nothing synchronous: mask + occupancy of the existing keypoints, per-colour work lists,
+// the four colour launches, assembly in cell order + threshold adaptation, cornerSubPix.  Work-list lengths and the
+// point count never visit the host: the dependent grids are upper bounds and their workgroups compare against the
+// device-side counters.
+extern "C" ov2_status ov2_detect_grid_batch_dev(ov2_ctx *c, const ov2_pyr *pyr, int cell, int mode, double *d_thresh,
+                                                int n_cur, const float *d_cur_xy, const int32_t *d_cur_img,
+                                                const uint8_t *d_cur_valid, const int *roi, int do_subpix,
+                                                int32_t *d_n_out, float *d_out_xy, int out_cap)
 {
     if (!c) return OV2_ERR_INVALID;
-    if (!pyr || !thresh || !n_out || !out_xy || !n_cur) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    if (!pyr || !d_thresh || !d_n_out || !d_out_xy || n_cur < 0) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    if (n_cur > 0 && (!d_cur_xy || !d_cur_img)) return ov2_set_err(c, OV2_ERR_INVALID, "null keypoint arrays");
     if (cell < 8 || cell > DET_MAX_CELL || cell / 4 > DET_MAX_R)
         return ov2_set_err(c, OV2_ERR_INVALID, "cell size %d unsupported (8..%d)", cell, DET_MAX_CELL);
     if (mode != OV2_DETECT_FAST && mode != OV2_DETECT_MINEIG) return ov2_set_err(c, OV2_ERR_INVALID, "mode %d", mode);
@@ -461,127 +601,54 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
     const int B = pyr->buf->batch, w = L.w, h = L.h;
     const unsigned char *img = v.base + L.img_off + (size_t)v.pad * L.istride + OV2_LM;
     const int nh = h / cell, nw = w / cell, nb = nh * nw;
-    for (int b = 0; b < B; ++b) n_out[b] = 0;
+    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemsetAsync(d_n_out, 0, sizeof(int) * B, st));
     if (nb == 0) return OV2_OK;
     if (out_cap < 2 * nb) return ov2_set_err(c, OV2_ERR_INVALID, "out_cap %d < 2 * cells (%d)", out_cap, 2 * nb);
-    int ncur_tot = 0;
-    for (int b = 0; b < B; ++b) {
-        if (n_cur[b] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative keypoint count");
-        ncur_tot += n_cur[b];
-    }
-    if (ncur_tot && !cur_xy) return ov2_set_err(c, OV2_ERR_INVALID, "null cur_xy");
     const int rx = roi ? roi[0] : 0, ry = roi ? roi[1] : 0, rw = roi ? roi[2] : w, rh = roi ? roi[3] : h;
-    // scratch: masks | occupancy | det_out[B][nb] | thresholds | cur kps + image ids | points + image ids | weights
+    // scratch: [counters | occupancy | det_out] zeroed per call, then masks | work lists | point refs | weights
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t occ_sz = (size_t)(nh + 1) * (nw + 1);
-    const size_t off_mask = 0, off_occ = up((size_t)w * h * B), off_out = off_occ + up(occ_sz * B);
-    const size_t off_th = off_out + up(sizeof(det_out) * nb * B), off_cur = off_th + up(sizeof(double) * B);
-    const size_t off_cimg = off_cur + up((size_t)ncur_tot * 8), off_pts = off_cimg + up((size_t)ncur_tot * 4);
-    const size_t off_pimg = off_pts + up((size_t)nb * 2 * 8 * B), off_wm = off_pimg + up((size_t)nb * 2 * 4 * B);
-    const size_t off_work = off_wm + 1024;
+    const int list_cap = ((nh + 1) / 2) * ((nw + 1) / 2) * B;           // cells of one colour, all images
+    const size_t off_cnt = 0, off_occ = 256, off_out = off_occ + up(occ_sz * B);
+    const size_t zero_bytes = off_out + up(sizeof(det_out) * nb * B);
+    const size_t off_mask = zero_bytes, off_work = off_mask + up((size_t)w * h * B);
+    const size_t off_ref = off_work + up(sizeof(int2) * 4 * (size_t)list_cap), off_pimg = off_ref + up(sizeof(int) * (size_t)nb * B);
+    const size_t off_wm = off_pimg + up(sizeof(int) * (size_t)nb * B), total = off_wm + 1024;
     void *scr = nullptr;
-    ov2_status s = ov2_scratch(c, off_work + sizeof(int2) * (size_t)nb * B + 256, &scr);
+    ov2_status s = ov2_scratch(c, total, &scr);
     if (s != OV2_OK) return s;
     char *base = (char *)scr;
-    unsigned char *mask = (unsigned char *)(base + off_mask), *occ = (unsigned char *)(base + off_occ);
+    unsigned *cnt = (unsigned *)(base + off_cnt);           // [0..3] work-list lengths, [4] number of points
+    unsigned char *occ = (unsigned char *)(base + off_occ), *mask = (unsigned char *)(base + off_mask);
     det_out *dout = (det_out *)(base + off_out);
-    double *dth = (double *)(base + off_th);
-    float2 *dcur = (float2 *)(base + off_cur), *dpts = (float2 *)(base + off_pts);
-    int *dcimg = (int *)(base + off_cimg), *dpimg = (int *)(base + off_pimg);
+    int2 *dwork = (int2 *)(base + off_work);
+    int *pt_ref = (int *)(base + off_ref), *pt_img = (int *)(base + off_pimg);
     float *dwm = (float *)(base + off_wm);
-    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemsetAsync(base, 0, zero_bytes, st));
     OV2_HIP(c, hipMemsetAsync(mask, 1, (size_t)w * h * B, st));
-    OV2_HIP(c, hipMemsetAsync(dout, 0, sizeof(det_out) * nb * B, st));
-    OV2_HIP(c, hipMemcpyAsync(dth, thresh, sizeof(double) * B, hipMemcpyHostToDevice, st));
     const disc_shape ds = make_disc(cell / 4);
-    std::vector<int> cimg(ncur_tot);
-    // occupancy (voccupcells, :316-320 / :466-470) and the per-colour lists of free, border-valid cells (:338-350)
-    std::vector<unsigned char> hocc(occ_sz * B, 0);
-    {
-        int k = 0;
-        for (int b = 0; b < B; ++b)
-            for (int q = 0; q < n_cur[b]; ++q, ++k) {
-                cimg[k] = b;
-                const float px = cur_xy[2 * k], py = cur_xy[2 * k + 1];
-                const int cr = (int)(py / (float)cell), cc = (int)(px / (float)cell);
-                if (cr >= 0 && cr <= nh && cc >= 0 && cc <= nw) hocc[(size_t)b * occ_sz + cr * (nw + 1) + cc] = 1;
-            }
-    }
-    std::vector<int2> work[4];
-    std::vector<int> h_occupied(B, 0), h_empty(B, 0);
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < nb; ++i) {
-            const int rr = i / nw, cc = i % nw;
-            if (hocc[(size_t)b * occ_sz + rr * (nw + 1) + cc]) { h_occupied[b]++; continue; }
-            h_empty[b]++;
-            if (!(cc * cell + cell < w - 1 && rr * cell + cell < h - 1)) continue;
-            work[(rr & 1) * 2 + (cc & 1)].push_back(make_int2(b, i));
-        }
-    int2 *dwork = nullptr;   // the work lists live at the end of the scratch block
-    if (ncur_tot > 0) {
-        OV2_HIP(c, hipMemcpyAsync(dcur, cur_xy, (size_t)ncur_tot * 8, hipMemcpyHostToDevice, st));
-        OV2_HIP(c, hipMemcpyAsync(dcimg, cimg.data(), (size_t)ncur_tot * 4, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT + 1, det_mask_kernel, dim3(ncur_tot), dim3(64), 0, st, dcur, dcimg, ncur_tot, cell, nw, nh, occ,
-                   mask, w, h, ds);
-    }
-    dwork = (int2 *)(base + off_work);
-    {
-        size_t o = 0;
-        for (int k = 0; k < 4; ++k) {
-            if (!work[k].empty())
-                OV2_HIP(c, hipMemcpyAsync(dwork + o, work[k].data(), work[k].size() * sizeof(int2), hipMemcpyHostToDevice, st));
-            o += work[k].size();
-        }
-    }
+    if (n_cur > 0)
+        OV2_LAUNCH(c, OV2_K_DETECT + 1, det_mask_kernel, dim3(std::min(n_cur, 65536)), dim3(64), 0, st,
+                   reinterpret_cast<const float2 *>(d_cur_xy), d_cur_img, d_cur_valid, n_cur, cell, nw, nh, occ, mask, w, h, ds);
+    OV2_LAUNCH(c, OV2_K_DETECT + 5, det_worklist_kernel, dim3(B), dim3(256), 0, st, cell, nw, nh, w, h, occ, dwork, list_cap, cnt);
     const int nthreads = (cell * cell <= 256) ? 64 : 256;   // small cells: one wave walks the cell
     const size_t mineig_lds = (size_t)(cell + 2) * (cell + 2) * 10 + (size_t)cell * cell * 5;
-    size_t woff = 0;
     for (int colour = 0; colour < 4; ++colour) {
-        const int nitems = (int)work[colour].size();
-        if (nitems > 0) {
-            if (mode == OV2_DETECT_MINEIG)
-                OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nitems), dim3(nthreads), mineig_lds, st, img,
-                           L.img_bstride, L.istride, w, h, cell, nw, nh, dwork + woff, mask, ds, rx, ry, rw, rh, dth, dout);
-            else
-                OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 4, st, img,
-                           L.img_bstride, L.istride, w, h, cell, nw, nh, dwork + woff, mask, ds, dth, dout);
-        }
-        woff += nitems;
+        // cells of this colour per image (upper bound of the list): rows of parity colour>>1 x columns of parity colour&1
+        const int rows_c = (nh + 1 - (colour >> 1)) / 2, cols_c = (nw + 1 - (colour & 1)) / 2, nitems = rows_c * cols_c * B;
+        if (nitems <= 0) continue;
+        const int2 *wl = dwork + (size_t)colour * list_cap;
+        if (mode == OV2_DETECT_MINEIG)
+            OV2_LAUNCH(c, OV2_K_DETECT, det_mineig_kernel, dim3(nitems), dim3(nthreads), mineig_lds, st, img, L.img_bstride, L.istride,
+                       w, h, cell, nw, nh, wl, cnt + colour, mask, ds, rx, ry, rw, rh, d_thresh, dout);
+        else
+            OV2_LAUNCH(c, OV2_K_DETECT, det_fast_kernel, dim3(nitems), dim3(nthreads), (size_t)cell * cell * 4, st, img, L.img_bstride,
+                       L.istride, w, h, cell, nw, nh, wl, cnt + colour, mask, ds, d_thresh, dout);
     }
-    std::vector<det_out> hout((size_t)nb * B);
-    OV2_HIP(c, hipMemcpyAsync(hout.data(), dout, sizeof(det_out) * nb * B, hipMemcpyDeviceToHost, st));
-    OV2_HIP(c, hipStreamSynchronize(st));
-    // per image: assemble in cell order (:393-412 / :532-538) and adapt the threshold (:418-423 / :546-552)
-    std::vector<int> pimg;
-    std::vector<float> pts;
-    for (int b = 0; b < B; ++b) {
-        const det_out *ho = hout.data() + (size_t)b * nb;
-        float *o = out_xy + (size_t)b * out_cap * 2;
-        int n = 0, nboccup = 0, nbempty = 0;
-        nboccup = h_occupied[b];
-        nbempty = h_empty[b];
-        for (int i = 0; i < nb; ++i) {
-            if (ho[i].has_first) { o[2 * n] = ho[i].fx; o[2 * n + 1] = ho[i].fy; ++n; }
-        }
-        if (mode == OV2_DETECT_MINEIG) {
-            if (n + nboccup < nb) {
-                const int nbsec = nb - (n + nboccup);
-                int k = 0;
-                for (int i = 0; i < nb && k < nbsec; ++i)
-                    if (ho[i].has_second) { o[2 * n] = ho[i].sx; o[2 * n + 1] = ho[i].sy; ++n; ++k; }
-            }
-            if ((double)n < 0.33 * (double)(nb - nboccup)) thresh[b] /= 2.;
-            else if ((double)n > 0.9 * (double)(nb - nboccup)) thresh[b] *= 1.5;
-        } else {
-            const int cur_th = (int)thresh[b];
-            if ((double)n < 0.5 * (double)nbempty && nbempty > 10) thresh[b] = (double)(int)((double)cur_th * 0.66);
-            else if (n == nbempty) thresh[b] = (double)(int)((double)cur_th * 1.5);
-        }
-        n_out[b] = n;
-        for (int k = 0; k < n; ++k) { pts.push_back(o[2 * k]); pts.push_back(o[2 * k + 1]); pimg.push_back(b); }
-    }
-    const int ntot = (int)pimg.size();
-    if (ntot > 0 && do_subpix) {
+    OV2_LAUNCH(c, OV2_K_DETECT + 5, det_assemble_kernel, dim3(B), dim3(256), 0, st, mode, nw, nh, occ, dout, d_thresh, d_n_out,
+               reinterpret_cast<float2 *>(d_out_xy), out_cap, pt_ref, pt_img, cnt + 4);
+    if (do_subpix) {
         const int hw = 3, win = 7;
         float wm[49];
         for (int i = 0; i < win; ++i) {
@@ -592,20 +659,59 @@ extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int 
                 wm[i * win + j] = (float)(vy * expf(-x * x));
             }
         }
-        OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));
-        OV2_HIP(c, hipMemcpyAsync(dpts, pts.data(), (size_t)ntot * 8, hipMemcpyHostToDevice, st));
-        OV2_HIP(c, hipMemcpyAsync(dpimg, pimg.data(), (size_t)ntot * 4, hipMemcpyHostToDevice, st));
-        OV2_LAUNCH(c, OV2_K_DETECT + 2, subpix_kernel<3>, dim3((ntot + 3) / 4), dim3(64), 0, st, img, L.img_bstride, dpimg, L.istride,
-                   w, h, ntot, dpts, 30, 0.01 * 0.01, dwm);
-        OV2_HIP(c, hipMemcpyAsync(pts.data(), dpts, (size_t)ntot * 8, hipMemcpyDeviceToHost, st));
-        OV2_HIP(c, hipStreamSynchronize(st));
-        int k = 0;
-        for (int b = 0; b < B; ++b) {
-            memcpy(out_xy + (size_t)b * out_cap * 2, pts.data() + 2 * (size_t)k, (size_t)n_out[b] * 8);
-            k += n_out[b];
-        }
+        OV2_HIP(c, hipMemcpyAsync(dwm, wm, sizeof(wm), hipMemcpyHostToDevice, st));   // 196 B: copied at enqueue time
+        OV2_LAUNCH(c, OV2_K_DETECT + 2, subpix_kernel<3>, dim3(((size_t)nb * B + 3) / 4), dim3(64), 0, st, img, L.img_bstride, pt_img,
+                   pt_ref, cnt + 4, L.istride, w, h, reinterpret_cast<float2 *>(d_out_xy), 30, 0.01 * 0.01, dwm);
     }
     OV2_HIP(c, hipGetLastError());
+    return OV2_OK;
+}
+
+// host-pointer form: stages the arguments through pinned memory, runs the device pipeline, one synchronisation
+extern "C" ov2_status ov2_detect_grid_batch(ov2_ctx *c, const ov2_pyr *pyr, int cell, int mode, double *thresh,
+                                            const int *n_cur, const float *cur_xy, const int *roi, int do_subpix,
+                                            int *n_out, float *out_xy, int out_cap)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (!pyr || !thresh || !n_out || !out_xy || !n_cur) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    const int B = pyr->buf->batch;
+    int ncur_tot = 0;
+    for (int b = 0; b < B; ++b) {
+        if (n_cur[b] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative keypoint count");
+        ncur_tot += n_cur[b];
+    }
+    if (ncur_tot && !cur_xy) return ov2_set_err(c, OV2_ERR_INVALID, "null cur_xy");
+    if (out_cap <= 0) return ov2_set_err(c, OV2_ERR_INVALID, "out_cap %d", out_cap);
+    OV2_HIP(c, hipSetDevice(c->device));
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    // pinned staging (host) and its device twin: [thresh B | n_out B | cur_img | cur_xy | out_xy B x cap]
+    const size_t o_th = 0, o_no = up(sizeof(double) * B), o_ci = o_no + up(sizeof(int) * B);
+    const size_t o_cx = o_ci + up(sizeof(int) * (size_t)ncur_tot), o_ox = o_cx + up(8 * (size_t)ncur_tot);
+    const size_t total = o_ox + up(8 * (size_t)B * out_cap);
+    char *hp = nullptr, *dp = nullptr;
+    ov2_status s = ov2_staging(c, total, (void **)&hp, (void **)&dp);
+    if (s != OV2_OK) return s;
+    memcpy(hp + o_th, thresh, sizeof(double) * B);
+    {
+        int *ci = (int *)(hp + o_ci);
+        int k = 0;
+        for (int b = 0; b < B; ++b)
+            for (int q = 0; q < n_cur[b]; ++q) ci[k++] = b;
+        if (ncur_tot) memcpy(hp + o_cx, cur_xy, 8 * (size_t)ncur_tot);
+    }
+    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemcpyAsync(dp, hp, o_ox, hipMemcpyHostToDevice, st));          // everything before the output block
+    s = ov2_detect_grid_batch_dev(c, pyr, cell, mode, (double *)(dp + o_th), ncur_tot, (const float *)(dp + o_cx),
+                                  (const int32_t *)(dp + o_ci), nullptr, roi, do_subpix, (int32_t *)(dp + o_no),
+                                  (float *)(dp + o_ox), out_cap);
+    if (s != OV2_OK) return s;
+    OV2_HIP(c, hipMemcpyAsync(hp, dp, o_ci, hipMemcpyDeviceToHost, st));          // thresholds + counts
+    OV2_HIP(c, hipMemcpyAsync(hp + o_ox, dp + o_ox, 8 * (size_t)B * out_cap, hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipStreamSynchronize(st));
+    memcpy(thresh, hp + o_th, sizeof(double) * B);
+    memcpy(n_out, hp + o_no, sizeof(int) * B);
+    for (int b = 0; b < B; ++b)
+        if (n_out[b] > 0) memcpy(out_xy + (size_t)b * out_cap * 2, hp + o_ox + 8 * (size_t)b * out_cap, 8 * (size_t)n_out[b]);
     return OV2_OK;
 }
 

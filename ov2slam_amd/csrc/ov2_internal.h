@@ -73,6 +73,8 @@ struct ov2_ctx {
     ov2_images *tmp_img;                 // staging image for ov2_pyramid_build(host img)
     void *ba_arena;                      // device arena of ov2_ba_solve, grown on demand, kept across solves
     size_t ba_arena_cap;
+    void *stage_host, *stage_dev;        // pinned staging block + its device twin for the host-pointer entry points
+    size_t stage_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
     size_t ba_host_cap;
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
@@ -97,6 +99,8 @@ struct ov2_pyr {
 
 ov2_status ov2_set_err(ov2_ctx *ctx, ov2_status s, const char *fmt, ...);
 ov2_status ov2_scratch(ov2_ctx *ctx, size_t bytes, void **out);
+// pinned host block of `bytes` and a device block of the same size (grown on demand, kept by the ctx)
+ov2_status ov2_staging(ov2_ctx *ctx, size_t bytes, void **host, void **dev);
 
 #define OV2_HIP(ctx, call)                                                                          \
     do {                                                                                            \

@@ -280,6 +280,18 @@ class FeatureExtractor:
         return self._detect(0, pyr, vcurkps, roi, b, subpix)
 
 
+def detect_grid_batch_dev(ctx, pyr, cell, mode, d_thresh, n_cur, d_cur_xy, d_cur_img, d_cur_valid, d_n_out, d_out_xy,
+                          out_cap, roi=None, subpix=True):
+    """device-resident, asynchronous keyframe detection on every image of `pyr` (ov2_detect_grid_batch_dev): thresholds,
+    keypoints, counts and corners all stay in HBM; nothing is synchronised."""
+    ptr = lambda a: None if a is None else (a.ptr if isinstance(a, DeviceArray) else a)
+    r = None if roi is None else np.ascontiguousarray(roi, np.int32)
+    _check(ctx.h, ctx.lib.ov2_detect_grid_batch_dev(ctx.h, pyr.h, cell, mode, ptr(d_thresh), int(n_cur), ptr(d_cur_xy),
+                                                    ptr(d_cur_img), ptr(d_cur_valid),
+                                                    None if r is None else r.ctypes.data_as(C.c_void_p), int(subpix),
+                                                    ptr(d_n_out), ptr(d_out_xy), int(out_cap)))
+
+
 def detect_grid_batch(ctx, pyr, cell, mode, thresh, cur_list, roi=None, subpix=True):
     """every image of `pyr` in one call.  thresh: float array [B] (updated in place), cur_list: list of (n_b,2) arrays.
     returns list of (n_b, 2) float32 arrays."""

@@ -97,3 +97,32 @@ def test_detect_batched_equals_per_image(ctx, oracle, stream):
         ex = fe.FeatureExtractor(ctx, nmaxdist=cell, dmaxquality=th0, nfast_th=int(th0))
         one = ex.detectSingleScale(pyr, cur[1], b=1) if mode == 1 else ex.detectGridFAST(pyr, cur[1], b=1)
         assert np.array_equal(one.view(np.uint32), got[1].view(np.uint32))
+
+
+def test_detect_dev_variant_with_validity_mask(ctx, oracle, stream):
+    """ov2_detect_grid_batch_dev: keypoints, thresholds, counts and corners device-resident; d_cur_valid selects which
+    keypoints count (the tracking status in a real front-end).  Same result as the oracle fed the valid subset."""
+    from ov2slam_amd import frontend as fe, synth
+    B = 3
+    ims = fe.Images(ctx, B, 752, 480)
+    raws = [stream.left(4 * b) for b in range(B)]
+    for b in range(B):
+        ims.upload(b, raws[b])
+    pyr = fe.preprocess_images(ctx, ims)
+    rng = np.random.default_rng(3)
+    kps = [synth.grid_keypoints(300, seed=50 + b) for b in range(B)]
+    valid = [rng.uniform(size=len(k)) < 0.7 for k in kps]
+    cell, cap = 35, 2 * (752 // 35) * (480 // 35)
+    d_xy = ctx.to_device(np.concatenate(kps).astype(np.float32))
+    d_img = ctx.to_device(np.concatenate([np.full(len(k), b, np.int32) for b, k in enumerate(kps)]))
+    d_val = ctx.to_device(np.concatenate(valid).astype(np.uint8))
+    d_th = ctx.to_device(np.full(B, 0.001))
+    d_n, d_out = ctx.empty((B,), np.int32), ctx.empty((B, cap, 2), np.float32)
+    fe.detect_grid_batch_dev(ctx, pyr, cell, 1, d_th, sum(len(k) for k in kps), d_xy, d_img, d_val, d_n, d_out, cap)
+    ctx.synchronize()
+    n, out, th = d_n.get(), d_out.get(), d_th.get()
+    for b in range(B):
+        e, eth = oracle.detect_single_scale(oracle.clahe(raws[b]), cell, kps[b][valid[b]], 0.001)
+        assert n[b] == len(e)
+        assert np.array_equal(out[b, :n[b]].view(np.uint32), e.view(np.uint32))
+        assert th[b] == eth
