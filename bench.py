@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--ba-lms", type=int, default=10000, help="landmarks in the local-BA window")
     ap.add_argument("--no-ba", action="store_true", help="front-end only (no concurrent localBA worker)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pnp", action="store_true",
+                    help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
+                         "device-resident; off by default: the BASELINE metric is the tracking path")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for the real multi-GPU run; gloo rehearses the N > 1 control flow with "
@@ -140,6 +143,23 @@ class Workload:
         self.d_det_nout = ctx.empty((seqs,), np.int32)
 
     detect = True
+    pnp = None
+
+    def enable_pnp(self, seed):
+        """per-frame computePose stand-in: one synthetic pose-refinement problem per sequence (kps points, 10 % outliers,
+        perturbed initial pose), device-resident; every step re-solves it from the same initial pose."""
+        from ov2slam_amd import synth_ba
+        from ov2slam_amd.multi_view_geometry import MultiViewGeometry
+        ctx, B, N = self.ctx, self.B, self.N
+        fr = [synth_ba.make_pnp(N, seed=seed + 7 * b) for b in range(B)]
+        self.pnp = dict(mvg=MultiViewGeometry(ctx),
+                        off=ctx.to_device(np.arange(B + 1, dtype=np.int32) * N),
+                        unpx=ctx.to_device(np.concatenate([f["unpx"] for f in fr])),
+                        wpts=ctx.to_device(np.concatenate([f["wpts"] for f in fr])),
+                        K=ctx.to_device(np.stack([f["K"] for f in fr])),
+                        T0=ctx.to_device(np.stack([f["Twc0"] for f in fr])), T=ctx.empty((B, 7), np.float64),
+                        outl=ctx.empty((B * N,), np.uint8), rem=ctx.empty((B * N,), np.uint8),
+                        ok=ctx.empty((B,), np.int32))
 
     def step(self, kf_every, want_work=False):
         fe, ctx, c = self.fe, self.ctx, self.step_no % self.L
@@ -149,6 +169,11 @@ class Workload:
             self.trk.kltTracking_dev(self.prev, cur, WIN, NLVL, 30.0, 0.5, self.kps[c], self.pri[c], self.has[c],
                                      self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, work)
             self.prev.release()
+            if self.pnp:                                                              # 2.FE_TM_computePose (ceresPnP)
+                q = self.pnp
+                q["T"].copy_from(q["T0"])
+                q["mvg"].ceresPnP_batch_dev(self.B, q["off"], q["unpx"], q["wpts"], None, q["K"], q["T"], 5, 5.9915, True,
+                                            True, q["outl"], q["rem"], q["ok"])
         self.prev = cur
         is_kf = (self.step_no % kf_every) == 0
         if is_kf:                                                                    # 1.KF_stereoMatching
@@ -253,6 +278,8 @@ def main():
     ctx = fe.Context(local)
     wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank)
 
+    if a.pnp:
+        wl.enable_pnp(seed=777 + rank)
     ba = None
     if not a.no_ba:
         ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank)
@@ -304,7 +331,8 @@ def main():
         "config": {"workload": "synthetic 752x480 stereo streams, CLAHE + 4-level pyramid + 2-stage fwd-bwd KLT "
                                f"(win 9, 30 it, eps 0.01) on {a.kps} kps/frame; every {a.kf_every}th frame is a keyframe: "
                                f"right-image pyramid + stereo KLT + grid detector (min-eig, cell {wl.det_cell} px) + "
-                               f"cornerSubPix; {a.seqs} sequences per GPU in lock-step",
+                               f"cornerSubPix; {a.seqs} sequences per GPU in lock-step"
+                               + ("; per-frame ceresPnP pose refinement on the same stream" if a.pnp else ""),
                    "sequences_per_gpu": a.seqs, "keypoints_per_frame": a.kps, "kf_every": a.kf_every,
                    "image": [W, H], "parallelism": f"replicas x{world} (one batch of sequences per GPU)"},
         "gpu_stream_ms_per_step": gpu_ms / a.steps,

@@ -65,6 +65,7 @@ ov2_status ov2_dev_alloc(ov2_ctx *ctx, size_t bytes, void **dptr);
 ov2_status ov2_dev_free(ov2_ctx *ctx, void *dptr);
 ov2_status ov2_memcpy_h2d(ov2_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);  /* sync */
 ov2_status ov2_memcpy_d2h(ov2_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);  /* sync */
+ov2_status ov2_memcpy_d2d(ov2_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* async, ctx stream */
 
 /* ---- images ---------------------------------------------------------------------------------- */
 ov2_status ov2_images_create(ov2_ctx *ctx, int batch, int w, int h, ov2_images **out);
@@ -261,6 +262,12 @@ ov2_status ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_opti
 ov2_status ov2_pnp_solve_batch(ov2_ctx *ctx, int B, const int *n_pts, const double *unpx, const double *wpts,
                                const int *scales, const double *K, double *Twc, int max_iters, float chi2th,
                                int use_robust, int l2_after_robust, uint8_t *outlier, int *success, int *iters);
+/* device-resident, asynchronous form: d_off = B + 1 prefix offsets of the frames' points, d_removed = scratch of
+ * sum(n) bytes; every other array as above but in HBM.  Nothing is synchronised. */
+ov2_status ov2_pnp_solve_batch_dev(ov2_ctx *ctx, int B, const int32_t *d_off, const double *d_unpx, const double *d_wpts,
+                                   const int32_t *d_scales, const double *d_K, double *d_Twc, int max_iters, float chi2th,
+                                   int use_robust, int l2_after_robust, uint8_t *d_outlier, uint8_t *d_removed,
+                                   int32_t *d_success, int32_t *d_iters);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ov2_dev_free": (C.c_int, [vp, vp]),
     "ov2_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ov2_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ov2_memcpy_d2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ov2_images_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vpp]),
     "ov2_images_upload": (C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
     "ov2_images_destroy": (None, [vp]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "ov2_detect_grid_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]),
     "ov2_ba_default_options": (None, [vp, C.c_float]),
     "ov2_ba_solve": (C.c_int, [vp, vp, vp, vp]),
+    "ov2_pnp_solve_batch_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
+                                          vp, vp, vp, vp]),
     "ov2_pnp_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                       vp, vp, vp]),
 }

@@ -148,6 +148,13 @@ extern "C" ov2_status ov2_memcpy_d2h(ov2_ctx *c, void *dst, const void *src, siz
     return OV2_OK;
 }
 
+extern "C" ov2_status ov2_memcpy_d2d(ov2_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return OV2_OK;
+}
+
 ov2_status ov2_scratch(ov2_ctx *c, size_t bytes, void **out)
 {
     if (bytes > c->scratch_bytes) {

@@ -375,39 +375,19 @@ __global__ __launch_bounds__(256) void pnp_kernel(int B, const int *__restrict__
 
 }  // namespace
 
-extern "C" ov2_status ov2_pnp_solve_batch(ov2_ctx *c, int B, const int *n_pts, const double *unpx, const double *wpts,
-                                          const int *scales, const double *K, double *Twc, int max_iters, float chi2th,
-                                          int use_robust, int l2_after_robust, uint8_t *outlier, int *success, int *iters)
+// device-resident, asynchronous form: every array already in HBM, nothing synchronised.
+// d_off: B + 1 prefix offsets of the frames' points; d_removed: scratch of sum(n) bytes (may alias nothing else).
+extern "C" ov2_status ov2_pnp_solve_batch_dev(ov2_ctx *c, int B, const int32_t *d_off, const double *d_unpx,
+                                              const double *d_wpts, const int32_t *d_scales, const double *d_K,
+                                              double *d_Twc, int max_iters, float chi2th, int use_robust,
+                                              int l2_after_robust, uint8_t *d_outlier, uint8_t *d_removed,
+                                              int32_t *d_success, int32_t *d_iters)
 {
     if (!c) return OV2_ERR_INVALID;
-    if (B < 0 || (B && (!n_pts || !K || !Twc || !success))) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    if (B < 0 || (B && (!d_off || !d_K || !d_Twc || !d_success || !d_outlier || !d_removed || !d_unpx || !d_wpts)))
+        return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
     if (B == 0) return OV2_OK;
-    std::vector<int> off(B + 1, 0);
-    for (int b = 0; b < B; ++b) {
-        if (n_pts[b] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative point count");
-        off[b + 1] = off[b] + n_pts[b];
-    }
-    const int n = off[B];
-    if (n && (!unpx || !wpts || !outlier)) return ov2_set_err(c, OV2_ERR_INVALID, "null point arrays");
     OV2_HIP(c, hipSetDevice(c->device));
-    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t o_off = 0, o_un = up(sizeof(int) * (B + 1)), o_wp = o_un + up(sizeof(double) * 2 * n);
-    const size_t o_sc = o_wp + up(sizeof(double) * 3 * n), o_K = o_sc + up(sizeof(int) * n), o_T = o_K + up(sizeof(double) * 4 * B);
-    const size_t o_out = o_T + up(sizeof(double) * 7 * B), o_rem = o_out + up((size_t)n), o_ok = o_rem + up((size_t)n);
-    const size_t o_it = o_ok + up(sizeof(int) * B), total = o_it + up(sizeof(int) * 2 * B);
-    void *scr = nullptr;
-    ov2_status s = ov2_scratch(c, total, &scr);
-    if (s != OV2_OK) return s;
-    char *base = (char *)scr;
-    hipStream_t st = c->stream;
-    OV2_HIP(c, hipMemcpyAsync(base + o_off, off.data(), sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
-    if (n) {
-        OV2_HIP(c, hipMemcpyAsync(base + o_un, unpx, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
-        OV2_HIP(c, hipMemcpyAsync(base + o_wp, wpts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-        if (scales) OV2_HIP(c, hipMemcpyAsync(base + o_sc, scales, sizeof(int) * n, hipMemcpyHostToDevice, st));
-    }
-    OV2_HIP(c, hipMemcpyAsync(base + o_K, K, sizeof(double) * 4 * B, hipMemcpyHostToDevice, st));
-    OV2_HIP(c, hipMemcpyAsync(base + o_T, Twc, sizeof(double) * 7 * B, hipMemcpyHostToDevice, st));
     pnp_params P;
     ov2_ba_options o;
     ov2_ba_default_options(&o, chi2th);
@@ -417,15 +397,61 @@ extern "C" ov2_status ov2_pnp_solve_batch(ov2_ctx *c, int B, const int *n_pts, c
     P.initial_radius = o.initial_radius; P.max_radius = o.max_radius; P.min_radius = o.min_radius;
     P.min_diag = o.min_lm_diagonal; P.max_diag = o.max_lm_diagonal; P.min_rel = o.min_relative_decrease;
     P.ptol = o.parameter_tolerance;
-    OV2_LAUNCH(c, OV2_K_DETECT + 3, pnp_kernel, dim3(B), dim3(256), 0, st, B, (const int *)(base + o_off),
-               (const double *)(base + o_un), (const double *)(base + o_wp), scales ? (const int *)(base + o_sc) : nullptr,
-               (const double *)(base + o_K), (double *)(base + o_T), (unsigned char *)(base + o_out),
-               (unsigned char *)(base + o_rem), (int *)(base + o_ok), iters ? (int *)(base + o_it) : nullptr, P);
-    OV2_HIP(c, hipMemcpyAsync(Twc, base + o_T, sizeof(double) * 7 * B, hipMemcpyDeviceToHost, st));
-    if (n) OV2_HIP(c, hipMemcpyAsync(outlier, base + o_out, (size_t)n, hipMemcpyDeviceToHost, st));
-    OV2_HIP(c, hipMemcpyAsync(success, base + o_ok, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    if (iters) OV2_HIP(c, hipMemcpyAsync(iters, base + o_it, sizeof(int) * 2 * B, hipMemcpyDeviceToHost, st));
-    OV2_HIP(c, hipStreamSynchronize(st));
+    OV2_LAUNCH(c, OV2_K_DETECT + 3, pnp_kernel, dim3(B), dim3(256), 0, c->stream, B, d_off, d_unpx, d_wpts, d_scales, d_K,
+               d_Twc, d_outlier, d_removed, d_success, d_iters, P);
     OV2_HIP(c, hipGetLastError());
+    return OV2_OK;
+}
+
+// host-pointer form: arguments staged through pinned memory (one copy in, one copy out, one synchronisation)
+extern "C" ov2_status ov2_pnp_solve_batch(ov2_ctx *c, int B, const int *n_pts, const double *unpx, const double *wpts,
+                                          const int *scales, const double *K, double *Twc, int max_iters, float chi2th,
+                                          int use_robust, int l2_after_robust, uint8_t *outlier, int *success, int *iters)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (B < 0 || (B && (!n_pts || !K || !Twc || !success))) return ov2_set_err(c, OV2_ERR_INVALID, "null argument");
+    if (B == 0) return OV2_OK;
+    size_t n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (n_pts[b] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative point count");
+        n += (size_t)n_pts[b];
+    }
+    if (n && (!unpx || !wpts || !outlier)) return ov2_set_err(c, OV2_ERR_INVALID, "null point arrays");
+    OV2_HIP(c, hipSetDevice(c->device));
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    // staging block: inputs first (one H2D), then the outputs (one D2H): [off | K | unpx | wpts | scales || T | ok | it | outlier | removed]
+    const size_t o_off = 0, o_K = up(sizeof(int) * (B + 1)), o_un = o_K + up(sizeof(double) * 4 * B);
+    const size_t o_wp = o_un + up(sizeof(double) * 2 * n), o_sc = o_wp + up(sizeof(double) * 3 * n);
+    const size_t o_T = o_sc + up(sizeof(int) * n), o_ok = o_T + up(sizeof(double) * 7 * B), o_it = o_ok + up(sizeof(int) * B);
+    const size_t o_out = o_it + up(sizeof(int) * 2 * B), o_rem = o_out + up(n), total = o_rem + up(n);
+    char *hp = nullptr, *dp = nullptr;
+    ov2_status s = ov2_staging(c, total, (void **)&hp, (void **)&dp);
+    if (s != OV2_OK) return s;
+    {
+        int *off = (int *)(hp + o_off);
+        off[0] = 0;
+        for (int b = 0; b < B; ++b) off[b + 1] = off[b] + n_pts[b];
+    }
+    memcpy(hp + o_K, K, sizeof(double) * 4 * B);
+    if (n) {
+        memcpy(hp + o_un, unpx, sizeof(double) * 2 * n);
+        memcpy(hp + o_wp, wpts, sizeof(double) * 3 * n);
+        if (scales) memcpy(hp + o_sc, scales, sizeof(int) * n);
+    }
+    memcpy(hp + o_T, Twc, sizeof(double) * 7 * B);
+    hipStream_t st = c->stream;
+    OV2_HIP(c, hipMemcpyAsync(dp, hp, o_ok, hipMemcpyHostToDevice, st));   // inputs + initial poses
+    s = ov2_pnp_solve_batch_dev(c, B, (const int32_t *)(dp + o_off), (const double *)(dp + o_un), (const double *)(dp + o_wp),
+                                scales ? (const int32_t *)(dp + o_sc) : nullptr, (const double *)(dp + o_K),
+                                (double *)(dp + o_T), max_iters, chi2th, use_robust, l2_after_robust,
+                                (uint8_t *)(dp + o_out), (uint8_t *)(dp + o_rem), (int32_t *)(dp + o_ok),
+                                iters ? (int32_t *)(dp + o_it) : nullptr);
+    if (s != OV2_OK) return s;
+    OV2_HIP(c, hipMemcpyAsync(hp + o_T, dp + o_T, o_rem - o_T, hipMemcpyDeviceToHost, st));   // poses, flags, counts, outliers
+    OV2_HIP(c, hipStreamSynchronize(st));
+    memcpy(Twc, hp + o_T, sizeof(double) * 7 * B);
+    memcpy(success, hp + o_ok, sizeof(int) * B);
+    if (iters) memcpy(iters, hp + o_it, sizeof(int) * 2 * B);
+    if (n) memcpy(outlier, hp + o_out, n);
     return OV2_OK;
 }

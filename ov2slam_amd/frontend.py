@@ -99,6 +99,11 @@ class DeviceArray:
         assert arr.nbytes == self.nbytes
         _check(self.ctx.h, self.ctx.lib.ov2_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
 
+    def copy_from(self, other):
+        """asynchronous device-to-device copy on the ctx stream"""
+        assert other.nbytes == self.nbytes
+        _check(self.ctx.h, self.ctx.lib.ov2_memcpy_d2d(self.ctx.h, self.ptr, other.ptr, self.nbytes))
+
     def __del__(self):
         if getattr(self, "ptr", None) and getattr(self.ctx, "h", None):
             self.ctx.free(self.ptr)

@@ -25,6 +25,16 @@ class MultiViewGeometry:
                                             None if vscales is None else [vscales])
         return bool(ok[0]), T[0], np.flatnonzero(out[0]).astype(np.int32)
 
+    def ceresPnP_batch_dev(self, B, d_off, d_unpx, d_wpts, d_scales, d_K, d_Twc, nmaxiter, chi2th, buse_robust,
+                           bapply_l2_after_robust, d_outlier, d_removed, d_success, d_iters=None):
+        """device-resident, asynchronous form (ov2_pnp_solve_batch_dev): DeviceArrays in, nothing synchronised."""
+        p = lambda a: None if a is None else a.ptr
+        c = self.ctx
+        _check(c.h, c.lib.ov2_pnp_solve_batch_dev(c.h, int(B), p(d_off), p(d_unpx), p(d_wpts), p(d_scales), p(d_K), p(d_Twc),
+                                                  int(nmaxiter), float(chi2th), int(bool(buse_robust)),
+                                                  int(bool(bapply_l2_after_robust)), p(d_outlier), p(d_removed),
+                                                  p(d_success), p(d_iters)))
+
     def ceresPnP_batch(self, unpx_list, wpts_list, Twc, nmaxiter, chi2th, buse_robust, bapply_l2_after_robust, K,
                        scales_list=None):
         """B independent frames in one launch (one workgroup each).

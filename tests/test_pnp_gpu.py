@@ -73,3 +73,27 @@ def test_invalid_arguments(ctx):
                      400, 400, 300, 200)
     ok, T, outs, it = mvg.ceresPnP_batch([], [], np.zeros((0, 7)), 5, 5.99, True, True, np.zeros((0, 4)))
     assert len(ok) == 0 and len(outs) == 0
+
+
+def test_device_resident_variant(ctx, oracle):
+    """ov2_pnp_solve_batch_dev: every array in HBM, nothing synchronised by the call"""
+    frames = [synth_ba.make_pnp(500, seed=900 + b, with_scales=True) for b in range(5)]
+    n = [len(p["unpx"]) for p in frames]
+    mvg = MultiViewGeometry(ctx)
+    d = dict(off=ctx.to_device(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)),
+             unpx=ctx.to_device(np.concatenate([p["unpx"] for p in frames])),
+             wpts=ctx.to_device(np.concatenate([p["wpts"] for p in frames])),
+             sc=ctx.to_device(np.concatenate([p["scales"] for p in frames]).astype(np.int32)),
+             K=ctx.to_device(np.stack([p["K"] for p in frames])), T=ctx.to_device(np.stack([p["Twc0"] for p in frames])),
+             out=ctx.empty((sum(n),), np.uint8), rem=ctx.empty((sum(n),), np.uint8), ok=ctx.empty((5,), np.int32),
+             it=ctx.empty((5, 2), np.int32))
+    mvg.ceresPnP_batch_dev(5, d["off"], d["unpx"], d["wpts"], d["sc"], d["K"], d["T"], 5, 5.9915, True, True, d["out"],
+                           d["rem"], d["ok"], d["it"])
+    ctx.synchronize()
+    T, out, ok, it = d["T"].get(), d["out"].get().astype(bool), d["ok"].get(), d["it"].get()
+    o = 0
+    for b, p in enumerate(frames):
+        eok, eT, eout, eit = oracle.pnp_solve(p["unpx"], p["wpts"], p["K"], p["Twc0"], p["scales"])
+        assert bool(ok[b]) == eok and tuple(it[b]) == eit
+        assert np.array_equal(out[o:o + n[b]], eout) and np.abs(T[b] - eT).max() < TOL
+        o += n[b]
