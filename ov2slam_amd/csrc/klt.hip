@@ -392,51 +392,50 @@ __global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_vie
 // takes live keypoints [g*KPW, (g+1)*KPW) and workgroups beyond the count retire at once.  So every launched wave is
 // full, there is no intra-workgroup imbalance, and the grid needs no host-side knowledge of the live count.
 
-// stage = 1: live = has a prior (the others are initialised for stage 2: position = the keypoint itself, status 0);
-// stage = 2: live = not already tracked in stage 1.
-__global__ __launch_bounds__(256) void klt_compact_kernel(int n, int stage, const unsigned char *__restrict__ has_prior,
-                                                          const float2 *__restrict__ kps, float2 *__restrict__ out_xy,
-                                                          unsigned char *__restrict__ out_status,
-                                                          unsigned *__restrict__ iters, int *__restrict__ live_idx,
-                                                          unsigned *__restrict__ live_cnt, int *__restrict__ p3p_req,
-                                                          int batch)
+// pass 1 lists the keypoints with a prior (list A, 2 pyramid levels) and those without (list B, full pyramid: they do
+// not depend on the outcome of the first group, so both groups run in ONE launch); pass 2 lists the failures of
+// list A, which are re-tracked on the full pyramid once the per-image tally of list A is complete (the 33 % rule).
+__global__ __launch_bounds__(256) void klt_compact_kernel(int n, int pass, const unsigned char *__restrict__ has_prior,
+                                                          const unsigned char *__restrict__ out_status,
+                                                          unsigned *__restrict__ iters, int *__restrict__ list_a,
+                                                          int *__restrict__ list_b, unsigned *__restrict__ cnt,
+                                                          int *__restrict__ p3p_req, int batch)
 {
-    __shared__ int wsum[4];
-    __shared__ int wbase;
+    __shared__ int wsum[2][4];
+    __shared__ int wbase[2];
     const int f = blockIdx.x * 256 + threadIdx.x;
-    bool live = false;
+    bool la = false, lb = false;
     if (f < n) {
         const bool hp = has_prior[f] != 0;
-        if (stage == 1) {
-            live = hp;
-            if (!live) {   // no prior: stage 2 starts from the keypoint itself
-                out_xy[f] = kps[f];
-                out_status[f] = 0;
-                if (iters) iters[f] = 0;
-            }
+        if (pass == 1) {
+            la = hp; lb = !hp;
+            if (iters) iters[hp ? n + f : f] = 0;   // the slot of the stage the keypoint does not take (so far)
         } else {
-            live = !(hp && out_status[f] != 0);
-            if (!live && iters) iters[n + f] = 0;
+            la = hp && out_status[f] == 0;
         }
     }
-    if (stage == 1 && p3p_req)
+    if (pass == 1 && p3p_req)
         for (int k = f; k < batch; k += gridDim.x * 256) p3p_req[k] = 0;
-    const unsigned long long m = __ballot(live);
+    const unsigned long long ma = __ballot(la), mb = __ballot(lb);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wv] = __popcll(m);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int ra = __popcll(ma & below), rb = __popcll(mb & below);
+    if (lane == 0) { wsum[0][wv] = __popcll(ma); wsum[1][wv] = __popcll(mb); }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        wbase = tot ? (int)atomicAdd(live_cnt, (unsigned)tot) : 0;
+    if (threadIdx.x < 2) {
+        const int q = threadIdx.x;
+        const int tot = wsum[q][0] + wsum[q][1] + wsum[q][2] + wsum[q][3];
+        wbase[q] = tot ? (int)atomicAdd(&cnt[pass == 1 ? q : 2], (unsigned)tot) : 0;
     }
     __syncthreads();
-    int off = wbase;
-    for (int k = 0; k < wv; ++k) off += wsum[k];
-    if (live) live_idx[off + rank] = f;
+    int oa = wbase[0], ob = wbase[1];
+    for (int k = 0; k < wv; ++k) { oa += wsum[0][k]; ob += wsum[1][k]; }
+    if (la) list_a[oa + ra] = f;
+    if (lb) list_b[ob + rb] = f;
 }
 
-// stage 1: keypoints with a prior, 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190)
+// first launch: list A = keypoints with a prior on 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190),
+// list B = keypoints without prior on the full pyramid from their own position (:237-270, vpriors = vkps)
 template <int WIN, int KLT_GL>
 __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                         const float2 *__restrict__ kps,
@@ -444,50 +443,67 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
                                                         unsigned char *__restrict__ out_status,
                                                         unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
-                                                        unsigned *__restrict__ iters, const int *__restrict__ live_idx,
-                                                        const unsigned *__restrict__ live_cnt)
+                                                        unsigned *__restrict__ iters, const int *__restrict__ list_a,
+                                                        const int *__restrict__ list_b, const unsigned *__restrict__ cnt)
 {
     constexpr int KLT_KPW = 64 / KLT_GL;
-    const int total = (int)*live_cnt;
-    if ((int)blockIdx.x * KLT_KPW >= total) return;
-    const int sub = threadIdx.x & (KLT_GL - 1), idx = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
+    const int total_a = (int)cnt[0], total_b = (int)cnt[1];
+    const int groups_a = (total_a + KLT_KPW - 1) / KLT_KPW;
+    const bool is_a = (int)blockIdx.x < groups_a;
+    const int g = is_a ? (int)blockIdx.x : (int)blockIdx.x - groups_a;
+    const int total = is_a ? total_a : total_b;
+    if (g * KLT_KPW >= total) return;
+    const int sub = threadIdx.x & (KLT_GL - 1), idx = g * KLT_KPW + (int)(threadIdx.x / KLT_GL);
     const bool act = idx < total;
-    const int i = live_idx[act ? idx : total - 1];
+    const int i = (is_a ? list_a : list_b)[act ? idx : total - 1];
     const float2 kp = kps[i];
     const int b = img_idx ? img_idx[i] : 0;
-    float2 pr = prior[i];
+    float2 pr = is_a ? prior[i] : kp;
     unsigned work = 0;
-    const int nl = min(1, pv.nlevels - 1);
+    const int nl = is_a ? min(1, pv.nlevels - 1) : P.nlevels;
     const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work);
     if (act && sub == 0) {
-        out_xy[i] = pr;   // tracked position, or the failed forward result that seeds stage 2 (:217-219)
+        out_xy[i] = pr;   // tracked position, or the failed forward result that seeds the re-tracking (:217-219)
         out_status[i] = (unsigned char)ok;
-        if (iters) iters[i] = work;
+        if (iters) iters[is_a ? i : n + i] = work;   // second half of the work-word array = full-pyramid passes
         // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
         // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
-        atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
+        if (is_a) atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
     }
 }
 
-// stage 2: keypoints without prior + stage-1 failures, full pyramid (src/visual_front_end.cpp:237-270)
+// second launch: the failures of list A, full pyramid, from the failed forward result -- or from the keypoint itself
+// when less than 33 % of the image's list-A keypoints were tracked (:228-233, which also raises bp3preq_)
 template <int WIN, int KLT_GL>
 __global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                         const float2 *__restrict__ kps,
-                                                        const unsigned char *__restrict__ has_prior,
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
                                                         unsigned char *__restrict__ out_status,
                                                         const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
-                                                        unsigned *__restrict__ iters, const int *__restrict__ live_idx,
-                                                        const unsigned *__restrict__ live_cnt)
+                                                        unsigned *__restrict__ iters, const int *__restrict__ list_c,
+                                                        const unsigned *__restrict__ cnt, int batch)
 {
     constexpr int KLT_KPW = 64 / KLT_GL;
-    const int total = (int)*live_cnt;
+    const int sub = threadIdx.x & (KLT_GL - 1), grp = (int)(threadIdx.x / KLT_GL);
+    // the 33 % flag is per image and must be raised even when no failure of that image is re-tracked
+    if (p3p_req) {
+        for (int b = blockIdx.x * KLT_KPW + grp; b < batch; b += gridDim.x * KLT_KPW) {
+            int n3 = 0, good = 0;
+            for (int q = 0; q < 64 / KLT_GL; ++q) {
+                const unsigned cw = counts[64 * b + sub * (64 / KLT_GL) + q];
+                n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
+            }
+            n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
+            if (sub == 0 && n3 > 0 && (double)good < 0.33 * (double)n3) p3p_req[b] = 1;
+        }
+    }
+    const int total = (int)cnt[2];
     if ((int)blockIdx.x * KLT_KPW >= total) return;
-    const int sub = threadIdx.x & (KLT_GL - 1), idx = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
+    const int idx = blockIdx.x * KLT_KPW + grp;
     const bool act = idx < total;
-    const int i = live_idx[act ? idx : total - 1];
+    const int i = list_c[act ? idx : total - 1];
     const int b = img_idx ? img_idx[i] : 0;
-    // per-image stage-1 tally: 64 slots shared out over the lanes of the group
+    // per-image tally of the first launch: 64 slots shared out over the lanes of the group
     int n3 = 0, good = 0;
     for (int q = 0; q < 64 / KLT_GL; ++q) {
         const unsigned cw = counts[64 * b + sub * (64 / KLT_GL) + q];
@@ -495,16 +511,14 @@ __global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr
     }
     n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
     const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
-    if (act && sub == 0 && p3p_req && drop) p3p_req[b] = 1;
-    const bool hp = has_prior[i] != 0;
     const float2 kp = kps[i];
-    float2 pr = (hp && !drop) ? out_xy[i] : kp;
+    float2 pr = drop ? kp : out_xy[i];
     unsigned work = 0;
     const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
     if (act && sub == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
-        if (iters) iters[n + i] = work;  // second half of the work-word array = stage 2
+        if (iters) iters[n + i] = work;
     }
 }
 
@@ -611,32 +625,30 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
     const int B = prev->buf->batch;
-    // scratch: [stage-1 tallies B x 64 | live counts (2) ] zeroed per call, then the two live-index lists
+    // scratch: [tallies B x 64 | list lengths (3)] zeroed per call, then the three keypoint lists
     const size_t cnt_bytes = ((size_t)B * 64 + 16) * sizeof(unsigned);
     void *scr = nullptr;
-    s = ov2_scratch(c, cnt_bytes + 2 * (size_t)n * sizeof(int) + 256, &scr);
+    s = ov2_scratch(c, cnt_bytes + 3 * (size_t)n * sizeof(int) + 256, &scr);
     if (s != OV2_OK) return s;
     unsigned *counts = (unsigned *)scr, *live_cnt = counts + (size_t)B * 64;
-    int *live1 = (int *)((char *)scr + cnt_bytes), *live2 = live1 + n;
+    int *list_a = (int *)((char *)scr + cnt_bytes), *list_b = list_a + n, *list_c = list_b + n;
     OV2_HIP(c, hipMemsetAsync(counts, 0, cnt_bytes, c->stream));
     const dim3 cgrid((n + 255) / 256);
 #define KLT_STAGES_GL(W, G)                                                                                     \
     do {                                                                                                        \
-        const dim3 tgrid((n + 64 / G - 1) / (64 / G));                                                          \
+        const dim3 tgrid((n + 64 / G - 1) / (64 / G) + 1);   /* groups of list A + groups of list B <= n/KPW + 2 */ \
         OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 1, d_has_prior,  \
-                   reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_out_xy), d_out_status, \
-                   d_iters, live1, live_cnt, d_p3p_req, B);                                                     \
-        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
+                   d_out_status, d_iters, list_a, list_b, live_cnt, d_p3p_req, B);                              \
+        OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), dim3(tgrid.x + 1), dim3(64), 0, c->stream,   \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),              \
                    reinterpret_cast<const float2 *>(d_prior), d_img_idx, reinterpret_cast<float2 *>(d_out_xy),  \
-                   d_out_status, counts, d_iters, live1, live_cnt);                                             \
+                   d_out_status, counts, d_iters, list_a, list_b, live_cnt);                                    \
         OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 2, d_has_prior,  \
-                   reinterpret_cast<const float2 *>(d_kps), reinterpret_cast<float2 *>(d_out_xy), d_out_status, \
-                   d_iters, live2, live_cnt + 1, d_p3p_req, B);                                                 \
+                   d_out_status, d_iters, list_c, list_c, live_cnt, d_p3p_req, B);                              \
         OV2_LAUNCH(c, OV2_K_KLT_STAGE2, (klt_stage2_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
-                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_has_prior, \
-                   d_img_idx, reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters,   \
-                   live2, live_cnt + 1);                                                                        \
+                   prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_img_idx,   \
+                   reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters, list_c,      \
+                   live_cnt, B);                                                                                \
     } while (0)
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \

@@ -28,8 +28,8 @@ for _ in range(3):
 ctx.synchronize()
 w = d_w.get()
 it, ps_ = (w & 0xffff), (w >> 16)
-print(f"B={B}: tracked {d_s.get().mean():.3f}; stage1 live {np.count_nonzero(ps_[:n])} kps, {it[:n].sum()} iterations, {ps_[:n].sum()} level passes; "
-      f"stage2 live {np.count_nonzero(ps_[n:])} kps, {it[n:].sum()} iterations, {ps_[n:].sum()} level passes")
+print(f"B={B}: tracked {d_s.get().mean():.3f}; 2-level passes on {np.count_nonzero(ps_[:n])} kps ({it[:n].sum()} iterations, {ps_[:n].sum()} level passes); "
+      f"full-pyramid passes on {np.count_nonzero(ps_[n:])} kps ({it[n:].sum()} iterations, {ps_[n:].sum()} level passes)")
 ctx.kernel_timing(True); ctx.kernel_times()
 R = 20
 for _ in range(R):

@@ -187,7 +187,7 @@ def test_fb_klt_full_size_properties(ctx, stream):
     assert np.array_equal(out3.view(np.uint32), out.view(np.uint32)) and np.array_equal(st3, st)
 
 
-@pytest.mark.parametrize("win", [7, 9, 11])
+@pytest.mark.parametrize("win", [5, 7, 9, 11])
 def test_klt_large_call_eight_lane_path(ctx, oracle, stream, win):
     """calls with >= 65536 keypoints switch the kernels to 8 lanes per keypoint (eight keypoints per wave; for
     win 9 / 11 the columns beyond the eighth are dealt out pixel by pixel): bit parity with the oracle on 66k keypoints,
