@@ -361,10 +361,14 @@ __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_vi
 // 16 lanes (four per wave) give twice as many, shorter waves and win while the launch is latency-bound (68k vs 60k
 // frames/s at 16 x 2048).
 #define KLT_GL8_MIN_KPS 65536
+// occupancy bounds handed to the register allocator (min, max waves per SIMD).  Measured on 64 x 2048 keypoints,
+// first launch: register-squeezed to 6-7 waves 228 us, unconstrained (5 waves) 209 us, capped at 3 / 4 / 5 waves
+// 204 / 203.5 / 205 us -- the kernel is issue-bound, extra waves only add pressure, so the allocator gets room.
+#define KLT_WAVES(W, G) 1, 4
 
 // 64 threads = 64 / GL keypoints.  grid = ceil(n / (64 / GL))
 template <int WIN, int KLT_GL>
-__global__ __launch_bounds__(64) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WIN, KLT_GL)))) void klt_fb_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                     const float2 *__restrict__ kps, float2 *__restrict__ priors,
                                                     unsigned char *__restrict__ status,
                                                     const int *__restrict__ img_idx, unsigned *__restrict__ iters)
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void klt_compact_kernel(int n, int pass, const
 // first launch: list A = keypoints with a prior on 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190),
 // list B = keypoints without prior on the full pyramid from their own position (:237-270, vpriors = vkps)
 template <int WIN, int KLT_GL>
-__global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WIN, KLT_GL)))) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                         const float2 *__restrict__ kps,
                                                         const float2 *__restrict__ prior,
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
@@ -448,9 +452,11 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
 {
     constexpr int KLT_KPW = 64 / KLT_GL;
     const int total_a = (int)cnt[0], total_b = (int)cnt[1];
-    const int groups_a = (total_a + KLT_KPW - 1) / KLT_KPW;
-    const bool is_a = (int)blockIdx.x < groups_a;
-    const int g = is_a ? (int)blockIdx.x : (int)blockIdx.x - groups_a;
+    // list B first: its waves run the full pyramid (about twice the work of a list-A wave), so the short list-A waves
+    // fill the tail of the launch instead of the long ones forming it
+    const int groups_b = (total_b + KLT_KPW - 1) / KLT_KPW;
+    const bool is_a = (int)blockIdx.x >= groups_b;
+    const int g = is_a ? (int)blockIdx.x - groups_b : (int)blockIdx.x;
     const int total = is_a ? total_a : total_b;
     if (g * KLT_KPW >= total) return;
     const int sub = threadIdx.x & (KLT_GL - 1), idx = g * KLT_KPW + (int)(threadIdx.x / KLT_GL);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(64) void klt_stage1_kernel(ov2_pyr_view pv, ov2_pyr
 // second launch: the failures of list A, full pyramid, from the failed forward result -- or from the keypoint itself
 // when less than 33 % of the image's list-A keypoints were tracked (:228-233, which also raises bp3preq_)
 template <int WIN, int KLT_GL>
-__global__ __launch_bounds__(64) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WIN, KLT_GL)))) void klt_stage2_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
                                                         const float2 *__restrict__ kps,
                                                         const int *__restrict__ img_idx, float2 *__restrict__ out_xy,
                                                         unsigned char *__restrict__ out_status,
