@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--ba-kfs", type=int, default=50, help="keyframes in the local-BA window (north_star: ~50)")
     ap.add_argument("--ba-lms", type=int, default=10000, help="landmarks in the local-BA window")
     ap.add_argument("--no-ba", action="store_true", help="front-end only (no concurrent localBA worker)")
+    ap.add_argument("--ba-workers", type=int, default=1,
+                    help="Estimator threads per GPU (the reference runs one per SLAM instance; each owns a share of the "
+                         "sequences and its own high-priority HIP context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnp", action="store_true",
                     help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
@@ -197,33 +200,40 @@ class BaWorker:
     newest).  The loop is a NATIVE thread of libov2host.so (ov2slam_amd/host/ov2_host_capi.cpp): a Python thread here
     fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
-    def __init__(self, device, seqs, n_kf, n_lm, seed):
+    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1):
         from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
-        self.w = host_map.EstimatorWorker(device, self.P0, seqs)
-        self.w.submit_all()                       # warm-up (allocations, code objects); not counted
-        t0 = time.perf_counter()
-        while self.w.stats()["last_status"] != 0 and time.perf_counter() - t0 < 5.0:
-            time.sleep(0.001)
+        workers = max(1, min(workers, seqs))
+        share = [seqs // workers + (1 if k < seqs % workers else 0) for k in range(workers)]
+        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k]) for k in range(workers)]
+        for w in self.ws:
+            w.submit_all()                        # warm-up (allocations, code objects); not counted
         self.solves = self.iters = self.dropped = self.submitted = 0
         self.busy_s = 0.0
 
     def submit_all(self):
-        self.w.submit_all()
+        for w in self.ws:
+            w.submit_all()
 
     def set_counting(self, on):
-        self.w.set_counting(on)
+        for w in self.ws:
+            w.set_counting(on)
 
     def refresh(self):
-        st = self.w.stats()
-        if st["last_status"] != 0:
-            raise RuntimeError(f"ov2_ba_solve failed in the worker (status {st['last_status']})")
-        self.solves, self.iters, self.dropped = st["solves"], st["iters"], st["dropped"]
-        self.submitted, self.busy_s = st["submitted"], st["busy_s"]
-        return st
+        tot = dict(solves=0, iters=0, dropped=0, submitted=0, busy_s=0.0)
+        for w in self.ws:
+            st = w.stats()
+            if st["last_status"] != 0:
+                raise RuntimeError(f"ov2_ba_solve failed in the worker (status {st['last_status']})")
+            for k in tot:
+                tot[k] += st[k]
+        self.solves, self.iters, self.dropped = tot["solves"], tot["iters"], tot["dropped"]
+        self.submitted, self.busy_s = tot["submitted"], tot["busy_s"] / len(self.ws)
+        return tot
 
     def stop(self):
-        self.w.close()
+        for w in self.ws:
+            w.close()
 
 
 def cpu_baseline(workload, kf_every, budget_s):
@@ -284,7 +294,7 @@ def main():
         wl.enable_pnp(seed=777 + rank)
     ba = None
     if not a.no_ba:
-        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank)
+        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers)
     for _ in range(a.warmup):
         if wl.step(a.kf_every) and ba:
             ba.submit_all()
@@ -350,7 +360,8 @@ def main():
                            "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
                            "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
                                       "parametrisation": "anchored inverse depth (buse_inv_depth: 1)"},
-                           "mode": "one Estimator-like worker per GPU on its own HIP stream, concurrent with the "
+                           "workers_per_gpu": len(ba.ws),
+                           "mode": "Estimator-like native worker threads, each on its own high-priority HIP stream, concurrent with the "
                                    "front-end (reference: src/estimator.cpp:32-98); robust solve (<=5 it) + L2 (<=10 it)",
                            "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
         out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"
