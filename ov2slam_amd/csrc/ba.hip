@@ -1150,13 +1150,17 @@ __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ 
     double x[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? ((r < m) ? A[(size_t)(k0 + c) * m + r] : rhs[k0 + c]) : 0.0;
-    // right-looking within the row: once x[c] is final, all later entries take their update at once (31 independent
-    // FMAs) -- the dependent chain is 32 divisions long instead of 528 FMAs
+    // left-looking per entry: a chain of ~500 dependent FMAs (2 us).  The right-looking variant (each final x[c] updating
+    // all later entries at once) has more parallelism, but the scheduler hoisted its 496 LDS reads and the kernel
+    // spilled 624 registers into 2.5 KB of scratch per lane -- and scratch costs milliseconds per dispatch here.
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-        x[c] = x[c] / LD[c][c];          // columns c >= nb hold the identity of the padded block: x stays 0
+        if (c < nb) {
+            double v = x[c];
 #pragma unroll
-        for (int c2 = c + 1; c2 < NB; ++c2) x[c2] -= x[c] * LD[c2][c];
+            for (int k = 0; k < c; ++k) v -= x[k] * LD[c][k];
+            x[c] = v / LD[c][c];
+        }
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) {

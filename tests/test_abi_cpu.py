@@ -77,3 +77,41 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 # comments may cite the oracle as the restated spec; code must not import, include, link or dlopen it
                 assert not re.search(r"^\s*(from|import)\s+oracle|oracle_py|libov2oracle|#include\s+\"[^\"]*oracle", txt, re.M), f
+
+
+def test_no_kernel_uses_scratch():
+    """every gfx950 kernel embedded in libov2hip.so must have private_segment_fixed_size == 0: on this runtime a
+    dispatch that needs scratch (register spills, dynamically indexed local arrays) stalls for milliseconds in
+    queue-scratch management -- a silent 5-10x slowdown of the BA path when it happened."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "ov2slam_amd", "lib", "libov2hip.so")
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("library or LLVM tools not present")
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        data = open(fat, "rb").read()
+        offs = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+        assert offs, "no offload bundle found in the library"
+        n_kernels, bad = 0, []
+        for k, o in enumerate(offs):
+            b, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"b{k}.co")
+            open(b, "wb").write(data[o:offs[k + 1] if k + 1 < len(offs) else len(data)])
+            subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={b}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.search(r"\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+                if m:
+                    n_kernels += 1
+                    if int(m.group(1)) > 0:
+                        bad.append((name, int(m.group(1))))
+        assert n_kernels > 40
+        assert not bad, f"kernels using scratch: {bad}"
