@@ -1098,12 +1098,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restric
 // L_D goes to a side buffer (the rows below are still reading the unfactored block from A).  (B) the trailing matrix
 // gets A22 -= L21 L21^T on the matrix cores: one wave per 16 x 16 tile of the lower triangle, eight
 // v_mfma_f64_16x16x4_f64 per tile (operands straight from L2: lanes of one k read 16 consecutive doubles), plus the
-// rhs row.  Then one workgroup does the blocked backward substitution.  m = 480: 1.52 -> 0.77 ms per factorisation
+// rhs row.  Then one workgroup does the blocked backward substitution.  m = 480: 1.52 -> ~0.6 ms per factorisation
 // + solve against the one-workgroup kernel above; no upper limit on m any more.
 typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
 #define CHOL_NB 32
-#define CHOL_MULTI_MIN 320   // measured: at m = 250 the 16 extra launches cost what the kernels save (3.4 vs 3.6 ms per
-                             // 3-iteration minimize); at m = 480 the multi-workgroup path wins 9.9 -> 8.0 ms
+#define CHOL_MULTI_MIN 192   // measured (3-iteration minimize): m = 250: 3.28 -> 3.08 ms, m = 480: 9.9 -> 6.9 ms against the
+                             // one-workgroup kernel; below ~6 panels the extra launches are not worth it
 
 __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ A, double *__restrict__ rhs,
                                                            double *__restrict__ Dbuf, int m, int k0, int *__restrict__ flags)
@@ -1727,7 +1727,8 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
         }
         const auto tb = tnow();
         if (d.m > 0) {
-            if (d.m >= CHOL_MULTI_MIN) {
+            static const int chol_multi_min = getenv("OV2_CHOL_MULTI_MIN") ? atoi(getenv("OV2_CHOL_MULTI_MIN")) : CHOL_MULTI_MIN;
+            if (d.m >= chol_multi_min) {
                 // right-looking, two launches per panel (trailing update on the matrix cores), then the backward pass
                 for (int k0 = 0; k0 < d.m; k0 += CHOL_NB) {
                     const int nb = std::min(CHOL_NB, d.m - k0), below = d.m - (k0 + nb) + 1;
