@@ -356,58 +356,8 @@ __global__ __launch_bounds__(256) void ba_max_kernel(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K_COLNORM: squared column norms and J'r.  One thread per landmark; F side aggregated over runs of equal pose.
+// K_COLNORM helpers / scaling
 
-__device__ inline void flush_cols(double *sqn, double *grad, int base, const double *s, const double *g)
-{
-    for (int c = 0; c < 6; ++c) {
-        atomicAdd(&sqn[base + c], s[c]);
-        atomicAdd(&grad[base + c], g[c]);
-    }
-}
-
-__global__ __launch_bounds__(64) void ba_colnorm_kernel(ba_dev d)
-{
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    if (l >= d.n_e) return;
-    const int e = d.e, ne = d.n_e * e;
-    double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
-    double sk[6], gk[6], sa[6] = {0, 0, 0, 0, 0, 0}, ga[6] = {0, 0, 0, 0, 0, 0};
-    int cur = -1, fa_seen = -1;
-    for (int c = 0; c < 6; ++c) { sk[c] = 0; gk[c] = 0; }
-    for (int r = d.row_ptr[l]; r < d.row_ptr[l + 1]; ++r) {
-        const double *Je = d.Je + (size_t)r * 2 * e, *Jf = d.Jf + (size_t)r * 24;
-        const double r0 = d.res[2 * r], r1 = d.res[2 * r + 1];
-        for (int c = 0; c < e; ++c) {
-            se[c] += Je[c] * Je[c] + Je[e + c] * Je[e + c];
-            ge[c] += Je[c] * r0 + Je[e + c] * r1;
-        }
-        const int fk = d.fk[r], fa = d.fa[r];
-        if (fk >= 0) {
-            if (fk != cur) {
-                if (cur >= 0) flush_cols(d.sqn, d.grad, ne + cur * 6, sk, gk);
-                for (int c = 0; c < 6; ++c) { sk[c] = 0; gk[c] = 0; }
-                cur = fk;
-            }
-            for (int c = 0; c < 6; ++c) {
-                sk[c] += Jf[c] * Jf[c] + Jf[6 + c] * Jf[6 + c];
-                gk[c] += Jf[c] * r0 + Jf[6 + c] * r1;
-            }
-        }
-        if (fa >= 0) {
-            fa_seen = fa;
-            for (int c = 0; c < 6; ++c) {
-                sa[c] += Jf[12 + c] * Jf[12 + c] + Jf[18 + c] * Jf[18 + c];
-                ga[c] += Jf[12 + c] * r0 + Jf[18 + c] * r1;
-            }
-        }
-    }
-    if (cur >= 0) flush_cols(d.sqn, d.grad, ne + cur * 6, sk, gk);
-    if (fa_seen >= 0) flush_cols(d.sqn, d.grad, ne + fa_seen * 6, sa, ga);
-    for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
-}
-
-// iteration 0: scale = 1/(1+sqrt(|col|^2)) (trust_region_minimizer.cc:261-276), keep the unscaled gradient
 __global__ void ba_make_scale_kernel(ba_dev d)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,157 +403,9 @@ __global__ void ba_sinit_kernel(ba_dev d)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K_SCHUR: SchurEliminator::Eliminate per landmark chunk (schur_eliminator_impl.h:179-308)
-
-// add a 6x6 block B[i*6+j] = d2/(p_i, q_j) into column-major S at block (fp, fq); only the lower triangle of S is
-// read by the factorisation, so off-diagonal blocks go to (max, min) with the matching transpose.
-__device__ inline void add_block(double *S, int m, int fp, int fq, const double *B, double sign)
-{
-    if (fp >= fq) {
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < 6; ++j) {
-                if (fp == fq && i < j) continue;
-                atomicAdd(&S[(size_t)(fq * 6 + j) * m + fp * 6 + i], sign * B[i * 6 + j]);
-            }
-    } else {
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < 6; ++j) atomicAdd(&S[(size_t)(fp * 6 + i) * m + fq * 6 + j], sign * B[i * 6 + j]);
-    }
-}
+// shared device helpers of the landmark kernels (SchurEliminator::Eliminate, schur_eliminator_impl.h:179-308)
 
 #define BA_MAX_RUNS 40   // distinct free observing poses per landmark handled in registers/scratch per thread
-
-template <int E>
-__global__ __launch_bounds__(64) void ba_schur_kernel(ba_dev d, double *__restrict__ Wbuf /* n_e x wstride x 6E */,
-                                                      int *__restrict__ Wf /* n_e x wstride */, int wstride)
-{
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    if (l >= d.n_e) return;
-    const int r0 = d.row_ptr[l], r1 = d.row_ptr[l + 1];
-    double ete[E * E], g[E];
-    for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
-    for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] = dv * dv; g[i] = 0.0; }
-    for (int r = r0; r < r1; ++r) {
-        const double *Je = d.Je + (size_t)r * 2 * E;
-        const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
-        for (int i = 0; i < E; ++i) {
-            for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
-            g[i] += Je[i] * b0 + Je[E + i] * b1;
-        }
-    }
-    // inverse of the SPD E'E (closed form; invert_psd_matrix.h uses an LLT solve -- same matrix)
-    double ie[E * E], ieg[E];
-    if (E == 1) {
-        ie[0] = 1.0 / ete[0];
-    } else {
-        const double a = ete[0], b = ete[1], c = ete[2], dd = ete[4], ee = ete[5], f = ete[8];
-        const double A = dd * f - ee * ee, B = c * ee - b * f, C = b * ee - c * dd;
-        const double det = a * A + b * B + c * C;
-        const double id = 1.0 / det;
-        ie[0] = A * id; ie[1] = B * id; ie[2] = C * id;
-        ie[3] = B * id; ie[4] = (a * f - c * c) * id; ie[5] = (b * c - a * ee) * id;
-        ie[6] = C * id; ie[7] = ie[5]; ie[8] = (a * dd - b * b) * id;
-    }
-    for (int i = 0; i < E; ++i) {
-        double s = 0;
-        for (int j = 0; j < E; ++j) s += ie[i * E + j] * g[j];
-        ieg[i] = s;
-    }
-    for (int i = 0; i < E * E; ++i) d.iete[(size_t)l * E * E + i] = ie[i];
-    for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
-
-    // second pass: per (landmark, pose) run aggregation, then the outer products
-    double *W = Wbuf + (size_t)l * wstride * 6 * E;
-    int *wf = Wf + (size_t)l * wstride;
-    int nruns = 0, cur = -1, fa_seen = -1;
-    double Wk[6 * E], vk[6], FkFk[36], FkFa[36];
-    double Wa[6 * E], va[6], FaFa[36];
-    for (int i = 0; i < 6 * E; ++i) { Wk[i] = 0; Wa[i] = 0; }
-    for (int i = 0; i < 6; ++i) { vk[i] = 0; va[i] = 0; }
-    for (int i = 0; i < 36; ++i) { FkFk[i] = 0; FkFa[i] = 0; FaFa[i] = 0; }
-    auto flush_run = [&](int f) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&d.rhs[f * 6 + i], vk[i]);
-        add_block(d.S, d.m, f, f, FkFk, 1.0);
-        if (fa_seen >= 0) add_block(d.S, d.m, f, fa_seen, FkFa, 1.0);
-        if (nruns < wstride - 1) {
-            for (int i = 0; i < 6 * E; ++i) W[nruns * 6 * E + i] = Wk[i];
-            wf[nruns] = f;
-            ++nruns;
-        }
-        for (int i = 0; i < 6 * E; ++i) Wk[i] = 0;
-        for (int i = 0; i < 6; ++i) vk[i] = 0;
-        for (int i = 0; i < 36; ++i) { FkFk[i] = 0; FkFa[i] = 0; }
-    };
-    for (int r = r0; r < r1; ++r) {
-        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
-        double sj[2] = {d.res[2 * r], d.res[2 * r + 1]};
-        for (int i = 0; i < E; ++i) { sj[0] -= Je[i] * ieg[i]; sj[1] -= Je[E + i] * ieg[i]; }
-        const int fk = d.fk[r], fa = d.fa[r];
-        if (fa >= 0) fa_seen = fa;
-        if (fk >= 0) {
-            if (fk != cur) {
-                if (cur >= 0) flush_run(cur);
-                cur = fk;
-            }
-            for (int i = 0; i < 6; ++i) {
-                for (int c = 0; c < E; ++c) Wk[i * E + c] += Jf[i] * Je[c] + Jf[6 + i] * Je[E + c];
-                vk[i] += Jf[i] * sj[0] + Jf[6 + i] * sj[1];
-                for (int j = 0; j < 6; ++j) FkFk[i * 6 + j] += Jf[i] * Jf[j] + Jf[6 + i] * Jf[6 + j];
-                if (fa >= 0)
-                    for (int j = 0; j < 6; ++j) FkFa[i * 6 + j] += Jf[i] * Jf[12 + j] + Jf[6 + i] * Jf[18 + j];
-            }
-        }
-        if (fa >= 0) {
-            for (int i = 0; i < 6; ++i) {
-                for (int c = 0; c < E; ++c) Wa[i * E + c] += Jf[12 + i] * Je[c] + Jf[18 + i] * Je[E + c];
-                va[i] += Jf[12 + i] * sj[0] + Jf[18 + i] * sj[1];
-                for (int j = 0; j < 6; ++j) FaFa[i * 6 + j] += Jf[12 + i] * Jf[12 + j] + Jf[18 + i] * Jf[18 + j];
-            }
-        }
-    }
-    if (cur >= 0) flush_run(cur);
-    if (fa_seen >= 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&d.rhs[fa_seen * 6 + i], va[i]);
-        add_block(d.S, d.m, fa_seen, fa_seen, FaFa, 1.0);
-        for (int i = 0; i < 6 * E; ++i) W[nruns * 6 * E + i] = Wa[i];
-        wf[nruns] = fa_seen;
-        ++nruns;
-    }
-    // S -= (E'F)' (E'E)^-1 (E'F) over all pairs of this landmark's pose blocks (ChunkOuterProduct)
-    for (int p = 0; p < nruns; ++p) {
-        double T[6 * E];  // W_p * ie  (6 x E)
-        for (int i = 0; i < 6; ++i)
-            for (int c = 0; c < E; ++c) {
-                double s = 0;
-                for (int k = 0; k < E; ++k) s += W[p * 6 * E + i * E + k] * ie[k * E + c];
-                T[i * E + c] = s;
-            }
-        for (int q = p; q < nruns; ++q) {
-            double B[36];
-            for (int i = 0; i < 6; ++i)
-                for (int j = 0; j < 6; ++j) {
-                    double s = 0;
-                    for (int c = 0; c < E; ++c) s += T[i * E + c] * W[q * 6 * E + j * E + c];
-                    B[i * 6 + j] = s;
-                }
-            add_block(d.S, d.m, wf[p], wf[q], B, -1.0);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// 16-lane-group kernels: one DPP row (16 lanes) per landmark, lane = residual row (chunks of 16), coalesced row
-// loads, reductions by DPP inside the row (no LDS, no cross-wave traffic).  These replace the thread-per-landmark
-// kernels above on the hot path (kept for reference / fallback of exotic shapes).
-
-__device__ __forceinline__ double readlane_f64(double v, int lane)   // lane must be wave-uniform
-{
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | lo);
-}
-
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -613,7 +415,14 @@ __device__ __forceinline__ double dpp_f64(double v)
     return __longlong_as_double(((long long)hi << 32) | lo);
 }
 
-// sum over the 16 lanes of a DPP row; every lane of the row receives the total (fixed order => reproducible)
+__device__ __forceinline__ double readlane_f64(double v, int lane)   // lane must be wave-uniform
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double row_sum(double v)
 {
     v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -692,184 +501,10 @@ __global__ __launch_bounds__(256) void ba_colnorm_pose_kernel(ba_dev d, const in
     }
 }
 
-// Schur elimination, 16 lanes per landmark.  W (= F'E per pose cell) goes through dynamic LDS.
-// f64 atomics are request-rate bound when every lane hits its own 64-B line (measured: ~20 G adds/s), so all 16
-// lanes of a group work on ONE 6x6 block at a time, consecutive lanes on consecutive addresses of a column of the
-// column-major S: a block costs ~3 memory-side requests per 16 adds instead of 16.
+// lower-triangle element order of a symmetric 6x6 block
 __constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
 __constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
 
-template <int E>
-__global__ __launch_bounds__(256) void ba_schur16_kernel(ba_dev d, int wstride)
-{
-    extern __shared__ __attribute__((aligned(16))) double wlds[];
-    constexpr int REC = 6 * E + 2;   // per cell: W (6 x E), F block id, first row of the run (-1 for the anchor cell)
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    const int l = blockIdx.x * (blockDim.x >> 4) + grp;
-    const bool live = l < d.n_e;
-    const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
-    double *W = wlds + (size_t)grp * wstride * REC;
-    const int m = d.m;
-    // ---- pass 1: E'E and E'b
-    double ete[E * E], g[E];
-    for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
-    for (int i = 0; i < E; ++i) g[i] = 0.0;
-    for (int base = r0; base < r1; base += 16) {
-        const int r = base + sub;
-        if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E;
-            const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
-            for (int i = 0; i < E; ++i) {
-                for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
-                g[i] += Je[i] * b0 + Je[E + i] * b1;
-            }
-        }
-    }
-    for (int i = 0; i < E * E; ++i) ete[i] = row_sum(ete[i]);
-    for (int i = 0; i < E; ++i) g[i] = row_sum(g[i]);
-    if (live) for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] += dv * dv; }
-    else for (int i = 0; i < E; ++i) ete[i * E + i] = 1.0;
-    double ie[E * E], ieg[E];
-    invert_ete<E>(ete, ie);
-    for (int i = 0; i < E; ++i) {
-        double sacc = 0;
-        for (int j = 0; j < E; ++j) sacc += ie[i * E + j] * g[j];
-        ieg[i] = sacc;
-    }
-    if (live && sub == 0) {
-        for (int i = 0; i < E * E; ++i) d.iete[(size_t)l * E * E + i] = ie[i];
-        for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
-    }
-    // ---- pass 2a: W = F'E of every pose cell -> LDS (observing cells by the first row of each run, anchor by row_sum)
-    double Wa[6 * E];
-    for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
-    int fa_seen = -1, ncell = 0;
-    for (int base = r0; base < r1; base += 16) {
-        const int r = base + sub;
-        const bool have = r < r1;
-        const int fk = have ? d.fk[r] : -1, fa = have ? d.fa[r] : -1;
-        const bool leader = have && fk >= 0 && (r == r0 || d.fk[r - 1] != fk);
-        const unsigned long long lmk = __ballot(leader);
-        const unsigned rowmask = (unsigned)((lmk >> (threadIdx.x & 48)) & 0xffffu);
-        const int slot = ncell + __popc(rowmask & ((1u << sub) - 1u));
-        if (have) {
-            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
-            if (fa >= 0) {
-                fa_seen = fa;
-                for (int i = 0; i < 6; ++i)
-                    for (int c = 0; c < E; ++c) Wa[i * E + c] += Jf[12 + i] * Je[c] + Jf[18 + i] * Je[E + c];
-            }
-            if (leader && slot < wstride - 1) {
-                double Wk[6 * E];
-                for (int i = 0; i < 6 * E; ++i) Wk[i] = 0.0;
-                for (int r2 = r; r2 < r1 && d.fk[r2] == fk; ++r2) {
-                    const double *Je2 = d.Je + (size_t)r2 * 2 * E, *J2 = d.Jf + (size_t)r2 * 24;
-                    for (int i = 0; i < 6; ++i)
-                        for (int c = 0; c < E; ++c) Wk[i * E + c] += J2[i] * Je2[c] + J2[6 + i] * Je2[E + c];
-                }
-                for (int i = 0; i < 6 * E; ++i) W[slot * REC + i] = Wk[i];
-                W[slot * REC + 6 * E] = (double)fk;
-                W[slot * REC + 6 * E + 1] = (double)r;
-            }
-        }
-        ncell += __popc(rowmask);
-    }
-    for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
-    int fam = fa_seen;
-    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0xB1, 0xf, 0xf, false));
-    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x4E, 0xf, 0xf, false));
-    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x141, 0xf, 0xf, false));
-    fam = max(fam, __builtin_amdgcn_update_dpp(-1, fam, 0x140, 0xf, 0xf, false));
-    ncell = min(ncell, wstride - 1);
-    const int nobs = ncell;   // observing cells; the anchor cell (if any) comes last
-    if (live && fam >= 0) {
-        if (sub == 0) {
-            for (int i = 0; i < 6 * E; ++i) W[ncell * REC + i] = Wa[i];
-            W[ncell * REC + 6 * E] = (double)fam;
-            W[ncell * REC + 6 * E + 1] = -1.0;
-        }
-        ++ncell;
-    }
-    __syncthreads();
-    // ---- pass 2b: F'F, F'Fa and F'(b - E (E'E)^-1 g) of every cell, the 16 lanes share one cell at a time
-    for (int c = 0; c < nobs; ++c) {
-        const int fk = (int)W[c * REC + 6 * E], rs = (int)W[c * REC + 6 * E + 1];
-        for (int t = sub; t < 63; t += 16) {
-            int i, j, kind;   // kind 0: rhs[i] ; 1: F'F lower (i,j) ; 2: F'Fa (i,j)
-            if (t < 6) { kind = 0; i = t; j = 0; }
-            else if (t < 27) { kind = 1; i = c_tri_i[t - 6]; j = c_tri_j[t - 6]; }
-            else { kind = 2; i = (t - 27) % 6; j = (t - 27) / 6; }
-            if (kind == 2 && fam < 0) continue;
-            double v = 0.0;
-            for (int r2 = rs; r2 < r1 && d.fk[r2] == fk; ++r2) {
-                const double *J2 = d.Jf + (size_t)r2 * 24;
-                if (kind == 0) {
-                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
-                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
-                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
-                    v += J2[i] * t0 + J2[6 + i] * t1;
-                } else if (kind == 1) {
-                    v += J2[i] * J2[j] + J2[6 + i] * J2[6 + j];
-                } else if (d.fa[r2] >= 0) {
-                    v += J2[i] * J2[12 + j] + J2[6 + i] * J2[18 + j];
-                }
-            }
-            if (kind == 0) atomicAdd(&d.rhs[fk * 6 + i], v);
-            else if (kind == 1) atomicAdd(&d.S[(size_t)(fk * 6 + j) * m + fk * 6 + i], v);
-            else if (fk >= fam) atomicAdd(&d.S[(size_t)(fam * 6 + j) * m + fk * 6 + i], v);
-            else atomicAdd(&d.S[(size_t)(fk * 6 + i) * m + fam * 6 + j], v);
-        }
-    }
-    if (live && fam >= 0) {   // anchor cell: sums over every row of the landmark
-        for (int t = sub; t < 27; t += 16) {
-            const int i = (t < 6) ? t : c_tri_i[t - 6], j = (t < 6) ? 0 : c_tri_j[t - 6];
-            double v = 0.0;
-            for (int r2 = r0; r2 < r1; ++r2) {
-                if (d.fa[r2] < 0) continue;
-                const double *J2 = d.Jf + (size_t)r2 * 24;
-                if (t < 6) {
-                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
-                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
-                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
-                    v += J2[12 + i] * t0 + J2[18 + i] * t1;
-                } else {
-                    v += J2[12 + i] * J2[12 + j] + J2[18 + i] * J2[18 + j];
-                }
-            }
-            if (t < 6) atomicAdd(&d.rhs[fam * 6 + i], v);
-            else atomicAdd(&d.S[(size_t)(fam * 6 + j) * m + fam * 6 + i], v);
-        }
-    }
-    // ---- pass 2c: S -= W_p (E'E)^-1 W_q^T over all cell pairs p <= q (ChunkOuterProduct), one block at a time
-    for (int p = 0; p < ncell; ++p) {
-        const double *Wp = W + p * REC;
-        const int fp = (int)Wp[6 * E];
-        for (int q = p; q < ncell; ++q) {
-            const double *Wq = W + q * REC;
-            const int fq = (int)Wq[6 * E];
-            if (p == q) {
-                for (int t = sub; t < 21; t += 16) {
-                    const int i = c_tri_i[t], j = c_tri_j[t];
-                    double v = 0.0;
-                    for (int k = 0; k < E; ++k)
-                        for (int cc = 0; cc < E; ++cc) v += Wp[i * E + k] * ie[k * E + cc] * Wq[j * E + cc];
-                    atomicAdd(&d.S[(size_t)(fp * 6 + j) * m + fp * 6 + i], -v);
-                }
-            } else {
-                for (int t = sub; t < 36; t += 16) {
-                    // element (p_i, q_j); lanes run along the contiguous direction of the lower-triangle copy
-                    int i, j;
-                    if (fp >= fq) { i = t % 6; j = t / 6; } else { j = t % 6; i = t / 6; }
-                    double v = 0.0;
-                    for (int k = 0; k < E; ++k)
-                        for (int cc = 0; cc < E; ++cc) v += Wp[i * E + k] * ie[k * E + cc] * Wq[j * E + cc];
-                    if (fp >= fq) atomicAdd(&d.S[(size_t)(fq * 6 + j) * m + fp * 6 + i], -v);
-                    else atomicAdd(&d.S[(size_t)(fp * 6 + i) * m + fq * 6 + j], -v);
-                }
-            }
-        }
-    }
-}
 
 // back-substitution + model cost change, 16 lanes per landmark
 template <int E>
@@ -1258,47 +893,6 @@ __global__ __launch_bounds__(256) void ba_chol_backward_kernel(const double *__r
     for (int i = tid; i < m; i += nth) rhs[i] = zb[i];
 }
 
-// ------------------------------------------------------------------------------------------------------
-// K_BACKSUB: y_e per landmark (schur_eliminator_impl.h:311-377), step = -[y; z], model cost change partials
-
-template <int E>
-__global__ __launch_bounds__(64) void ba_backsub_kernel(ba_dev d, double *__restrict__ part)
-{
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    if (l >= d.n_e) return;
-    const int ne = d.n_e * E;
-    const int r0 = d.row_ptr[l], r1 = d.row_ptr[l + 1];
-    double acc[E];
-    for (int i = 0; i < E; ++i) acc[i] = 0.0;
-    for (int r = r0; r < r1; ++r) {
-        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
-        double sj[2] = {d.res[2 * r], d.res[2 * r + 1]};
-        const int fk = d.fk[r], fa = d.fa[r];
-        if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; sj[0] -= Jf[c] * z; sj[1] -= Jf[6 + c] * z; }
-        if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; sj[0] -= Jf[12 + c] * z; sj[1] -= Jf[18 + c] * z; }
-        for (int i = 0; i < E; ++i) acc[i] += Je[i] * sj[0] + Je[E + i] * sj[1];
-    }
-    double y[E];
-    for (int i = 0; i < E; ++i) {
-        double s = 0;
-        for (int j = 0; j < E; ++j) s += d.iete[(size_t)l * E * E + i * E + j] * acc[j];
-        y[i] = s;
-        d.step[l * E + i] = -s;
-    }
-    // model_cost_change = -sum m.(r + m/2), m = J step = -(E y + F z)
-    double mc = 0.0;
-    for (int r = r0; r < r1; ++r) {
-        const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
-        double m0 = 0.0, m1 = 0.0;
-        for (int i = 0; i < E; ++i) { m0 -= Je[i] * y[i]; m1 -= Je[E + i] * y[i]; }
-        const int fk = d.fk[r], fa = d.fa[r];
-        if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; m0 -= Jf[c] * z; m1 -= Jf[6 + c] * z; }
-        if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; m0 -= Jf[12 + c] * z; m1 -= Jf[18 + c] * z; }
-        mc += m0 * (d.res[2 * r] + m0 / 2.0) + m1 * (d.res[2 * r + 1] + m1 / 2.0);
-    }
-    part[l] = mc;
-    (void)ne;
-}
 
 __global__ void ba_zstep_kernel(ba_dev d)
 {
@@ -1525,6 +1119,333 @@ __global__ __launch_bounds__(256) void bb_poseptr_kernel(const unsigned long lon
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Schur complement without atomics.  Structure (once per program): the pose CELLS of every landmark (one per run of
+// rows of the same free observing pose, plus the anchor pose of an inverse-depth landmark) in CSR form, every unordered
+// cell pair of a landmark keyed by its pose pair and sorted (so each off-diagonal 6x6 block of S owns a contiguous
+// list of (cell, cell) entries), and the cells of every pose.  Per LM iteration: (1) per landmark: (E'E + D)^-1, E'b and
+// per cell W = F'E, F'F, F'Fa, F'(b - E (E'E)^-1 E'b) -> global; (2) one wave per diagonal block gathers its cells,
+// one wave per off-diagonal block gathers its entries.  Every block of S has exactly one writer, so S and the rhs are
+// bitwise reproducible, and the 10 M f64 atomics per iteration of the previous form (its bound: atomic request rate)
+// are gone.
+
+struct ba_cells {
+    const int *cell_ptr;      // n_e + 1
+    const int *cell_f;        // pose block of the cell
+    const int *cell_row;      // first row of its run, -1 = anchor cell (always the last cell of its landmark)
+    const int *cell_lm;       // landmark block of the cell
+    double *W, *FF, *FFa, *rhsc;   // per cell: 6E, 21, 36, 6 doubles
+};
+
+__global__ __launch_bounds__(256) void bs_count_kernel(ba_dev d, int *__restrict__ ncell, int *__restrict__ npair)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l > d.n_e) return;
+    int n = 0;
+    if (l < d.n_e) {
+        int cur = -2, anchor = 0;
+        for (int r = d.row_ptr[l]; r < d.row_ptr[l + 1]; ++r) {
+            const int fk = d.fk[r];
+            if (fk >= 0 && fk != cur) { cur = fk; ++n; }
+            if (d.fa[r] >= 0) anchor = 1;
+        }
+        n += anchor;
+    }
+    ncell[l] = n;                 // entry n_e = 0, so the exclusive scans end with the totals
+    npair[l] = n * (n - 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void bs_cells_kernel(ba_dev d, const int *__restrict__ cell_ptr,
+                                                       const int *__restrict__ pair_off, int *__restrict__ cell_f,
+                                                       int *__restrict__ cell_row, int *__restrict__ cell_lm,
+                                                       unsigned long long *__restrict__ pkey,
+                                                       unsigned long long *__restrict__ ckey)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.n_e) return;
+    const int c0 = cell_ptr[l], nc = cell_ptr[l + 1] - c0;
+    int c = 0, cur = -2, fam = -1;
+    for (int r = d.row_ptr[l]; r < d.row_ptr[l + 1]; ++r) {
+        const int fk = d.fk[r];
+        if (fk >= 0 && fk != cur) { cur = fk; cell_f[c0 + c] = fk; cell_row[c0 + c] = r; cell_lm[c0 + c] = l; ++c; }
+        if (d.fa[r] >= 0) fam = d.fa[r];
+    }
+    if (fam >= 0) { cell_f[c0 + c] = fam; cell_row[c0 + c] = -1; cell_lm[c0 + c] = l; ++c; }
+    for (int p = 0; p < nc; ++p) ckey[c0 + p] = ((unsigned long long)(unsigned)cell_f[c0 + p] << 32) | (unsigned)(c0 + p);
+    int o = pair_off[l];
+    for (int p = 0; p < nc; ++p)
+        for (int q = p + 1; q < nc; ++q, ++o) {
+            const int fp = cell_f[c0 + p], fq = cell_f[c0 + q];
+            const int hi = fp >= fq ? p : q, lo = fp >= fq ? q : p;   // cell of the larger pose block first
+            // (pose hi : 11 | pose lo : 11 | cell hi : 21 | cell lo : 21) -- one 64-bit key, so the sort needs no payload
+            pkey[o] = ((unsigned long long)(unsigned)cell_f[c0 + hi] << 53) | ((unsigned long long)(unsigned)cell_f[c0 + lo] << 42) |
+                      ((unsigned long long)(unsigned)(c0 + hi) << 21) | (unsigned long long)(unsigned)(c0 + lo);
+        }
+}
+
+// boundaries of the pose-sorted cell list -> pcell_ptr (n_f + 1) and the cell ids
+__global__ __launch_bounds__(256) void bs_posecells_kernel(const unsigned long long *__restrict__ ck, int n, int n_f,
+                                                           int *__restrict__ pcell_ptr, int *__restrict__ pcell_ent)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int f = (int)(ck[j] >> 32);
+    pcell_ent[j] = (int)(ck[j] & 0xffffffffull);
+    if (j == 0 || (int)(ck[j - 1] >> 32) != f) pcell_ptr[f] = j;
+    if (j == n - 1) pcell_ptr[n_f] = n;
+}
+
+// segment heads of the sorted pair list (a new pose pair starts) ...
+__global__ __launch_bounds__(256) void bs_heads_kernel(const unsigned long long *__restrict__ pk, int n, int *__restrict__ head)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    head[j] = (j < n && (j == 0 || (pk[j] >> 42) != (pk[j - 1] >> 42))) ? 1 : 0;   // entry n = 0: its rank is the pair count
+}
+
+// ... and, from their exclusive ranks, the start of every pair's segment (+ the end of the last one)
+__global__ __launch_bounds__(256) void bs_segs_kernel(const unsigned long long *__restrict__ pk, int n,
+                                                      const int *__restrict__ head, const int *__restrict__ rank,
+                                                      int *__restrict__ seg_start, unsigned *__restrict__ pair_key)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    if (head[j]) { seg_start[rank[j]] = j; pair_key[rank[j]] = (unsigned)(pk[j] >> 42); }
+    if (j == n - 1) seg_start[rank[n]] = n;
+}
+
+// (1) per landmark, 16 lanes: (E'E + D)^-1, (E'E)^-1 E'b, and per cell W / F'F / F'Fa / rhs contribution
+template <int E>
+__global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
+{
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int l = blockIdx.x * 16 + grp;
+    const bool live = l < d.n_e;
+    const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
+    double ete[E * E], g[E];
+    for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
+    for (int i = 0; i < E; ++i) g[i] = 0.0;
+    for (int base = r0; base < r1; base += 16) {
+        const int r = base + sub;
+        if (r < r1) {
+            const double *Je = d.Je + (size_t)r * 2 * E;
+            const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+            for (int i = 0; i < E; ++i) {
+                for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
+                g[i] += Je[i] * b0 + Je[E + i] * b1;
+            }
+        }
+    }
+    for (int i = 0; i < E * E; ++i) ete[i] = row_sum(ete[i]);
+    for (int i = 0; i < E; ++i) g[i] = row_sum(g[i]);
+    if (live) for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] += dv * dv; }
+    else for (int i = 0; i < E; ++i) ete[i * E + i] = 1.0;
+    double ie[E * E], ieg[E];
+    invert_ete<E>(ete, ie);
+    for (int i = 0; i < E; ++i) {
+        double sacc = 0;
+        for (int j = 0; j < E; ++j) sacc += ie[i * E + j] * g[j];
+        ieg[i] = sacc;
+    }
+    if (live && sub == 0) {
+        for (int i = 0; i < E * E; ++i) d.iete[(size_t)l * E * E + i] = ie[i];
+        for (int i = 0; i < E; ++i) d.ieg[(size_t)l * E + i] = ieg[i];
+    }
+    if (!live) return;
+    const int c0 = C.cell_ptr[l], nc = C.cell_ptr[l + 1] - c0;
+    const bool has_anchor = nc > 0 && C.cell_row[c0 + nc - 1] < 0;
+    const int nobs = has_anchor ? nc - 1 : nc;
+    // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once and keeps all of the
+    // cell's quantities in registers: W = F'E (6E), F'F (lower 21), F'Fa (36), F'(b - E (E'E)^-1 E'b) (6).  (A first
+    // version shared one cell among the 16 lanes, cell after cell: four serial passes over the rows per cell.)
+    for (int c = sub; c < nobs; c += 16) {
+        const int fk = C.cell_f[c0 + c];
+        double Wk[6 * E], rh[6], ff[21], ffa[36];
+#pragma unroll
+        for (int i = 0; i < 6 * E; ++i) Wk[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rh[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) ff[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) ffa[i] = 0.0;
+        for (int r2 = C.cell_row[c0 + c]; r2 < r1 && d.fk[r2] == fk; ++r2) {
+            double J2[24], Je2[2 * E];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) J2[i] = d.Jf[(size_t)r2 * 24 + i];
+#pragma unroll
+            for (int i = 0; i < 2 * E; ++i) Je2[i] = d.Je[(size_t)r2 * 2 * E + i];
+            double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
+#pragma unroll
+            for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                rh[i] += J2[i] * t0 + J2[6 + i] * t1;
+#pragma unroll
+                for (int k = 0; k < E; ++k) Wk[i * E + k] += J2[i] * Je2[k] + J2[6 + i] * Je2[E + k];
+            }
+#pragma unroll
+            for (int t = 0; t < 21; ++t) ff[t] += J2[c_tri_i[t]] * J2[c_tri_j[t]] + J2[6 + c_tri_i[t]] * J2[6 + c_tri_j[t]];
+            if (d.fa[r2] >= 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ffa[i * 6 + j] += J2[i] * J2[12 + j] + J2[6 + i] * J2[18 + j];
+            }
+        }
+        const size_t cc = (size_t)(c0 + c);
+#pragma unroll
+        for (int i = 0; i < 6 * E; ++i) C.W[cc * 6 * E + i] = Wk[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) C.rhsc[cc * 6 + i] = rh[i];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) C.FF[cc * 21 + i] = ff[i];
+        if (has_anchor) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) C.FFa[cc * 36 + i] = ffa[i];
+        }
+    }
+    if (has_anchor) {   // W of the anchor cell: summed over all rows by the group
+        double Wa[6 * E];
+        for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
+        for (int base = r0; base < r1; base += 16) {
+            const int r = base + sub;
+            if (r < r1 && d.fa[r] >= 0) {
+                const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+                for (int i = 0; i < 6; ++i)
+                    for (int k = 0; k < E; ++k) Wa[i * E + k] += Jf[12 + i] * Je[k] + Jf[18 + i] * Je[E + k];
+            }
+        }
+        for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
+        if (sub == 0) for (int i = 0; i < 6 * E; ++i) C.W[(size_t)(c0 + nc - 1) * 6 * E + i] = Wa[i];
+    }
+    if (has_anchor) {   // anchor cell: sums over every row of the landmark that carries the anchor block
+        for (int t = sub; t < 27; t += 16) {
+            const int i = (t < 6) ? t : c_tri_i[t - 6], j = (t < 6) ? 0 : c_tri_j[t - 6];
+            double v = 0.0;
+            for (int r2 = r0; r2 < r1; ++r2) {
+                if (d.fa[r2] < 0) continue;
+                const double *J2 = d.Jf + (size_t)r2 * 24;
+                if (t < 6) {
+                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
+                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
+                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
+                    v += J2[12 + i] * t0 + J2[18 + i] * t1;
+                } else {
+                    v += J2[12 + i] * J2[12 + j] + J2[18 + i] * J2[18 + j];
+                }
+            }
+            if (t < 6) C.rhsc[(size_t)(c0 + nc - 1) * 6 + i] = v;
+            else C.FF[(size_t)(c0 + nc - 1) * 21 + (t - 6)] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_total(double v)
+{
+    v = row_sum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// (2a) one workgroup per pose block: diagonal block of S (lower triangle) and its rhs segment, summed over the pose's
+// cells.  Threads stride over the cells (a pose has thousands: a serial walk was latency-bound at ~1 us per cell),
+// every thread keeps the 27 partial sums, fixed-order wave + LDS reduction at the end.
+template <int E>
+__global__ __launch_bounds__(256) void bs_diag_kernel(ba_dev d, ba_cells C, const int *__restrict__ pcell_ptr,
+                                                      const int *__restrict__ pcell_ent)
+{
+    __shared__ double red[4][27];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.0;
+    for (int q = pcell_ptr[f] + tid; q < pcell_ptr[f + 1]; q += 256) {
+        const int c = pcell_ent[q];
+        const double *W = C.W + (size_t)c * 6 * E, *ie = d.iete + (size_t)C.cell_lm[c] * E * E;
+        double T[6 * E];   // T = W (E'E)^-1
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int cc = 0; cc < E; ++cc) {
+                double w = 0.0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) w += W[i * E + k] * ie[k * E + cc];
+                T[i * E + cc] = w;
+            }
+#pragma unroll
+        for (int t = 0; t < 21; ++t) {
+            const int i = c_tri_i[t], j = c_tri_j[t];
+            double w = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * W[j * E + cc];
+            acc[t] += C.FF[(size_t)c * 21 + t] - w;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += C.rhsc[(size_t)c * 6 + i];
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const double w = wave_total(acc[t]);
+        if ((tid & 63) == 0) red[tid >> 6][t] = w;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (tid >= 21) d.rhs[f * 6 + tid - 21] = v;                         // ba_sinit zeroed it; this is its only writer
+        else d.S[(size_t)(f * 6 + c_tri_j[tid]) * d.m + f * 6 + c_tri_i[tid]] += v;   // on top of the LM diagonal of ba_sinit
+    }
+}
+
+// (2b) one wave per pose pair (hi > lo): S[hi, lo] = sum over the landmarks seen by both of  -W_hi (E'E)^-1 W_lo^T,
+// plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries.
+template <int E>
+__global__ __launch_bounds__(64) void bs_pair_kernel(ba_dev d, ba_cells C, const int *__restrict__ n_pairs,
+                                                     const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
+                                                     const unsigned long long *__restrict__ pk)
+{
+    const int pidx = blockIdx.x, lane = threadIdx.x;
+    if (pidx >= *n_pairs) return;
+    const int hi = (int)(pair_key[pidx] >> 11), lo = (int)(pair_key[pidx] & 0x7ffu);
+    double acc[36];   // element (i of hi, j of lo) at i + 6 j
+#pragma unroll
+    for (int t = 0; t < 36; ++t) acc[t] = 0.0;
+    const int s0 = seg_start[pidx], s1 = seg_start[pidx + 1];
+    for (int q = s0 + lane; q < s1; q += 64) {
+        const int ch = (int)((pk[q] >> 21) & 0x1fffffull), cl = (int)(pk[q] & 0x1fffffull);
+        const double *Wh = C.W + (size_t)ch * 6 * E, *Wl = C.W + (size_t)cl * 6 * E;
+        const double *ie = d.iete + (size_t)C.cell_lm[ch] * E * E;
+        double T[6 * E];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int cc = 0; cc < E; ++cc) {
+                double w = 0.0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) w += Wh[i * E + k] * ie[k * E + cc];
+                T[i * E + cc] = w;
+            }
+        const bool lo_anchor = C.cell_row[cl] < 0, hi_anchor = C.cell_row[ch] < 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double w = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * Wl[j * E + cc];
+                double v = -w;
+                if (lo_anchor) v += C.FFa[(size_t)ch * 36 + i * 6 + j];        // hi cell observes, lo cell is the anchor
+                else if (hi_anchor) v += C.FFa[(size_t)cl * 36 + j * 6 + i];   // lo cell observes, hi cell is the anchor
+                acc[i + 6 * j] += v;
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 36; ++t) {
+        const double v = wave_total(acc[t]);
+        const int i = t % 6, j = t / 6;
+        if (lane == 0 && (hi != lo || i >= j)) d.S[(size_t)(lo * 6 + j) * d.m + hi * 6 + i] += v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 
 struct dev_buf {
@@ -1546,6 +1467,17 @@ ov2_status dalloc(ov2_ctx *c, size_t &off, T **out, size_t n)
     if (off + bytes > c->ba_arena_cap)
         return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena exhausted (%zu + %zu > %zu)", off, bytes, c->ba_arena_cap);
     *out = (T *)((char *)c->ba_arena + off);
+    off += bytes;
+    return OV2_OK;
+}
+
+template <typename T>
+ov2_status dalloc2(ov2_ctx *c, size_t &off, T **out, size_t n)
+{
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) / 256 * 256;
+    if (off + bytes > c->ba_arena2_cap)
+        return ov2_set_err(c, OV2_ERR_NOMEM, "BA structure arena exhausted (%zu + %zu > %zu)", off, bytes, c->ba_arena2_cap);
+    *out = (T *)((char *)c->ba_arena2 + off);
     off += bytes;
     return OV2_OK;
 }
@@ -1582,14 +1514,18 @@ struct ba_solver {
     const ov2_ba_options *o;
     size_t arena_off = 0;
     ba_dev d;
-    int wstride = 1;             // cells (runs + anchor) reserved per landmark in Wbuf / Wf
     ba_raw raw;                  // the flat problem on the device (uploaded once per solve) + the active flags
     size_t raw_end = 0;          // arena offset behind it: programs are (re)built from here
     const int *rows = nullptr;   // device: sorted row -> original residual index
+    // atomic-free Schur complement: cells, pose -> cells, pose pairs -> (cell, cell) entries (see the bs_* kernels)
+    ba_cells cells;
+    const int *pcell_ptr = nullptr, *pcell_ent = nullptr;
+    const int *n_pairs = nullptr, *seg_start = nullptr, *seg_len = nullptr;
+    const unsigned *pair_key = nullptr;
+    const unsigned long long *pair_val = nullptr;
+    int pair_cap = 0;
     double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states
-    double *Wbuf = nullptr;
     double *chold = nullptr;      // diagonal blocks of the Cholesky factor (multi-workgroup path)
-    int *Wf = nullptr;
     double *chi2_dev = nullptr;
     unsigned char *depth_dev = nullptr;
     int eval_blocks = 0;
@@ -1707,7 +1643,6 @@ ov2_status build_program(ba_solver &S)
     d.m = 6 * d.n_f; d.nc = d.n_e * e + d.m;
     if (h_hdr[BH_RUNS] > BA_MAX_RUNS)
         return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "a landmark is observed by %d free keyframes (max %d)", h_hdr[BH_RUNS], BA_MAX_RUNS);
-    S.wstride = h_hdr[BH_RUNS] + 1;
     d.type = O.type; d.pose = O.pose; d.lm = O.lm; d.anch = O.anch; d.eb = O.eb; d.fk = O.fk; d.fa = O.fa;
     d.uv = O.uv; d.inv_sigma = O.isg; d.auv = O.auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
     S.rows = rows; S.pose_ptr = pose_ptr; S.pose_ent = pose_ent;
@@ -1722,8 +1657,6 @@ ov2_status build_program(ba_solver &S)
     AL(scal, SC_N + 2); AL(flags, 4);
 #undef AL
     if ((s = dalloc(c, S.arena_off, &S.chold, (size_t)(d.m / CHOL_NB + 1) * CHOL_NB * CHOL_NB)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.Wbuf, (size_t)d.n_e * S.wstride * 6 * e)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.Wf, (size_t)d.n_e * S.wstride)) != OV2_OK) return s;
     if ((s = dalloc(c, S.arena_off, &S.chi2_dev, (size_t)n)) != OV2_OK) return s;     // indexed by ORIGINAL residual
     if ((s = dalloc(c, S.arena_off, &S.depth_dev, (size_t)n)) != OV2_OK) return s;
     const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * e;
@@ -1731,6 +1664,79 @@ ov2_status build_program(ba_solver &S)
     if ((s = dalloc(c, S.arena_off, &S.cp, np)) != OV2_OK) return s;
     if ((s = dalloc(c, S.arena_off, &S.xl, nl)) != OV2_OK) return s;
     if ((s = dalloc(c, S.arena_off, &S.cl, nl)) != OV2_OK) return s;
+    if (d.n_rows == 0 || d.n_e == 0) return OV2_OK;
+    // ---- structure of the atomic-free Schur complement (bs_* kernels)
+    {
+        int *ncell, *npair, *cell_ptr, *pair_off, *h2;
+#define AL2(ptr, count) if ((s = dalloc(c, S.arena_off, &ptr, (size_t)(count))) != OV2_OK) return s
+#define AL3(ptr, count) if ((s = dalloc2(c, off2, &ptr, (size_t)(count))) != OV2_OK) return s
+        AL2(ncell, d.n_e + 1); AL2(npair, d.n_e + 1); AL2(cell_ptr, d.n_e + 1); AL2(pair_off, d.n_e + 1); AL2(h2, 4);
+        size_t tb = 0;
+        OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ncell, cell_ptr, d.n_e + 1, st));
+        unsigned char *tscan;
+        AL2(tscan, tb + 256);
+        BA_LAUNCH(S, K_MISC, bs_count_kernel, dim3((d.n_e + 256) / 256), dim3(256), 0, st, d, ncell, npair);
+        OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tscan, tb, ncell, cell_ptr, d.n_e + 1, st));
+        OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tscan, tb, npair, pair_off, d.n_e + 1, st));
+        int *h_tot = (int *)c->ba_host;
+        OV2_HIP(c, hipMemcpyAsync(h_tot, cell_ptr + d.n_e, sizeof(int), hipMemcpyDeviceToHost, st));
+        OV2_HIP(c, hipMemcpyAsync(h_tot + 1, pair_off + d.n_e, sizeof(int), hipMemcpyDeviceToHost, st));
+        OV2_HIP(c, hipStreamSynchronize(st));
+        const int C_tot = h_tot[0], P_tot = h_tot[1];
+        if (d.n_f > 2047 || C_tot >= (1 << 21))
+            return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "window too large for the packed pair keys (%d free poses, %d cells)", d.n_f, C_tot);
+        int *cell_f, *cell_row, *cell_lm, *pcell_ptr, *pcell_ent, *seg_start, *head, *rank;
+        unsigned *ukey;
+        unsigned long long *pkey = nullptr, *pkey2 = nullptr, *ckey = nullptr, *ckey2 = nullptr;
+        ba_cells &Cc = S.cells;
+        const int pair_cap = (int)std::min<long long>((long long)P_tot, (long long)d.n_f * (d.n_f + 1) / 2);
+        size_t t1 = 0, t2 = 0, t4 = 0;
+        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, t1, pkey, pkey2, std::max(P_tot, 1), 0, 64, st));
+        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, t2, ckey, ckey2, std::max(C_tot, 1), 0, 64, st));
+        OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
+        size_t tbytes = std::max(std::max(t1, t2), t4);
+        {   // the structure lives in its own block, sized now that the counts are known and kept across solves
+            const size_t need2 = (size_t)C_tot * (7 * 4 + 2 * 8 + (size_t)(6 * e + 63) * 8) + (size_t)P_tot * (2 * 8 + 2 * 4) +
+                                 (size_t)pair_cap * 8 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
+            if (need2 > c->ba_arena2_cap) {
+                OV2_HIP(c, hipStreamSynchronize(st));
+                if (c->ba_arena2) OV2_HIP(c, hipFree(c->ba_arena2));
+                c->ba_arena2 = nullptr; c->ba_arena2_cap = 0;
+                const size_t want = need2 + need2 / 4;
+                hipError_t he = hipMalloc(&c->ba_arena2, want);
+                if (he != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA structure arena hipMalloc(%zu): %s", want, hipGetErrorString(he));
+                c->ba_arena2_cap = want;
+            }
+        }
+        size_t off2 = 0;
+        AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot);
+        AL3(Cc.W, (size_t)C_tot * 6 * e); AL3(Cc.FF, (size_t)C_tot * 21); AL3(Cc.FFa, (size_t)C_tot * 36); AL3(Cc.rhsc, (size_t)C_tot * 6);
+        AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
+        AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
+        AL3(ukey, pair_cap + 1); AL3(seg_start, pair_cap + 2);
+        unsigned char *tsort;
+        AL3(tsort, tbytes + 256);
+#undef AL3
+#undef AL2
+        Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm;
+        BA_LAUNCH(S, K_MISC, bs_cells_kernel, dim3((d.n_e + 255) / 256), dim3(256), 0, st, d, cell_ptr, pair_off, cell_f, cell_row,
+                  cell_lm, pkey, ckey);
+        if (C_tot > 0) {
+            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, ckey, ckey2, C_tot, 0, 64, st));
+            BA_LAUNCH(S, K_MISC, bs_posecells_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, ckey2, C_tot, d.n_f, pcell_ptr, pcell_ent);
+        }
+        if (P_tot > 0) {
+            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, pkey, pkey2, P_tot, 0, 64, st));
+            BA_LAUNCH(S, K_MISC, bs_heads_kernel, dim3((P_tot + 256) / 256), dim3(256), 0, st, pkey2, P_tot, head);
+            OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tsort, tbytes, head, rank, P_tot + 1, st));
+            BA_LAUNCH(S, K_MISC, bs_segs_kernel, dim3((P_tot + 255) / 256), dim3(256), 0, st, pkey2, P_tot, head, rank, seg_start, ukey);
+        }
+        int *n_pairs = rank + P_tot;     // exclusive rank behind the last entry = number of pose pairs
+        int *seg_len = nullptr;
+        unsigned long long *pval2 = pkey2;
+        S.pcell_ptr = pcell_ptr; S.pcell_ent = pcell_ent; S.n_pairs = n_pairs; S.seg_start = seg_start; S.seg_len = seg_len;
+        S.pair_key = ukey; S.pair_val = pval2; S.pair_cap = P_tot > 0 ? pair_cap : 0;
+    }
     return OV2_OK;
 }
 
@@ -1878,13 +1884,19 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             OV2_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int), st));
         }
         {
-            // 16 lanes per landmark; W of every cell through dynamic LDS, groups per workgroup sized to <= 48 KiB
-            int groups = 16;
-            while (groups > 1 && (size_t)groups * S.wstride * (6 * e + 2) * 8 > 48 * 1024) groups >>= 1;
-            const size_t lds = (size_t)groups * S.wstride * (6 * e + 2) * 8;
-            const int nblk = (d.n_e + groups - 1) / groups;
-            if (e == 1) BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<1>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
-            else BA_LAUNCH(S, K_SCHUR, ba_schur16_kernel<3>, dim3(nblk), dim3(groups * 16), lds, st, d, S.wstride);
+            if (e == 1) {
+                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
+                if (d.n_f > 0) BA_LAUNCH(S, K_SCHUR, bs_diag_kernel<1>, dim3(d.n_f), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent);
+                if (S.pair_cap > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_pair_kernel<1>, dim3(S.pair_cap), dim3(64), 0, st, d, S.cells, S.n_pairs, S.pair_key,
+                              S.seg_start, S.pair_val);
+            } else {
+                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
+                if (d.n_f > 0) BA_LAUNCH(S, K_SCHUR, bs_diag_kernel<3>, dim3(d.n_f), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent);
+                if (S.pair_cap > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_pair_kernel<3>, dim3(S.pair_cap), dim3(64), 0, st, d, S.cells, S.n_pairs, S.pair_key,
+                              S.seg_start, S.pair_val);
+            }
         }
         const auto tb = tnow();
         if (d.m > 0) {

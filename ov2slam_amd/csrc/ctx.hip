@@ -50,6 +50,8 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->ba_arena_cap = 0;
     c->ba_host = nullptr;
     c->ba_host_cap = 0;
+    c->ba_arena2 = nullptr;
+    c->ba_arena2_cap = 0;
     c->stage_host = c->stage_dev = nullptr;
     c->stage_cap = 0;
     int prio_least = 0, prio_greatest = 0;
@@ -83,6 +85,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     if (c->ba_arena) (void)hipFree(c->ba_arena);
     if (c->ba_host) (void)hipHostFree(c->ba_host);
+    if (c->ba_arena2) (void)hipFree(c->ba_arena2);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     (void)hipEventDestroy(c->ev0);

@@ -75,6 +75,8 @@ struct ov2_ctx {
     size_t ba_arena_cap;
     void *stage_host, *stage_dev;        // pinned staging block + its device twin for the host-pointer entry points
     size_t stage_cap;
+    void *ba_arena2;                     // second device block: cell / pair structure of the Schur complement (sized after the build learns the counts)
+    size_t ba_arena2_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
     size_t ba_host_cap;
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
