@@ -1,6 +1,8 @@
 // ctx.hip -- context, device memory, image batches, pooled pyramid buffers of libov2hip.so
 #include "ov2_internal.h"
 
+#include <cstdlib>
+
 ov2_status ov2_set_err(ov2_ctx *ctx, ov2_status s, const char *fmt, ...)
 {
     char buf[512];
@@ -56,8 +58,27 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->stage_cap = 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least) != hipSuccess ||
+    // experiment hook: OV2_CU_SPLIT=k keeps the first k compute units of the device for the high-priority contexts
+    // (the local-BA worker) and the remaining ones for the others, instead of sharing all of them by priority
+    const char *split_env = getenv("OV2_CU_SPLIT");
+    const int split = split_env ? atoi(split_env) : 0;
+    hipError_t e1, e2;
+    if (split > 0) {
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, device);
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0u);
+        for (int i = 0; i < ncu; ++i) {
+            const bool mine = high_priority ? (i < split) : (i >= split);
+            if (mine) mask[i / 32] |= 1u << (i % 32);
+        }
+        e1 = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, mask.data());
+        e2 = hipExtStreamCreateWithCUMask(&c->stream_pyr, (uint32_t)words, mask.data());
+    } else {
+        e1 = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
+        e2 = hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
+    }
+    if (e1 != hipSuccess || e2 != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return OV2_ERR_HIP;
