@@ -1350,11 +1350,10 @@ __device__ __forceinline__ double wave_total(double v)
 // cells.  Threads stride over the cells (a pose has thousands: a serial walk was latency-bound at ~1 us per cell),
 // every thread keeps the 27 partial sums, fixed-order wave + LDS reduction at the end.
 template <int E>
-__global__ __launch_bounds__(256) void bs_diag_kernel(ba_dev d, ba_cells C, const int *__restrict__ pcell_ptr,
-                                                      const int *__restrict__ pcell_ent)
+__device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C, const int *__restrict__ pcell_ptr,
+                                              const int *__restrict__ pcell_ent, int f, double (*red)[27])
 {
-    __shared__ double red[4][27];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     double acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = 0.0;
@@ -1398,12 +1397,12 @@ __global__ __launch_bounds__(256) void bs_diag_kernel(ba_dev d, ba_cells C, cons
 // (2b) one wave per pose pair (hi > lo): S[hi, lo] = sum over the landmarks seen by both of  -W_hi (E'E)^-1 W_lo^T,
 // plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries.
 template <int E>
-__global__ __launch_bounds__(64) void bs_pair_kernel(ba_dev d, ba_cells C, const int *__restrict__ n_pairs,
-                                                     const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
-                                                     const unsigned long long *__restrict__ pk)
+__device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C, int n_pairs,
+                                              const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
+                                              const unsigned long long *__restrict__ pk, int pidx)
 {
-    const int pidx = blockIdx.x, lane = threadIdx.x;
-    if (pidx >= *n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    if (pidx >= n_pairs) return;
     const int hi = (int)(pair_key[pidx] >> 11), lo = (int)(pair_key[pidx] & 0x7ffu);
     double acc[36];   // element (i of hi, j of lo) at i + 6 j
 #pragma unroll
@@ -1443,6 +1442,20 @@ __global__ __launch_bounds__(64) void bs_pair_kernel(ba_dev d, ba_cells C, const
         const int i = t % 6, j = t / 6;
         if (lane == 0 && (hi != lo || i >= j)) d.S[(size_t)(lo * 6 + j) * d.m + hi * 6 + i] += v;
     }
+}
+
+// (2) ONE launch for all of S: workgroups [0, n_f) gather the diagonal blocks (+ rhs), the following ones take four
+// pose pairs each (one per wave).  One launch instead of two matters beside a busy front-end, where every dispatch of
+// the BA stream queues behind resident waves.
+template <int E>
+__global__ __launch_bounds__(256) void bs_gather_kernel(ba_dev d, ba_cells C, const int *__restrict__ pcell_ptr,
+                                                        const int *__restrict__ pcell_ent, const int *__restrict__ n_pairs,
+                                                        const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
+                                                        const unsigned long long *__restrict__ pk)
+{
+    __shared__ double red[4][27];
+    if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, pcell_ent, blockIdx.x, red);
+    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pk, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1884,18 +1897,17 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             OV2_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int), st));
         }
         {
+            const int gblocks = d.n_f + (S.pair_cap + 3) / 4;
             if (e == 1) {
                 BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
-                if (d.n_f > 0) BA_LAUNCH(S, K_SCHUR, bs_diag_kernel<1>, dim3(d.n_f), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent);
-                if (S.pair_cap > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_pair_kernel<1>, dim3(S.pair_cap), dim3(64), 0, st, d, S.cells, S.n_pairs, S.pair_key,
-                              S.seg_start, S.pair_val);
+                if (gblocks > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3(gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val);
             } else {
                 BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
-                if (d.n_f > 0) BA_LAUNCH(S, K_SCHUR, bs_diag_kernel<3>, dim3(d.n_f), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent);
-                if (S.pair_cap > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_pair_kernel<3>, dim3(S.pair_cap), dim3(64), 0, st, d, S.cells, S.n_pairs, S.pair_key,
-                              S.seg_start, S.pair_val);
+                if (gblocks > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3(gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val);
             }
         }
         const auto tb = tnow();
