@@ -739,8 +739,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restric
 // + solve against the one-workgroup kernel above; no upper limit on m any more.
 typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
 #define CHOL_NB 32
-#define CHOL_MULTI_MIN 192   // measured (3-iteration minimize): m = 250: 3.28 -> 3.08 ms, m = 480: 9.9 -> 6.9 ms against the
-                             // one-workgroup kernel; below ~6 panels the extra launches are not worth it
+#define CHOL_MULTI_MIN 320   // measured (3-iteration minimize): m = 480: 9.9 -> 5.9 ms against the one-workgroup kernel.  At
+                             // m = 250 the 16 launches win 6 % on an idle GPU (3.28 -> 3.08 ms) but lose 9 % beside a busy
+                             // front-end (332 vs 363 LM iterations/s: every dispatch queues), so the single launch stays there
 
 __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ A, double *__restrict__ rhs,
                                                            double *__restrict__ Dbuf, int m, int k0, int *__restrict__ flags)
