@@ -341,6 +341,26 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(const double *__restrict
     if (threadIdx.x == 0) out[0] = sign * tot;
 }
 
+__global__ void ba_copy2_kernel(double *__restrict__ d1, const double *__restrict__ s1, size_t n1, double *__restrict__ d2,
+                                const double *__restrict__ s2, size_t n2)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) d1[i] = s1[i];
+    if (i < n2) d2[i] = s2[i];
+}
+
+// up to three ordered sums in one launch (workgroup k reduces array k)
+struct ba_red3 { const double *in[3]; int n[3]; double *out[3]; double sign[3]; };
+__global__ __launch_bounds__(256) void ba_reduce3_kernel(ba_red3 r)
+{
+    __shared__ double sh[256];
+    const int k = blockIdx.x;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < r.n[k]; i += 256) v += r.in[k][i];
+    const double tot = block_sum_256(v, sh);
+    if (threadIdx.x == 0) r.out[k][0] = r.sign[k] * tot;
+}
+
 __global__ __launch_bounds__(256) void ba_max_kernel(const double *__restrict__ in, int n, double *__restrict__ out)
 {
     __shared__ double sh[256];
@@ -380,23 +400,27 @@ __global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
 }
 
 // LevenbergMarquardtStrategy::ComputeStep :76-89
-__global__ void ba_lmdiag_kernel(ba_dev d, int refresh_diag, double min_d, double max_d, double radius)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.nc) return;
-    if (refresh_diag) d.diag[i] = fmin(fmax(d.sqn[i], min_d), max_d);
-    d.lmd[i] = sqrt(d.diag[i] / radius);
-}
-
-// S = diag(D_f^2), rhs = 0
-__global__ void ba_sinit_kernel(ba_dev d)
+// LM diagonal of every column (refreshed from the column norms after an accepted step) and, in the same launch,
+// S = diag(D_f^2), rhs = 0, flag = 0.  The S part recomputes the few D_f it needs instead of reading what other
+// threads of this launch write.
+__global__ void ba_lmdiag_sinit_kernel(ba_dev d, int refresh_diag, double min_d, double max_d, double radius)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)d.nc) {
+        if (refresh_diag) d.diag[i] = fmin(fmax(d.sqn[i], min_d), max_d);
+        d.lmd[i] = sqrt(d.diag[i] / radius);
+    }
     const size_t mm = (size_t)d.m * d.m;
     if (i < mm) {
         const int r = (int)(i % d.m), c = (int)(i / d.m);
-        const double dv = d.lmd[d.n_e * d.e + r];
-        d.S[i] = (r == c) ? dv * dv : 0.0;
+        double v = 0.0;
+        if (r == c) {
+            const int col = d.n_e * d.e + r;
+            const double dg = refresh_diag ? fmin(fmax(d.sqn[col], min_d), max_d) : d.diag[col];
+            const double dv = sqrt(dg / radius);   // the same D the column's own thread stores in lmd
+            v = dv * dv;
+        }
+        d.S[i] = v;
     }
     if (i < (size_t)d.m) d.rhs[i] = 0.0;
     if (i == 0) d.flags[0] = 0;
@@ -510,6 +534,10 @@ __constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2
 template <int E>
 __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__restrict__ part)
 {
+    {   // the pose part of the step is -z (z = the reduced solve's result in rhs); written here to save a launch
+        const int gi = blockIdx.x * 256 + threadIdx.x;
+        if (gi < d.m) d.step[d.n_e * d.e + gi] = -d.rhs[gi];
+    }
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const bool live = l < d.n_e;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
@@ -895,11 +923,6 @@ __global__ __launch_bounds__(256) void ba_chol_backward_kernel(const double *__r
 }
 
 
-__global__ void ba_zstep_kernel(ba_dev d)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d.m) d.step[d.n_e * d.e + i] = -d.rhs[i];
-}
 
 // K_PLUS: candidate = Plus(x, step .* scale); partials: |x - cand|^2 and |cand|^2 over the free blocks (global size)
 __global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__restrict__ xp, const double *__restrict__ xl,
@@ -1667,7 +1690,7 @@ ov2_status build_program(ba_solver &S)
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
     AL(S, (size_t)d.m * d.m); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
     S.eval_blocks = (nr + 255) / 256;
-    AL(part, std::max<size_t>({(size_t)S.eval_blocks, (size_t)d.n_e + d.n_f, 1}) * 2 + 16);
+    AL(part, std::max<size_t>({(size_t)S.eval_blocks, (size_t)d.n_e + d.n_f, 1}) * 3 + 16);
     AL(scal, SC_N + 2); AL(flags, 4);
 #undef AL
     if ((s = dalloc(c, S.arena_off, &S.chold, (size_t)(d.m / CHOL_NB + 1) * CHOL_NB * CHOL_NB)) != OV2_OK) return s;
@@ -1888,14 +1911,11 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
         };
         const auto ta = tnow();
         // ---- ComputeTrustRegionStep + candidate evaluation, all enqueued, one sync
-        BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, reuse_diagonal ? 0 : 1,
-                  o->min_lm_diagonal, o->max_lm_diagonal, radius);
-        reuse_diagonal = 1;
-        if (d.m > 0) {
-            const size_t mm = (size_t)d.m * d.m;
-            BA_LAUNCH(S, K_SINIT, ba_sinit_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, d);
-        } else {
-            OV2_HIP(c, hipMemsetAsync(d.flags, 0, sizeof(int), st));
+        {
+            const size_t cover = std::max<size_t>((size_t)d.nc, (size_t)d.m * d.m);
+            BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_sinit_kernel, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, d,
+                      reuse_diagonal ? 0 : 1, o->min_lm_diagonal, o->max_lm_diagonal, radius);
+            reuse_diagonal = 1;
         }
         {
             const int gblocks = d.n_f + (S.pair_cap + 3) / 4;
@@ -1936,18 +1956,25 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(CHOL_THREADS), lds8, st, d.S, d.rhs, d.m, d.flags);
             else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", d.m);
             }
-            BA_LAUNCH(S, K_MISC, ba_zstep_kernel, dim3((d.m + 255) / 256), dim3(256), 0, st, d);
         }
         const auto tc = tnow();
-        if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
-        else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, d.part);
-        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, d.n_e, d.scal + SC_MODEL, -1.0);
+        {
+            double *pm = d.part + 2 * (size_t)(d.n_e + d.n_f);   // model-change partials, behind the two arrays ba_plus fills
+            const int bgrid = std::max((d.n_e + 15) / 16, (d.m + 255) / 256);
+            if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3(bgrid), dim3(256), 0, st, d, pm);
+            else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3(bgrid), dim3(256), 0, st, d, pm);
+        }
         const int nb = d.n_e + d.n_f;
-        double *part_step = d.part, *part_norm = d.part + nb;
+        double *part_step = d.part, *part_norm = d.part + nb, *part_model = d.part + 2 * (size_t)nb;
         BA_LAUNCH(S, K_PLUS, ba_plus_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, d, S.xp, S.xl, S.cp, S.cl, d.step,
                   o->jacobi_scaling ? 1 : 0, part_step, part_norm);
-        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_step, nb, d.scal + SC_STEP2, 1.0);
-        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, part_norm, nb, d.scal + SC_XNORM2, 1.0);
+        {
+            ba_red3 r3;
+            r3.in[0] = part_model; r3.n[0] = d.n_e; r3.out[0] = d.scal + SC_MODEL; r3.sign[0] = -1.0;
+            r3.in[1] = part_step; r3.n[1] = nb; r3.out[1] = d.scal + SC_STEP2; r3.sign[1] = 1.0;
+            r3.in[2] = part_norm; r3.n[2] = nb; r3.out[2] = d.scal + SC_XNORM2; r3.sign[2] = 1.0;
+            BA_LAUNCH(S, K_REDUCE, ba_reduce3_kernel, dim3(3), dim3(256), 0, st, r3);
+        }
         if (e == 1)
             BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
                       o->huber_delta, 0, d.part);
@@ -1988,8 +2015,8 @@ ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_lo
             std::swap(S.xp, S.cp);
             std::swap(S.xl, S.cl);
             // keep the constant / unused blocks of the new candidate buffer in sync for the next Plus
-            OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, np * sizeof(double), hipMemcpyDeviceToDevice, st));
-            OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, nl * sizeof(double), hipMemcpyDeviceToDevice, st));
+            BA_LAUNCH(S, K_MISC, ba_copy2_kernel, dim3((unsigned)((std::max(np, nl) + 255) / 256)), dim3(256), 0, st, S.cp, S.xp, np,
+                      S.cl, S.xl, nl);
             x_norm = std::sqrt(sc[SC_XNORM2]);
             const auto tq1 = std::chrono::steady_clock::now();
             if ((s = eval_jacobian(S, use_loss, false)) != OV2_OK) return s;
