@@ -22,6 +22,7 @@ for B in (1, 16, 64):
         for _ in range(R):
             fe.preprocess_images(ctx, ims, True, 3.0, 9, nl).release()
         kt = ctx.kernel_times(); ctx.kernel_timing(False)
-        lv = kt["level_kernel"][0] / R * 1e3
-        print(f"B={B} nlevels={nl}: clahe_lut {kt['clahe_lut_kernel'][0]/R*1e3:.1f} us, level0 {kt['level0_kernel'][0]/R*1e3:.1f} us, "
-              f"level kernels total {lv:.1f} us ({kt['level_kernel'][1]//R} launches)", flush=True)
+        lv = kt.get("level_kernel", (0, 0))[0] / R * 1e3
+        nlv = kt.get("level_kernel", (0, 0))[1] // R
+        print(f"B={B} nlevels={nl}: clahe_lut {kt['clahe_lut_kernel'][0]/R*1e3:.1f} us, level0 {kt.get('level0_kernel',(0,0))[0]/R*1e3:.1f} us, "
+              f"level kernels total {lv:.1f} us ({nlv} launches)", flush=True)

@@ -47,6 +47,17 @@ def test_clahe_bit_exact(ctx, oracle, w, h, tiles, clip):
     assert np.array_equal(gi[p:p + gh, p:p + gw], ref)
 
 
+@pytest.mark.parametrize("w,h,tiles", [(97, 61, (3, 2)), (333, 257, (6, 5)), (1241, 376, (24, 7)), (70, 34, (2, 2)),
+                                       (66, 20, (1, 1)), (131, 18, (2, 1))])
+def test_clahe_pyramid_odd_sizes(ctx, oracle, w, h, tiles):
+    """the fused level-0 kernel (CLAHE -> plane + Scharr + pyrDown) on ragged tiles, padding and gradients included"""
+    rng = np.random.default_rng(7 * w + h)
+    img = (np.linspace(0, 255, w)[None, :] * 0.5 + rng.integers(0, 128, size=(h, w))).clip(0, 255).astype(np.uint8)
+    for nl in (0, 3):
+        gp = fe.preprocess_image(ctx, img, use_clahe=True, fclahe_val=3.0, tiles=tiles, nklt_pyr_lvl=nl)
+        _assert_pyr_equal(gp, oracle.Pyramid(oracle.clahe(img, 3.0, tiles[0], tiles[1]), 9, nl))
+
+
 def test_pyramid_batched_matches_single(ctx, oracle, stream):
     B = 3
     imgs = fe.Images(ctx, B, 752, 480)
