@@ -269,6 +269,77 @@ ov2_status ov2_pnp_solve_batch_dev(ov2_ctx *ctx, int B, const int32_t *d_off, co
                                    int use_robust, int l2_after_robust, uint8_t *d_outlier, uint8_t *d_removed,
                                    int32_t *d_success, int32_t *d_iters);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Flat device-resident map mirror: keyframe poses, landmark states and the observation table
+ * (keyframe, landmark, unpx, runpx, scale, stereo flag) as SoA arrays in HBM, kept in step with the reference's
+ * MapManager by the hooks below, so that the set-up stage of Optimizer::localBA (src/optimizer.cpp:43-430: the walk
+ * over Frame::map_covkfs_, Frame::mapkps_, MapPoint::set_kfids_ and the two hash maps of the MapManager) becomes a
+ * handful of linear scans over the observation table.  kfid / lmid index the tables directly (both are small dense
+ * counters in the reference: src/map_manager.cpp:621-690), capacities are fixed at creation.
+ *
+ *   hook                          reference mutation it mirrors
+ *   ov2_map_add_keyframe          MapManager::addKeyframe + addMapPointKfObs   src/map_manager.cpp:621-634,769-799
+ *   ov2_map_set_landmarks         MapManager::addMapPoint / updateMapPoint / setMapPointObs  :636-689,715-767,1053
+ *   ov2_map_set_poses             Frame::setTwc after localBA / pose-graph      src/optimizer.cpp:767-786
+ *   ov2_map_remove_obs            MapManager::removeMapPointObs                 :970-1019
+ *   ov2_map_set_obs_stereo        Frame::removeStereoKeypointById / stereoMatching results
+ *   ov2_map_remove_landmarks      MapManager::removeMapPoint                    :922-968
+ *   ov2_map_remove_keyframe       MapManager::removeKeyframe                    :885-920
+ * All array arguments are HOST pointers, staged through the ctx's pinned block; a hook returns once its copy has
+ * been consumed (one stream synchronisation). */
+typedef struct ov2_map ov2_map;
+
+#define OV2_LM_ALIVE 1   /* MapManager::map_plms_ holds it */
+#define OV2_LM_3D    2   /* MapPoint::is3d_ */
+#define OV2_LM_OBS   4   /* MapPoint::isobs_ (seen by the current frame) */
+#define OV2_LM_KP3D  8   /* its keypoints carry Keypoint::is3d_ (Frame::turnKeypoint3d ran): MapPoint::isBad() clears
+                            is3d_ but leaves the keypoints 3D, and the set-up selects by the keypoint flag (:176-180) */
+
+ov2_status ov2_map_create(ov2_ctx *ctx, int max_kf, int max_lm, int max_obs, ov2_map **out);
+void ov2_map_destroy(ov2_map *m);
+/* one keyframe with its n keypoints: lmid, unpx (n x 2), runpx (n x 2, read where is_stereo), is_stereo, scale */
+ov2_status ov2_map_add_keyframe(ov2_map *m, int kfid, const double *Twc, int n, const int32_t *lmid, const double *unpx,
+                                const double *runpx, const uint8_t *is_stereo, const int32_t *scale);
+/* state = OR of OV2_LM_*; xyz (n x 3) may be NULL to change the states only */
+ov2_status ov2_map_set_landmarks(ov2_map *m, int n, const int32_t *lmid, const double *xyz, const uint8_t *state);
+ov2_status ov2_map_set_poses(ov2_map *m, int n, const int32_t *kfid, const double *Twc);
+ov2_status ov2_map_remove_obs(ov2_map *m, int n, const int32_t *kfid, const int32_t *lmid);
+ov2_status ov2_map_set_obs_stereo(ov2_map *m, int n, const int32_t *kfid, const int32_t *lmid, const uint8_t *is_stereo,
+                                  const double *runpx);
+ov2_status ov2_map_remove_landmarks(ov2_map *m, int n, const int32_t *lmid);
+ov2_status ov2_map_remove_keyframe(ov2_map *m, int kfid);
+
+/* The flat problem of one local BA, in pinned host memory owned by the map (valid until the next set-up call):
+ * exactly the arrays ov2_ba_problem wants plus the reference ids behind the indices. */
+typedef struct ov2_local_ba_setup {
+    int32_t aborted;                 /* nb3dkps < nmin_covscore  (src/optimizer.cpp:61-63) */
+    int32_t n_pose, n_lm, n_res, n_bad;
+    const int32_t *pose_kfid;        /* n_pose, ascending kfid */
+    const uint8_t *pose_const;       /* n_pose */
+    double *pose;                    /* n_pose x 7 (Twc) */
+    const int32_t *lm_lmid;          /* n_lm, ascending lmid */
+    double *lm;                      /* n_lm x (inv_depth ? 1 : 3) */
+    const int32_t *lm_anchor_pose;   /* n_lm (inv_depth) */
+    const double *lm_anchor_uv;      /* n_lm x 2 (inv_depth) */
+    const uint8_t *res_type;         /* n_res */
+    const int32_t *res_pose, *res_lm;
+    const double *res_uv, *res_sigma;
+    const int32_t *bad_lmid;         /* n_bad: MapPoint::isBad() landmarks met on the way (set_badlmids, :204-207) */
+} ov2_local_ba_setup;
+
+/* Replaces the set-up stage of Optimizer::localBA (src/optimizer.cpp:43-430) for the keyframe newkf:
+ *  - covisibility scores of newkf (Frame::map_covkfs_, src/map_manager.cpp:117-193) recounted from the table,
+ *  - keyframes newest -> oldest: optimised while score >= nmin_covscore and kfid > 0, constant from the first that
+ *    fails (:150-190); their 3D keypoints' landmarks are the local landmarks (isBad() ones are listed, not used),
+ *  - every alive observation of a local landmark by a keyframe <= the newest covisible one becomes one or two
+ *    residual blocks (:193-392); observers outside the window enter as constant poses (:229-246); with inv_depth
+ *    the first observer is the anchor (:251-287),
+ *  - at least nmin_cst_kfs constant keyframes, smallest kfids first (:394-407).
+ * One synchronisation for the sizes, one for the arrays. */
+ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_covscore, int nmin_cst_kfs, int inv_depth,
+                                  const double *calib_l /* fx fy cx cy: anchor depth needs no intrinsics; reserved */,
+                                  ov2_local_ba_setup *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,16 @@ SIGNATURES = {
     "ov2_ba_solve": (C.c_int, [vp, vp, vp, vp]),
     "ov2_pnp_solve_batch_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                           vp, vp, vp, vp]),
+    "ov2_map_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "ov2_map_destroy": (None, [vp]),
+    "ov2_map_add_keyframe": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ov2_map_set_landmarks": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "ov2_map_set_poses": (C.c_int, [vp, C.c_int, vp, vp]),
+    "ov2_map_remove_obs": (C.c_int, [vp, C.c_int, vp, vp]),
+    "ov2_map_set_obs_stereo": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "ov2_map_remove_landmarks": (C.c_int, [vp, C.c_int, vp]),
+    "ov2_map_remove_keyframe": (C.c_int, [vp, C.c_int]),
+    "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ov2_pnp_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                       vp, vp, vp]),
 }

@@ -100,6 +100,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
         if (b->lut) (void)hipFree(b->lut);
         delete b;
     }
+    for (ov2_map *m : c->maps) ov2_map_orphan(m);
     if (c->tmp_img) ov2_images_destroy(c->tmp_img);
     for (auto &r : c->ktime_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ktime_free) (void)hipEventDestroy(e);
@@ -119,6 +120,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
 extern "C" ov2_status ov2_ctx_synchronize(ov2_ctx *c)
 {
     if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     return OV2_OK;
@@ -127,6 +129,7 @@ extern "C" ov2_status ov2_ctx_synchronize(ov2_ctx *c)
 extern "C" ov2_status ov2_timer_start(ov2_ctx *c)
 {
     if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipEventRecord(c->ev0, c->stream));
     return OV2_OK;
 }
@@ -134,6 +137,7 @@ extern "C" ov2_status ov2_timer_start(ov2_ctx *c)
 extern "C" ov2_status ov2_timer_stop(ov2_ctx *c, float *ms)
 {
     if (!c || !ms) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipEventRecord(c->ev1, c->stream));
     OV2_HIP(c, hipEventSynchronize(c->ev1));
     OV2_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -152,6 +156,7 @@ extern "C" ov2_status ov2_dev_alloc(ov2_ctx *c, size_t bytes, void **dptr)
 extern "C" ov2_status ov2_dev_free(ov2_ctx *c, void *dptr)
 {
     if (!c) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     if (dptr) OV2_HIP(c, hipFree(dptr));
     return OV2_OK;
 }
@@ -159,6 +164,7 @@ extern "C" ov2_status ov2_dev_free(ov2_ctx *c, void *dptr)
 extern "C" ov2_status ov2_memcpy_h2d(ov2_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     return OV2_OK;
@@ -167,6 +173,7 @@ extern "C" ov2_status ov2_memcpy_h2d(ov2_ctx *c, void *dst, const void *src, siz
 extern "C" ov2_status ov2_memcpy_d2h(ov2_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     return OV2_OK;
@@ -175,6 +182,7 @@ extern "C" ov2_status ov2_memcpy_d2h(ov2_ctx *c, void *dst, const void *src, siz
 extern "C" ov2_status ov2_memcpy_d2d(ov2_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c || (bytes && (!dst || !src))) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     return OV2_OK;
 }
@@ -239,6 +247,7 @@ extern "C" ov2_status ov2_images_create(ov2_ctx *c, int batch, int w, int h, ov2
 extern "C" ov2_status ov2_images_upload(ov2_ctx *c, ov2_images *im, int b, const uint8_t *host, int stride)
 {
     if (!c || !im || !host || b < 0 || b >= im->batch || stride < im->w) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));   // HIP's current device is per thread
     OV2_HIP(c, hipMemcpy2DAsync(im->base + im->bstride * b, im->stride, host, stride, im->w, im->h,
                                 hipMemcpyHostToDevice, c->stream));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
@@ -261,7 +270,7 @@ const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", 
                                            "ba_plus_kernel", "ba_flag_kernel", "ba_reduce_kernel", "ba_misc_kernels",
                                            nullptr, nullptr, "detect_cell_kernels", "detect_mask_kernel", "subpix_kernel",
                                            "pnp_kernel", "klt_compact_kernel",
-                                           "detect_list_kernels"};
+                                           "detect_list_kernels", "map_setup_kernels"};
 
 static hipEvent_t ktime_event(ov2_ctx *c)
 {

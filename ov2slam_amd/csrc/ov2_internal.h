@@ -50,6 +50,7 @@ enum ov2_kernel_id {
     OV2_K_CLAHE_LUT = 0, OV2_K_LEVEL0, OV2_K_LEVEL, OV2_K_KLT_FB, OV2_K_KLT_STAGE1, OV2_K_KLT_STAGE2,
     OV2_K_BA_FIRST,  // BA kernels register from here (ba.hip): 12 ids
     OV2_K_DETECT = 20,
+    OV2_K_MAP = 26,  // map mirror scans (map.hip)
     OV2_K_MAX = 48
 };
 extern const char *ov2_kernel_names[OV2_K_MAX];
@@ -66,6 +67,7 @@ struct ov2_ctx {
     hipEvent_t ev0, ev1;
     std::mutex mu;                       // guards pool + err
     std::vector<ov2_pyr_buf *> pool;     // free pyramid buffers
+    std::vector<struct ov2_map *> maps;  // live map mirrors (their device memory is released with the ctx)
     std::string err;
     // scratch for host-pointer entry points (grown on demand)
     void *scratch_dev;
@@ -103,6 +105,8 @@ ov2_status ov2_set_err(ov2_ctx *ctx, ov2_status s, const char *fmt, ...);
 ov2_status ov2_scratch(ov2_ctx *ctx, size_t bytes, void **out);
 // pinned host block of `bytes` and a device block of the same size (grown on demand, kept by the ctx)
 ov2_status ov2_staging(ov2_ctx *ctx, size_t bytes, void **host, void **dev);
+// ov2_ctx_destroy: free the device side of a map that outlives its ctx (the handle stays valid for ov2_map_destroy)
+void ov2_map_orphan(struct ov2_map *m);
 
 #define OV2_HIP(ctx, call)                                                                          \
     do {                                                                                            \

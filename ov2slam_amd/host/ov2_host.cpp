@@ -188,6 +188,7 @@ void MapManager::updateMapPoint(int lmid, const Vec3 &wpt, double kfanch_invdept
         if (plm->isobs_ && pcurframe_) pcurframe_->turnKeypoint3d(lmid);
     }
     plm->setPoint(wpt, kfanch_invdepth);
+    touchMapPoint(lmid);
 }
 
 void MapManager::removeMapPointObs(int lmid, int kfid)
@@ -196,6 +197,7 @@ void MapManager::removeMapPointObs(int lmid, int kfid)
     if (pkf) pkf->removeKeypointById(lmid);
     auto plm = getMapPoint(lmid);
     if (plm) plm->removeKfObs(kfid);
+    if (dev_) { dev_rm_kf_.push_back(kfid); dev_rm_lm_.push_back(lmid); }
 }
 
 void MapManager::removeMapPoint(int lmid)
@@ -208,6 +210,7 @@ void MapManager::removeMapPoint(int lmid)
     }
     if (plm->isobs_ && pcurframe_) pcurframe_->removeKeypointById(lmid);
     map_plms_.erase(lmid);
+    touchMapPoint(lmid);
 }
 
 void MapManager::removeObsFromCurFrameById(int lmid)
@@ -215,6 +218,7 @@ void MapManager::removeObsFromCurFrameById(int lmid)
     if (pcurframe_) pcurframe_->removeKeypointById(lmid);
     auto plm = getMapPoint(lmid);
     if (plm) plm->isobs_ = false;
+    touchMapPoint(lmid);
 }
 
 void MapManager::updateFrameCovisibility(Frame &frame)
@@ -231,6 +235,99 @@ void MapManager::updateFrameCovisibility(Frame &frame)
         auto pkf = getKeyframe(kv.first);
         if (pkf) pkf->map_covkfs_[frame.kfid_] = kv.second;
     }
+}
+
+// ---------------------------------------------------------------------------------------------- device map mirror
+MapManager::~MapManager() { if (dev_) ov2_map_destroy(dev_); }
+
+static uint8_t lm_state_of(const MapManager &map, const MapPoint &lm)
+{
+    // Keypoint::is3d_ of its observations (all turned together by Frame::turnKeypoint3d): read it off the first observer
+    bool kp3d = lm.is3d_;
+    if (!kp3d && !lm.set_kfids_.empty()) {
+        auto pkf = map.getKeyframe(*lm.set_kfids_.begin());
+        if (pkf) { const Keypoint kp = pkf->getKeypointById(lm.lmid_); kp3d = kp.lmid_ == lm.lmid_ && kp.is3d_; }
+    }
+    return (uint8_t)(OV2_LM_ALIVE | (lm.is3d_ ? OV2_LM_3D : 0) | (lm.isobs_ ? OV2_LM_OBS : 0) | (kp3d ? OV2_LM_KP3D : 0));
+}
+
+ov2_status MapManager::addKeyframeToDevice(const Frame &kf)
+{
+    if (!dev_) return OV2_OK;
+    const size_t n = kf.mapkps_.size();
+    std::vector<int32_t> lmid, scale; std::vector<double> un, run; std::vector<uint8_t> st;
+    lmid.reserve(n); scale.reserve(n); un.reserve(2 * n); run.reserve(2 * n); st.reserve(n);
+    for (const auto &kv : kf.mapkps_) {
+        const Keypoint &kp = kv.second;
+        lmid.push_back(kp.lmid_); scale.push_back(kp.scale_);
+        un.push_back(kp.unpx_.x); un.push_back(kp.unpx_.y);
+        run.push_back(kp.runpx_.x); run.push_back(kp.runpx_.y);
+        st.push_back(kp.is_stereo_ ? 1 : 0);
+    }
+    const SE3 T = kf.getTwc();
+    return ov2_map_add_keyframe(dev_, kf.kfid_, T.v.data(), (int)n, lmid.data(), un.data(), run.data(), st.data(), scale.data());
+}
+
+ov2_status MapManager::attachDevice(ov2_ctx *ctx, int max_kf, int max_lm, int max_obs)
+{
+    if (dev_) { ov2_map_destroy(dev_); dev_ = nullptr; }
+    ov2_status s = ov2_map_create(ctx, max_kf, max_lm, max_obs, &dev_);
+    if (s != OV2_OK) return s;
+    std::vector<int32_t> lmid; std::vector<double> xyz; std::vector<uint8_t> st;
+    for (const auto &kv : map_plms_) {
+        const Vec3 p = kv.second->getPoint();
+        lmid.push_back(kv.first); xyz.push_back(p.x); xyz.push_back(p.y); xyz.push_back(p.z);
+        st.push_back(lm_state_of(*this, *kv.second));
+    }
+    if ((s = ov2_map_set_landmarks(dev_, (int)lmid.size(), lmid.data(), xyz.data(), st.data())) != OV2_OK) return s;
+    for (const auto &kv : map_pkfs_)
+        if ((s = addKeyframeToDevice(*kv.second)) != OV2_OK) return s;
+    dev_lm_dirty_.clear(); dev_pose_dirty_.clear(); dev_rm_kf_.clear(); dev_rm_lm_.clear(); dev_st_kf_.clear(); dev_st_lm_.clear();
+    return OV2_OK;
+}
+
+ov2_status MapManager::flushDevice()
+{
+    if (!dev_) return OV2_OK;
+    ov2_status s;
+    if (!dev_rm_kf_.empty()) {
+        if ((s = ov2_map_remove_obs(dev_, (int)dev_rm_kf_.size(), dev_rm_kf_.data(), dev_rm_lm_.data())) != OV2_OK) return s;
+        dev_rm_kf_.clear(); dev_rm_lm_.clear();
+    }
+    if (!dev_st_kf_.empty()) {
+        std::vector<uint8_t> off(dev_st_kf_.size(), 0);
+        std::vector<double> zero(2 * dev_st_kf_.size(), 0.0);
+        if ((s = ov2_map_set_obs_stereo(dev_, (int)dev_st_kf_.size(), dev_st_kf_.data(), dev_st_lm_.data(), off.data(), zero.data())) != OV2_OK)
+            return s;
+        dev_st_kf_.clear(); dev_st_lm_.clear();
+    }
+    if (!dev_lm_dirty_.empty()) {
+        std::sort(dev_lm_dirty_.begin(), dev_lm_dirty_.end());
+        dev_lm_dirty_.erase(std::unique(dev_lm_dirty_.begin(), dev_lm_dirty_.end()), dev_lm_dirty_.end());
+        std::vector<double> xyz; std::vector<uint8_t> st;
+        for (int lmid : dev_lm_dirty_) {
+            auto plm = getMapPoint(lmid);
+            const Vec3 p = plm ? plm->getPoint() : Vec3{0, 0, 0};
+            xyz.push_back(p.x); xyz.push_back(p.y); xyz.push_back(p.z);
+            st.push_back(plm ? lm_state_of(*this, *plm) : 0);
+        }
+        if ((s = ov2_map_set_landmarks(dev_, (int)dev_lm_dirty_.size(), dev_lm_dirty_.data(), xyz.data(), st.data())) != OV2_OK) return s;
+        dev_lm_dirty_.clear();
+    }
+    if (!dev_pose_dirty_.empty()) {
+        std::sort(dev_pose_dirty_.begin(), dev_pose_dirty_.end());
+        dev_pose_dirty_.erase(std::unique(dev_pose_dirty_.begin(), dev_pose_dirty_.end()), dev_pose_dirty_.end());
+        std::vector<int32_t> ids; std::vector<double> T;
+        for (int kfid : dev_pose_dirty_) {
+            auto pkf = getKeyframe(kfid);
+            if (!pkf) continue;
+            const SE3 t = pkf->getTwc();
+            ids.push_back(kfid); T.insert(T.end(), t.v.begin(), t.v.end());
+        }
+        if ((s = ov2_map_set_poses(dev_, (int)ids.size(), ids.data(), T.data())) != OV2_OK) return s;
+        dev_pose_dirty_.clear();
+    }
+    return OV2_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- FeatureTracker
@@ -626,6 +723,52 @@ void Optimizer::setupLocalBA(Frame &newframe, LocalBAProblem &pb)
     }
 }
 
+ov2_status Optimizer::setupLocalBADevice(Frame &newframe, LocalBAProblem &pb)
+{   // src/optimizer.cpp:43-430 through ov2_map_local_ba_setup; fills the same LocalBAProblem as setupLocalBA
+    ov2_status s = pmap_->flushDevice();
+    if (s != OV2_OK) return s;
+    const bool inv = pslamstate_->buse_inv_depth_;
+    const CameraCalibration &cl = *newframe.pcalib_leftcam_;
+    const double Kl[4] = {cl.fx_, cl.fy_, cl.cx_, cl.cy_};
+    ov2_local_ba_setup f;
+    s = ov2_map_local_ba_setup(pmap_->dev_, newframe.kfid_, pslamstate_->nmin_covscore_, pslamstate_->stereo_ ? 1 : 2, inv ? 1 : 0, Kl, &f);
+    if (s != OV2_OK) return s;
+    if (f.aborted) { pb.aborted = true; return OV2_OK; }
+    const size_t P = f.n_pose, L = f.n_lm, R = f.n_res, e = inv ? 1 : 3;
+    pb.pose_kfid.assign(f.pose_kfid, f.pose_kfid + P);
+    pb.pose_const.assign(f.pose_const, f.pose_const + P);
+    pb.pose.assign(f.pose, f.pose + 7 * P);
+    pb.lm_lmid.assign(f.lm_lmid, f.lm_lmid + L);
+    pb.lm.assign(f.lm, f.lm + e * L);
+    pb.lm_anchor_pose.assign(f.lm_anchor_pose, f.lm_anchor_pose + L);
+    pb.lm_anchor_uv.assign(f.lm_anchor_uv, f.lm_anchor_uv + 2 * L);
+    pb.res_type.assign(f.res_type, f.res_type + R);
+    pb.res_pose.assign(f.res_pose, f.res_pose + R);
+    pb.res_lm.assign(f.res_lm, f.res_lm + R);
+    pb.res_uv.assign(f.res_uv, f.res_uv + 2 * R);
+    pb.res_sigma.assign(f.res_sigma, f.res_sigma + R);
+    // the id maps the update stage walks (:741-882)
+    pb.kfid_to_pose.reserve(P); pb.map_local_pkfs.reserve(P);
+    for (size_t i = 0; i < P; ++i) {
+        const int kfid = pb.pose_kfid[i];
+        pb.kfid_to_pose.emplace(kfid, (int)i);
+        pb.map_local_pkfs.emplace(kfid, pmap_->getKeyframe(kfid));
+        if (pb.pose_const[i]) pb.set_cstkfids.insert(kfid);
+    }
+    pb.lmid_to_lm.reserve(L); pb.map_local_plms.reserve(L);
+    for (size_t i = 0; i < L; ++i) {
+        const int lmid = pb.lm_lmid[i];
+        pb.lmid_to_lm.emplace(lmid, (int)i);
+        pb.map_local_plms.emplace(lmid, pmap_->getMapPoint(lmid));
+    }
+    for (int i = 0; i < f.n_bad; ++i) {   // MapPoint::isBad() also clears is3d_ (src/map_point.cpp:219,227)
+        pb.set_badlmids.insert(f.bad_lmid[i]);
+        auto plm = pmap_->getMapPoint(f.bad_lmid[i]);
+        if (plm) { plm->isBad(); pmap_->touchMapPoint(f.bad_lmid[i]); }
+    }
+    return OV2_OK;
+}
+
 void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res)
 {   // flags :500-592 / :637-735, update :741-882
     const bool inv = pslamstate_->buse_inv_depth_;
@@ -640,7 +783,7 @@ void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov
     }
     for (const auto &b : vbadstereokflmids) {   // :743-751
         auto it = pb.map_local_pkfs.find(b.first);
-        if (it != pb.map_local_pkfs.end()) it->second->removeStereoKeypointById(b.second);
+        if (it != pb.map_local_pkfs.end()) { it->second->removeStereoKeypointById(b.second); pmap_->touchStereoOff(b.first, b.second); }
         pb.set_badlmids.insert(b.second);
     }
     for (const auto &b : vbadkflmids) {         // :753-764
@@ -655,6 +798,7 @@ void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov
         SE3 T;
         for (int k = 0; k < 7; ++k) T.v[k] = pb.pose[7 * idx + k];
         kv.second->setTwc(T);
+        pmap_->touchPose(kv.first);
     }
     for (const auto &kv : pb.map_local_plms) {   // :789-853 landmarks
         const int lmid = kv.first;
@@ -695,7 +839,12 @@ void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov
 ov2_status Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)
 {
     LocalBAProblem pb;
-    setupLocalBA(newframe, pb);
+    if (pmap_->dev_) {
+        const ov2_status ss = setupLocalBADevice(newframe, pb);
+        if (ss != OV2_OK) return ss;
+    } else {
+        setupLocalBA(newframe, pb);
+    }
     if (pb.aborted || pb.res_type.empty()) { bstop_localba_ = false; return OV2_OK; }
     ov2_ba_problem p = pb.view(*pslamstate_, newframe);
     ov2_ba_options o;

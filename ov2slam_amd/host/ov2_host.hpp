@@ -121,6 +121,19 @@ public:
     // not reproduced: keypoints without a 3D prior start from their left pixel.
     ov2_status stereoMatching(Frame &frame, const struct Pyramid &vleftpyr, const struct Pyramid &vrightpyr,
                               const class FeatureTracker &tracker, const struct SlamParams &st, bool rectified);
+
+    // ---- flat device mirror (include/ov2slam_hip.h "ov2_map"): the hash maps above stay the host's source of truth,
+    // every mutation that the local-BA set-up can see is queued here and pushed in batches (flushDevice) before the
+    // next device set-up.  attachDevice walks the whole map once.
+    ~MapManager();
+    ov2_status attachDevice(ov2_ctx *ctx, int max_kf, int max_lm, int max_obs);
+    ov2_status addKeyframeToDevice(const Frame &kf);        // MapManager::addKeyframe hook
+    ov2_status flushDevice();
+    void touchMapPoint(int lmid) { if (dev_) dev_lm_dirty_.push_back(lmid); }
+    void touchPose(int kfid) { if (dev_) dev_pose_dirty_.push_back(kfid); }
+    void touchStereoOff(int kfid, int lmid) { if (dev_) { dev_st_kf_.push_back(kfid); dev_st_lm_.push_back(lmid); } }
+    ov2_map *dev_ = nullptr;
+    std::vector<int32_t> dev_lm_dirty_, dev_pose_dirty_, dev_rm_kf_, dev_rm_lm_, dev_st_kf_, dev_st_lm_;
 };
 
 struct SlamParams {   // the subset of include/slam_params.hpp the path reads (YAML keys of the same name)
@@ -232,6 +245,8 @@ public:
     ov2_status localBA(Frame &newframe, const bool buse_robust_cost);
     // the three stages, exposed for tests
     void setupLocalBA(Frame &newframe, LocalBAProblem &pb);                                   // :43-430
+    // the same stage from the device map mirror (ov2_map_local_ba_setup): linear scans instead of the hash-map walk
+    ov2_status setupLocalBADevice(Frame &newframe, LocalBAProblem &pb);
     void updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res);   // :741-882
     bool stopLocalBA() const { return bstop_localba_; }
     void signalStopLocalBA() { bstop_localba_ = true; }

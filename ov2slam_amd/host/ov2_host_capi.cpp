@@ -94,6 +94,45 @@ int ov2h_local_ba_setup(void *p, int newkf, int *n_pose, int *n_lm, int *n_res)
     return m->pb.aborted ? 1 : 0;
 }
 
+// device map mirror: walk the host map once into an ov2_map; later set-ups (and ov2h_apply_local_ba) use it
+int ov2h_map_attach_device(void *p, void *ctx, int max_kf, int max_lm, int max_obs)
+{
+    HostMap *m = (HostMap *)p;
+    return (int)m->map->attachDevice((ov2_ctx *)ctx, max_kf, max_lm, max_obs);
+}
+
+int ov2h_local_ba_setup_dev(void *p, int newkf, int *n_pose, int *n_lm, int *n_res)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(newkf);
+    if (!f || !m->map->dev_) return -1;
+    Optimizer opt(nullptr, m->st, m->map);
+    m->pb = LocalBAProblem();
+    if (opt.setupLocalBADevice(*f, m->pb) != OV2_OK) return -2;
+    *n_pose = (int)m->pb.pose_const.size(); *n_lm = (int)m->pb.lm_lmid.size(); *n_res = (int)m->pb.res_type.size();
+    return m->pb.aborted ? 1 : 0;
+}
+
+// test hooks for the incremental path: mutate the host map through the MapManager (which queues the device edits)
+int ov2h_map_remove_obs(void *p, int kfid, int lmid) { ((HostMap *)p)->map->removeMapPointObs(lmid, kfid); return 0; }
+int ov2h_map_remove_landmark(void *p, int lmid) { ((HostMap *)p)->map->removeMapPoint(lmid); return 0; }
+int ov2h_map_set_isobs(void *p, int lmid, int isobs)
+{
+    HostMap *m = (HostMap *)p;
+    auto plm = m->map->getMapPoint(lmid);
+    if (!plm) return -1;
+    plm->isobs_ = isobs != 0;
+    m->map->touchMapPoint(lmid);
+    return 0;
+}
+int ov2h_map_bad_lmids(void *p, int *out, int cap)
+{
+    HostMap *m = (HostMap *)p;
+    int n = 0;
+    for (int l : m->pb.set_badlmids) { if (n < cap) out[n] = l; ++n; }
+    return n;
+}
+
 int ov2h_local_ba_get(void *p, int *pose_kfid, uint8_t *pose_const, double *pose, int *lm_lmid, double *lm,
                       int *lm_anchor_kfid, double *lm_anchor_uv, uint8_t *res_type, int *res_kfid, int *res_lmid,
                       double *res_uv)

@@ -25,6 +25,12 @@ def lib():
         L.ov2h_map_add_obs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
         L.ov2h_map_finalize.argtypes = [C.c_void_p, C.c_int]
         L.ov2h_local_ba_setup.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ov2h_map_attach_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ov2h_local_ba_setup_dev.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ov2h_map_remove_obs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ov2h_map_remove_landmark.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_map_set_isobs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ov2h_map_bad_lmids.argtypes = [C.c_void_p, ip, C.c_int]
         L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
         L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int]
@@ -106,11 +112,38 @@ class HostMap:
             lib().ov2h_map_destroy(self.h)
             self.h = None
 
-    def setup_local_ba(self):
-        """Optimizer::setupLocalBA (CPU). returns dict of the flat problem keyed by reference ids."""
+    def attach_device(self, ctx, max_kf=None, max_lm=None, max_obs=None):
+        """MapManager::attachDevice: mirror the whole map into an ov2_map (HBM tables); later set-ups can run there."""
+        n_obs = self.prob.n_res + len(self.prob.lm)
+        rc = lib().ov2h_map_attach_device(self.h, ctx.h, max_kf or len(self.prob.pose) + 8, max_lm or len(self.prob.lm) + 8,
+                                          max_obs or n_obs + 64)
+        if rc != 0:
+            raise RuntimeError(f"attachDevice failed (status {rc})")
+
+    def remove_obs(self, kfid, lmid):
+        lib().ov2h_map_remove_obs(self.h, int(kfid), int(lmid))
+
+    def remove_landmark(self, lmid):
+        lib().ov2h_map_remove_landmark(self.h, int(lmid))
+
+    def set_isobs(self, lmid, isobs):
+        """MapPoint::isobs_ (seen by the current frame)"""
+        assert lib().ov2h_map_set_isobs(self.h, int(lmid), int(isobs)) == 0
+
+    def bad_lmids(self):
+        buf = np.zeros(max(1, len(self.prob.lm)), np.int32)
+        n = lib().ov2h_map_bad_lmids(self.h, buf.ctypes.data_as(C.POINTER(C.c_int)), len(buf))
+        return np.sort(buf[:n])
+
+    def setup_local_ba(self, dev=False):
+        """Optimizer::setupLocalBA (CPU hash-map walk) or, dev=True, Optimizer::setupLocalBADevice (scans of the device
+        map mirror). returns dict of the flat problem keyed by reference ids."""
         L = lib()
         npose, nlm, nres = C.c_int(), C.c_int(), C.c_int()
-        rc = L.ov2h_local_ba_setup(self.h, self.newkf, C.byref(npose), C.byref(nlm), C.byref(nres))
+        fn = L.ov2h_local_ba_setup_dev if dev else L.ov2h_local_ba_setup
+        rc = fn(self.h, self.newkf, C.byref(npose), C.byref(nlm), C.byref(nres))
+        if rc < 0:
+            raise RuntimeError(f"local BA set-up failed ({rc})")
         e = 1 if self.prob.inv_depth else 3
         ip, u8 = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
         out = dict(aborted=rc == 1, pose_kfid=np.zeros(npose.value, np.int32), pose_const=np.zeros(npose.value, np.uint8),

@@ -30,6 +30,11 @@ w = d_w.get()
 it, ps_ = (w & 0xffff), (w >> 16)
 print(f"B={B}: tracked {d_s.get().mean():.3f}; 2-level passes on {np.count_nonzero(ps_[:n])} kps ({it[:n].sum()} iterations, {ps_[:n].sum()} level passes); "
       f"full-pyramid passes on {np.count_nonzero(ps_[n:])} kps ({it[n:].sum()} iterations, {ps_[n:].sum()} level passes)")
+a = it[:n][ps_[:n] > 0].astype(np.float64)
+for g in (4, 8):
+    m = a[:len(a) // g * g].reshape(-1, g)
+    print(f"  divergence estimate, {g} keypoints per wave: mean iterations {a.mean():.2f}, mean of per-wave max {m.max(1).mean():.2f} "
+          f"(lock-step efficiency {a.mean() / m.max(1).mean():.2f}); histogram of iterations {np.bincount(a.astype(int))[:32].tolist()}")
 ctx.kernel_timing(True); ctx.kernel_times()
 R = 20
 for _ in range(R):

@@ -1,0 +1,135 @@
+"""Device map mirror (ov2_map, csrc/map.hip): the set-up stage of Optimizer::localBA as linear scans of the observation
+table equals the reference's hash-map walk (src/optimizer.cpp:43-430, restated in ov2slam_amd/host Optimizer::setupLocalBA)
+-- same keyframes with the same constness, same landmarks / anchors, same multiset of residual blocks, same bad
+landmarks -- on fresh maps, after incremental edits pushed through the MapManager hooks, and after a local BA's own
+update stage.  Index orders differ by design (ascending ids here), so problems are compared keyed by kfid / lmid."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ov2slam_amd import _lib, host_map, synth_ba
+
+pytestmark = pytest.mark.gpu
+
+
+def canon(pb):
+    if pb["aborted"]:
+        return "aborted"
+    poses = {int(k): (int(c), tuple(p)) for k, c, p in zip(pb["pose_kfid"], pb["pose_const"], pb["pose"])}
+    lms = {int(l): (tuple(v), int(a), tuple(uv)) for l, v, a, uv in zip(pb["lm_lmid"], pb["lm"], pb["lm_anchor_kfid"], pb["lm_anchor_uv"])}
+    res = sorted((int(t), int(k), int(l), float(uv[0]), float(uv[1]))
+                 for t, k, l, uv in zip(pb["res_type"], pb["res_kfid"], pb["res_lmid"], pb["res_uv"]))
+    return poses, lms, res
+
+
+def assert_same(hm, hd=None, tol=0.0):
+    """hm: map set up by the hash-map walk, hd: identical map set up through its device mirror (the same object when
+    no isBad() landmark is around: MapPoint::isBad() clears is3d_ as a side effect (src/map_point.cpp:219), so two
+    set-ups of ONE map do not see the same state)"""
+    hd = hd or hm
+    a = hm.setup_local_ba(dev=False)
+    bad_a = hm.bad_lmids()
+    b = hd.setup_local_ba(dev=True)
+    bad_b = hd.bad_lmids()
+    assert np.array_equal(bad_a, bad_b), "isBad() landmarks differ"
+    ca, cb = canon(a), canon(b)
+    if ca == "aborted" or cb == "aborted":
+        assert ca == cb
+        return a
+    pa, la, ra = ca
+    pb_, lb, rb = cb
+    assert {k: v[0] for k, v in pa.items()} == {k: v[0] for k, v in pb_.items()}, "keyframes / constness differ"
+    for k in pa:   # tol > 0: the two maps went through two (differently ordered, equally valid) solves
+        assert np.allclose(pa[k][1], pb_[k][1], rtol=0, atol=tol), "poses differ"
+    assert ra == rb, "residual blocks differ"
+    assert sorted(la) == sorted(lb), "landmark sets differ"
+    for l in la:
+        va, aa, ua = la[l]
+        vb, ab, ub = lb[l]
+        assert aa == ab and ua == ub
+        assert np.allclose(va, vb, rtol=max(1e-12, tol), atol=tol), (l, va, vb)   # 1/z: R'(p - t) here, (Tcw * p).z there
+    return a
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+@pytest.mark.parametrize("n_kf,n_lm,nmin", [(8, 300, 25), (30, 4000, 25), (50, 10000, 25), (30, 3000, 200), (12, 500, 10 ** 6)])
+def test_device_setup_equals_hash_map_walk(ctx, inv_depth, n_kf, n_lm, nmin):
+    P = synth_ba.make_window(n_kf, n_lm, inv_depth=inv_depth, seed=n_kf + n_lm, max_obs=7)
+    hm = host_map.HostMap(P, nmin_covscore=nmin)
+    hm.attach_device(ctx)
+    a = assert_same(hm)
+    if nmin == 10 ** 6:
+        assert a["aborted"]
+    elif n_kf >= 30:
+        assert 0 < int(np.sum(a["pose_const"])) and len(a["pose_kfid"]) <= n_kf   # a real window: constants present
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_incremental_edits_reach_the_device(ctx, inv_depth):
+    P = synth_ba.make_window(20, 2000, inv_depth=inv_depth, seed=77, max_obs=6)
+    hw, hd = host_map.HostMap(P), host_map.HostMap(P)
+    hd.attach_device(ctx)
+    a = assert_same(hw, hd)
+    rng = np.random.default_rng(5)
+    # drop observations, whole landmarks, clear isobs_ on a third, and bring a few landmarks down to ONE observer that
+    # the current frame does not see: MapPoint::isBad()
+    pick = rng.choice(len(a["res_kfid"]), 400, replace=False)
+    gone = set(int(l) for l in rng.choice(a["lm_lmid"], 60, replace=False))
+    lonely = [int(l) for l in a["lm_lmid"][1::50] if int(l) not in gone][:12]
+    for h in (hw, hd):
+        for i in pick:
+            h.remove_obs(a["res_kfid"][i], a["res_lmid"][i])
+        for l in gone:
+            h.remove_landmark(l)
+        for l in a["lm_lmid"][::3]:
+            if int(l) not in gone:
+                h.set_isobs(l, 0)
+        for l in lonely:
+            ks = sorted({int(k) for k, ll in zip(a["res_kfid"], a["res_lmid"]) if int(ll) == l} |
+                        ({int(a["lm_anchor_kfid"][list(a["lm_lmid"]).index(l)])} if inv_depth else set()))
+            for k in ks[:-1]:
+                h.remove_obs(k, l)
+            h.set_isobs(l, 0)
+    b = assert_same(hw, hd)
+    assert len(b["res_type"]) < len(a["res_type"]) and len(b["lm_lmid"]) < len(a["lm_lmid"])
+    assert len(hd.bad_lmids()) > 0
+    # and once more: the cleared is3d_ flags went to the device with the next flush
+    assert_same(hw, hd)
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_local_ba_through_the_mirror_equals_the_walk(ctx, inv_depth):
+    """Estimator::applyLocalBA with the device set-up == with the host walk; its update stage (poses, landmarks,
+    removed observations, demoted stereo keypoints) reaches the mirror, so the NEXT set-up agrees too."""
+    P = synth_ba.make_window(12, 800, inv_depth=inv_depth, seed=31)
+    h0, h1 = host_map.HostMap(P), host_map.HostMap(P)
+    h1.attach_device(ctx)
+    r0, r1 = h0.apply_local_ba(ctx), h1.apply_local_ba(ctx)
+    assert r0[0] == 0 and r1[0] == 0
+    assert r0[1:3] == r1[1:3]
+    assert r1[3] == pytest.approx(r0[3], rel=1e-9)
+    for k in range(len(P.pose)):
+        assert np.allclose(h0.pose(k), h1.pose(k), atol=1e-9)
+    assert_same(h0, h1, tol=1e-8)
+
+
+def test_capacity_and_argument_errors(ctx):
+    L = ctx.lib
+    m = C.c_void_p()
+    assert L.ov2_map_create(ctx.h, 4, 8, 16, C.byref(m)) == 0
+    T = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    lm = np.arange(10, dtype=np.int32)
+    uv = np.zeros((10, 2))
+    vp = lambda a: a.ctypes.data
+    assert L.ov2_map_add_keyframe(m, 7, vp(T), 0, None, None, None, None, None) != 0        # kfid beyond capacity
+    assert L.ov2_map_add_keyframe(m, 1, vp(T), 10, vp(lm), vp(uv), None, None, None) != 0    # lmid 8, 9 beyond capacity
+    assert L.ov2_map_add_keyframe(m, 1, vp(T), 8, vp(lm), vp(uv), None, None, None) == 0
+    assert L.ov2_map_add_keyframe(m, 2, vp(T), 8, vp(lm), vp(uv), None, None, None) == 0
+    assert L.ov2_map_add_keyframe(m, 3, vp(T), 1, vp(lm), vp(uv), None, None, None) != 0     # observation table full
+    out = (C.c_byte * 256)()
+    assert L.ov2_map_local_ba_setup(m, 9, 25, 1, 1, None, out) != 0
+    # no landmark is alive yet: nb3dkps = 0 < nmin_covscore -> aborted, not an error
+    assert L.ov2_map_local_ba_setup(m, 2, 25, 1, 1, None, out) == 0
+    assert np.frombuffer(out, np.int32, 1)[0] == 1
+    L.ov2_map_destroy(m)
