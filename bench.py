@@ -448,6 +448,31 @@ def main():
                                            "kind": "port", "sample": f"one solve of the same window ({dt:.2f} s), "
                                            "oracle/ C restatement of the Ceres LM + Schur path, 1 thread "
                                            "(the reference runs localBA with num_threads = 1, src/optimizer.cpp:460)"}
+    if do_cpu and ba:
+        # set-up stage of Optimizer::localBA on a map holding the same window: the reference-style hash-map walk (C++
+        # host mirror, this host's core) beside the scans of the device map mirror (whole call: scans, 2 syncs, D2H of
+        # the flat problem, host id maps).  Outside the timed region; reported, not part of `value`.
+        try:
+            import ctypes as C
+            from ov2slam_amd import host_map
+            hm = host_map.HostMap(ba.P0)
+            hm.attach_device(ctx)
+            HL = host_map.lib()
+            na, nb, nc = C.c_int(), C.c_int(), C.c_int()
+
+            def t_setup(fn, reps=10):
+                fn(hm.h, hm.newkf, C.byref(na), C.byref(nb), C.byref(nc))
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn(hm.h, hm.newkf, C.byref(na), C.byref(nb), C.byref(nc))
+                return 1e3 * (time.perf_counter() - t) / reps
+            out["local_ba"]["setup"] = {"hash_map_walk_ms": t_setup(HL.ov2h_local_ba_setup),
+                                        "device_map_scans_ms": t_setup(HL.ov2h_local_ba_setup_dev),
+                                        "problem": {"poses": na.value, "landmarks": nb.value, "residual_blocks": nc.value},
+                                        "note": "src/optimizer.cpp:43-430; walk = C++ mirror of the reference's maps on 1 host core"}
+            del hm
+        except Exception as e:   # the set-up comparison is a side report: never lose the bench line to it
+            out["local_ba"]["setup"] = {"error": repr(e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

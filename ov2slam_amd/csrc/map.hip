@@ -30,6 +30,7 @@ struct ov2_map {
     unsigned char *lm_new;                                          // [max_lm] observed by the new keyframe
     int *obs_cnt, *obs_off;                                         // [max_obs]
     int *blk;                                                       // block sums of the scans
+    unsigned char *zero_blk; size_t zero_bytes;                     // hdr | cov | kf_role | lm_nobs | lm_sel | lm_new: one memset per set-up
     // outputs: device image + pinned host image of the flat problem
     unsigned char *out_dev, *out_host;
     size_t out_cap;
@@ -452,8 +453,14 @@ extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max
 #define A(p, n) if (s == OV2_OK) s = dmalloc(c, &m->p, (n))
     A(kf_pose, 7 * K); A(kf_state, K); A(lm_xyz, 3 * L); A(lm_state, L);
     A(obs_kf, N); A(obs_lm, N); A(obs_scale, N); A(obs_uv, 2 * N); A(obs_ruv, 2 * N); A(obs_flag, N);
-    A(hdr, MH_N); A(cov, K); A(kf_role, K); A(kf_idx, K);
-    A(lm_nobs, L); A(lm_sel, L); A(lm_anchor, L); A(lm_idx, L); A(lm_flag, L); A(bad_idx, L); A(lm_new, L);
+    A(kf_idx, K); A(lm_anchor, L); A(lm_idx, L); A(lm_flag, L); A(bad_idx, L);
+    m->zero_bytes = sizeof(int) * (MH_N + 2 * K + 2 * L) + L;
+    A(zero_blk, m->zero_bytes);
+    if (s == OV2_OK) {
+        int *z = reinterpret_cast<int *>(m->zero_blk);
+        m->hdr = z; m->cov = z + MH_N; m->kf_role = m->cov + K; m->lm_nobs = m->kf_role + K; m->lm_sel = m->lm_nobs + L;
+        m->lm_new = reinterpret_cast<unsigned char *>(m->lm_sel + L);
+    }
     A(obs_cnt, N); A(obs_off, N); A(blk, (std::max(N, L) + 1023) / 1024 + 1);
 #undef A
     if (s == OV2_OK && hipHostMalloc((void **)&m->hdr_host, MH_N * sizeof(int), hipHostMallocDefault) != hipSuccess)
@@ -471,8 +478,8 @@ extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max
 static void free_tables(ov2_map *m)
 {
     void *dev[] = {m->kf_pose, m->kf_state, m->lm_xyz, m->lm_state, m->obs_kf, m->obs_lm, m->obs_scale, m->obs_uv, m->obs_ruv,
-                   m->obs_flag, m->hdr, m->cov, m->kf_role, m->kf_idx, m->lm_nobs, m->lm_sel, m->lm_anchor, m->lm_idx,
-                   m->lm_flag, m->bad_idx, m->lm_new, m->obs_cnt, m->obs_off, m->blk, m->out_dev};
+                   m->obs_flag, m->zero_blk, m->kf_idx, m->lm_anchor, m->lm_idx, m->lm_flag, m->bad_idx, m->obs_cnt, m->obs_off,
+                   m->blk, m->out_dev};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (m->out_host) (void)hipHostFree(m->out_host);
     if (m->hdr_host) (void)hipHostFree(m->hdr_host);
@@ -666,12 +673,7 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     const int N = m->n_obs, K = m->max_kf, L = m->max_lm, inv = inv_depth ? 1 : 0;
     const map_view M = view_of(m);
     const dim3 gN((std::max(N, 1) + 255) / 256), gL((L + 255) / 256), gK((K + 255) / 256), b(256);
-    OV2_HIP(c, hipMemsetAsync(m->hdr, 0, MH_N * sizeof(int), st));
-    OV2_HIP(c, hipMemsetAsync(m->cov, 0, sizeof(int) * K, st));
-    OV2_HIP(c, hipMemsetAsync(m->kf_role, 0, sizeof(int) * K, st));
-    OV2_HIP(c, hipMemsetAsync(m->lm_nobs, 0, sizeof(int) * L, st));
-    OV2_HIP(c, hipMemsetAsync(m->lm_sel, 0, sizeof(int) * L, st));
-    OV2_HIP(c, hipMemsetAsync(m->lm_new, 0, L, st));
+    OV2_HIP(c, hipMemsetAsync(m->zero_blk, 0, m->zero_bytes, st));
     OV2_HIP(c, hipMemsetAsync(m->lm_anchor, 0x7f, sizeof(int) * L, st));   // 0x7f7f7f7f: larger than any kfid
     OV2_LAUNCH(c, OV2_K_MAP, ms_count_kernel, gN, b, 0, st, M, newkf, m->lm_nobs, m->lm_new, m->hdr);
     OV2_LAUNCH(c, OV2_K_MAP, ms_cov_kernel, gN, b, 0, st, M, newkf, (const unsigned char *)m->lm_new, m->cov);
