@@ -24,6 +24,9 @@ def short(name):
     """'void (anonymous namespace)::klt_stage2_kernel<9>(ov2_pyr_view, ...)' -> 'klt_stage2_kernel' (the name
     bench.py's hipEvent table uses); template arguments are dropped, instantiations of one kernel are pooled."""
     n = name.strip('"').replace("(anonymous namespace)::", "")
+    m = re.search(r"rocprim::\w+::detail::wrapped_(\w+?)_config", n)
+    if m:   # hipCUB / rocPRIM device-wide primitives (key sorts and scans of the BA program build)
+        return "rocprim_" + m.group(1)
     head = n.split("(", 1)[0]
     while True:
         t = re.sub(r"<[^<>]*>", "", head)
