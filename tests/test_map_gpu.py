@@ -66,6 +66,17 @@ def test_device_setup_equals_hash_map_walk(ctx, inv_depth, n_kf, n_lm, nmin):
 
 
 @pytest.mark.parametrize("inv_depth", [True, False])
+def test_gauge_fix_in_mono_mode(ctx, inv_depth):
+    """mono: two constant keyframes are required (src/optimizer.cpp:65-68); only kfid 0 is constant by the walk, so the
+    smallest optimised kfid is fixed as well (:394-407) -- on both sides"""
+    P = synth_ba.make_window(8, 300, inv_depth=inv_depth, seed=4)
+    hm = host_map.HostMap(P, stereo=False)
+    hm.attach_device(ctx)
+    a = assert_same(hm)
+    assert {int(k) for k, c in zip(a["pose_kfid"], a["pose_const"]) if c} == {0, 1}
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
 def test_incremental_edits_reach_the_device(ctx, inv_depth):
     P = synth_ba.make_window(20, 2000, inv_depth=inv_depth, seed=77, max_obs=6)
     hw, hd = host_map.HostMap(P), host_map.HostMap(P)
