@@ -83,6 +83,65 @@ __device__ __forceinline__ unsigned ld_u16(const unsigned char *p)
     return r;
 }
 
+// 16 bytes from a dword-aligned address: one global_load_dwordx4
+__device__ __forceinline__ uint4 ld_b128(const unsigned char *p)
+{
+    return *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(p, 4));
+}
+
+// LDS staging of one keypoint's windows.  The kernel is bound by the texture addresser, not by VALU or HBM (TA busy
+// 80-90 % of the launch with one 2-byte gather per lane, row and iteration): the rows of a window are now fetched
+// with 16-byte loads (one lane per row: (WIN+1) x 16 B cover the WIN+1 columns a bilinear window touches) into LDS,
+// and the lanes read their column's pixel pairs from there.  Per group: two u8 windows (template I, search J) of
+// (WIN+1) rows x 16 B and one gradient window of (WIN+1) rows x GSEG x 16 B; +16 B so that the groups of a wave start
+// in different banks.
+template <int WIN>
+struct klt_lds {
+    static constexpr int ROWS = WIN + 1;
+    static constexpr int GSEG = ((WIN + 1) * 4 + 15) / 16;
+    static constexpr int WB = ROWS * 16 + 16;
+    static constexpr int GB = ROWS * GSEG * 16 + 16;
+};
+
+// rows r = sub, sub + GL, ... of a (WIN+1) x 16 B window.  src is DWORD-ALIGNED (the caller rounds the window's first
+// column down to a multiple of 4 and keeps the remainder as the read offset: (WIN+1) + 3 <= 16 bytes): a byte-aligned
+// 16-byte load is legal but is split by the memory pipeline (measured: 345 us instead of 204 us for the launch).
+template <int WIN, int GL>
+__device__ __forceinline__ void stage_u8(const unsigned char *src, int stride, unsigned char *lw, int sub)
+{
+    constexpr int NK = (WIN + 1 + GL - 1) / GL;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int r = sub + GL * k;
+        if (r < WIN + 1) *reinterpret_cast<uint4 *>(lw + r * 16) = ld_b128(src + (size_t)r * stride);
+    }
+}
+
+// 16-byte segments s = sub, sub + GL, ... of the (WIN+1) x GSEG gradient window ((Ix,Iy) int16 pairs, 4 B per pixel)
+template <int WIN, int GL>
+__device__ __forceinline__ void stage_grad(const int *src, int gstride, unsigned char *lg, int sub)
+{
+    constexpr int GSEG = klt_lds<WIN>::GSEG, NS = (WIN + 1) * GSEG, NK = (NS + GL - 1) / GL;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int sg = sub + GL * k;
+        if (sg < NS) {
+            const int row = sg / GSEG, part = sg - row * GSEG;
+            *reinterpret_cast<uint4 *>(lg + sg * 16) =
+                ld_b128(reinterpret_cast<const unsigned char *>(src + (size_t)row * gstride) + part * 16);
+        }
+    }
+}
+
+// (p[0], p[1]) of an LDS byte address with ALIGNED reads: the dword pair around it + v_alignbyte (odd-address
+// ds_read_u16 is legal but slow)
+__device__ __forceinline__ unsigned lds_u8x2(const unsigned char *p)
+{
+    const unsigned a = (unsigned)(size_t)p;
+    const unsigned *q = reinterpret_cast<const unsigned *>(p - (a & 3u));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+}
+
 typedef short ov2_s16x2 __attribute__((ext_vector_type(2)));
 
 // v_dot2_i32_i16: a.lo * b.lo + a.hi * b.hi + c (signed 16-bit halves, 32-bit accumulate, no clamp)
@@ -124,8 +183,10 @@ __device__ __forceinline__ level_ptrs level_of(const ov2_pyr_view &v, int l, int
 template <int WIN, int GL>
 __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
                                         bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
-                                        float &err, const klt_params &P, int sub, unsigned &passes)
+                                        float &err, const klt_params &P, int sub, unsigned &passes,
+                                        unsigned char *lwI, unsigned char *lwJ, unsigned char *lg)
 {
+    constexpr int GROW = klt_lds<WIN>::GSEG * 4;   // ints per row of the staged gradient window
     constexpr int OC = WIN < GL ? WIN : GL;        // columns with an owner lane
     constexpr int NE = (WIN - OC) * WIN;           // pixels of the remaining columns
     constexpr int NR = (NE + GL - 1) / GL;         // rounds to deal them out
@@ -164,9 +225,21 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         // fit int16 (w11 can be -1 after rounding), pixels and Scharr gradients too
         const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         const int bx0 = run ? (OV2_LM + ipx) : OV2_LM, by = run ? (ipy + pad) : pad;
-        const unsigned char *ip = I.img + (size_t)by * I.istride + bx0 + sc;
-        const int *gp = I.grad + (size_t)by * I.gstride + bx0 + sc;
-        unsigned T = spread_u8x2(ld_u16(ip));
+        // stage the template windows and, with them, the search window of the first iteration (its position is known)
+        {
+            const float sx = nx - half, sy = ny - half;
+            const int inx0 = (int)floorf(sx), iny0 = (int)floorf(sy);
+            const bool in0 = run && !(inx0 < -WIN || inx0 >= J.w || iny0 < -WIN || iny0 >= J.h);
+            __syncthreads();   // the previous pass may still read these buffers
+            const int jx0 = OV2_LM + (in0 ? inx0 : 0);
+            stage_u8<WIN, GL>(I.img + (size_t)by * I.istride + (bx0 & ~3), I.istride, lwI, sub);
+            stage_grad<WIN, GL>(I.grad + (size_t)by * I.gstride + bx0, I.gstride, lg, sub);
+            stage_u8<WIN, GL>(J.img + (size_t)((in0 ? iny0 : 0) + pad) * J.istride + (jx0 & ~3), J.istride, lwJ, sub);
+            __syncthreads();
+        }
+        const unsigned char *ip = lwI + (bx0 & 3) + sc;
+        const int *gp = reinterpret_cast<const int *>(lg) + sc;
+        unsigned T = spread_u8x2(lds_u8x2(ip));
         unsigned GX, GY;
         {
             const unsigned g0 = (unsigned)gp[0], g1 = (unsigned)gp[1];
@@ -176,8 +249,8 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         unsigned piv = 0, pix = 0, piy = 0;
 #pragma unroll
         for (int y = 0; y < WIN; ++y) {
-            ip += I.istride; gp += I.gstride;
-            const unsigned B = spread_u8x2(ld_u16(ip));
+            ip += 16; gp += GROW;
+            const unsigned B = spread_u8x2(lds_u8x2(ip));
             const unsigned h0 = (unsigned)gp[0], h1 = (unsigned)gp[1];
             const unsigned HX = pack_lo16(h0, h1), HY = pack_hi16(h0, h1);
             const unsigned iv = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
@@ -195,20 +268,18 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             T = B; GX = HX; GY = HY;
         }
         // pixels of the columns without an owner lane
-        const unsigned char *ib = I.img + (size_t)by * I.istride + bx0;
-        const int *gb = I.grad + (size_t)by * I.gstride + bx0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int e = sub + GL * r;
             const bool ev = e < NE;
             const int ec = ev ? e : 0;
             const int ecol = OC + ec / WIN, erow = ec - (ec / WIN) * WIN;
-            eoff[r] = erow * J.istride + ecol;
-            const unsigned char *ipe = ib + erow * I.istride + ecol;
-            const int *gpe = gb + erow * I.gstride + ecol;
-            const unsigned T0 = spread_u8x2(ld_u16(ipe)), T1 = spread_u8x2(ld_u16(ipe + I.istride));
+            eoff[r] = erow * 16 + ecol;
+            const unsigned char *ipe = lwI + (bx0 & 3) + eoff[r];
+            const int *gpe = reinterpret_cast<const int *>(lg) + erow * GROW + ecol;
+            const unsigned T0 = spread_u8x2(lds_u8x2(ipe)), T1 = spread_u8x2(lds_u8x2(ipe + 16));
             const unsigned g0 = (unsigned)gpe[0], g1 = (unsigned)gpe[1];
-            const unsigned h0 = (unsigned)gpe[I.gstride], h1 = (unsigned)gpe[I.gstride + 1];
+            const unsigned h0 = (unsigned)gpe[GROW], h1 = (unsigned)gpe[GROW + 1];
             const unsigned iv = (unsigned)dot2(T1, W23, dot2(T0, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             int ix = dot2(pack_lo16(h0, h1), W23, dot2(pack_lo16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
             int iy = dot2(pack_hi16(h0, h1), W23, dot2(pack_hi16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
@@ -250,22 +321,27 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             run = false;
         }
         lk_weights(nx - (float)inx, ny - (float)iny, w00, w01, w10, w11);
-        const unsigned char *jb = J.img + (size_t)((run ? iny : 0) + pad) * J.istride + OV2_LM + (run ? inx : 0);
+        if (j > 0) {   // iteration 0's window came with the template
+            __syncthreads();
+            stage_u8<WIN, GL>(J.img + (size_t)((run ? iny : 0) + pad) * J.istride + ((OV2_LM + (run ? inx : 0)) & ~3), J.istride, lwJ, sub);
+            __syncthreads();
+        }
+        const unsigned char *jb = lwJ + ((run ? inx : 0) & 3);   // OV2_LM is a multiple of 4
         const unsigned char *jp = jb + sc;
         const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         int pb1 = 0, pb2 = 0;
-        unsigned T = spread_u8x2(ld_u16(jp));
+        unsigned T = spread_u8x2(lds_u8x2(jp));
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            jp += J.istride;
-            unsigned B = spread_u8x2(ld_u16(jp));
+            jp += 16;
+            unsigned B = spread_u8x2(lds_u8x2(jp));
             // taps + rounding >= 1 (w11 >= -1), so the logical shift is the arithmetic one
             const unsigned j0 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             T = B;
             unsigned j1 = 0;
             if (2 * q + 1 < WIN) {
-                jp += J.istride;
-                B = spread_u8x2(ld_u16(jp));
+                jp += 16;
+                B = spread_u8x2(lds_u8x2(jp));
                 j1 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
                 T = B;
             }
@@ -277,13 +353,13 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
 #pragma unroll
         for (int q = 0; q < NRP; ++q) {   // the lane's pixels of the ownerless columns, two rounds per register
             const unsigned char *pe = jb + eoff[2 * q];
-            const unsigned j0 = (unsigned)dot2(spread_u8x2(ld_u16(pe + J.istride)), W23,
-                                               dot2(spread_u8x2(ld_u16(pe)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const unsigned j0 = (unsigned)dot2(spread_u8x2(lds_u8x2(pe + 16)), W23,
+                                               dot2(spread_u8x2(lds_u8x2(pe)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             unsigned j1 = 0;
             if (2 * q + 1 < NR) {
                 const unsigned char *pf = jb + eoff[2 * q + 1];
-                j1 = (unsigned)dot2(spread_u8x2(ld_u16(pf + J.istride)), W23,
-                                    dot2(spread_u8x2(ld_u16(pf)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                j1 = (unsigned)dot2(spread_u8x2(lds_u8x2(pf + 16)), W23,
+                                    dot2(spread_u8x2(lds_u8x2(pf)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             }
             const unsigned d2 = pk_sub16(j0 | (j1 << 16), IvE[q]);
             pb1 = dot2(d2, IxE[q], pb1);
@@ -324,14 +400,14 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
 template <int WIN, int GL>
 __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx,
                                           float ky, float &fx, float &fy, const klt_params &P, int nlevels, int sub,
-                                          unsigned &work)
+                                          unsigned &work, unsigned char *lwI, unsigned char *lwJ, unsigned char *lg)
 {
     int status = 1;
     float err = 0.f;
     unsigned it = 0, passes = 0;
     for (int l = nlevels; l >= 0; --l) {
         const level_ptrs I = level_of(pv, l, b), J = level_of(cv, l, b);
-        it += lk_level<WIN, GL>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes);
+        it += lk_level<WIN, GL>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes, lwI, lwJ, lg);
     }
     // gates of src/feature_tracker.cpp:79-101
     const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
@@ -342,7 +418,7 @@ __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_vi
     float e2 = 0.f, bx = kx, by = ky;
     {
         const level_ptrs I = level_of(cv, 0, b), J = level_of(pv, 0, b);
-        it += lk_level<WIN, GL>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes);
+        it += lk_level<WIN, GL>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes, lwI, lwJ, lg);
     }
     if (ok) {
         if (!st2) ok = 0;
@@ -373,6 +449,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                     unsigned char *__restrict__ status,
                                                     const int *__restrict__ img_idx, unsigned *__restrict__ iters)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
+    const int lgrp = (int)(threadIdx.x / KLT_GL);
     constexpr int KLT_KPW = 64 / KLT_GL;
     const int sub = threadIdx.x & (KLT_GL - 1), i = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
     const bool act = i < n;
@@ -381,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     const float2 kp = kps[ii];
     float2 pr = priors[ii];
     unsigned work = 0;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
     if (act && sub == 0) {
         priors[i] = pr;
         status[i] = (unsigned char)ok;
@@ -450,6 +530,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_a,
                                                         const int *__restrict__ list_b, const unsigned *__restrict__ cnt)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
+    const int lgrp = (int)(threadIdx.x / KLT_GL);
     constexpr int KLT_KPW = 64 / KLT_GL;
     const int total_a = (int)cnt[0], total_b = (int)cnt[1];
     // list B first: its waves run the full pyramid (about twice the work of a list-A wave), so the short list-A waves
@@ -467,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     float2 pr = is_a ? prior[i] : kp;
     unsigned work = 0;
     const int nl = is_a ? min(1, pv.nlevels - 1) : P.nlevels;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
     if (act && sub == 0) {
         out_xy[i] = pr;   // tracked position, or the failed forward result that seeds the re-tracking (:217-219)
         out_status[i] = (unsigned char)ok;
@@ -489,6 +573,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_c,
                                                         const unsigned *__restrict__ cnt, int batch)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
+    const int lgrp = (int)(threadIdx.x / KLT_GL);
     constexpr int KLT_KPW = 64 / KLT_GL;
     const int sub = threadIdx.x & (KLT_GL - 1), grp = (int)(threadIdx.x / KLT_GL);
     // the 33 % flag is per image and must be raised even when no failure of that image is re-tracked
@@ -520,7 +608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     const float2 kp = kps[i];
     float2 pr = drop ? kp : out_xy[i];
     unsigned work = 0;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
     if (act && sub == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
