@@ -106,9 +106,24 @@ struct klt_lds {
 // rows r = sub, sub + GL, ... of a (WIN+1) x 16 B window.  src is DWORD-ALIGNED (the caller rounds the window's first
 // column down to a multiple of 4 and keeps the remainder as the read offset: (WIN+1) + 3 <= 16 bytes): a byte-aligned
 // 16-byte load is legal but is split by the memory pipeline (measured: 345 us instead of 204 us for the launch).
+#ifndef KLT_STAGE_DWORD
+#define KLT_STAGE_DWORD 0
+#endif
 template <int WIN, int GL>
 __device__ __forceinline__ void stage_u8(const unsigned char *src, int stride, unsigned char *lw, int sub)
 {
+#if KLT_STAGE_DWORD
+    // four lanes per row, one dword each: the lanes of a quad share a cache line
+    constexpr int NE4 = (WIN + 1) * 4, NK4 = (NE4 + GL - 1) / GL;
+#pragma unroll
+    for (int k = 0; k < NK4; ++k) {
+        const int e = sub + GL * k;
+        if (e < NE4)
+            *reinterpret_cast<unsigned *>(lw + e * 4) =
+                *reinterpret_cast<const unsigned *>(src + (size_t)(e >> 2) * stride + (e & 3) * 4);
+    }
+    return;
+#endif
     constexpr int NK = (WIN + 1 + GL - 1) / GL;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -440,7 +455,10 @@ __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_vi
 // occupancy bounds handed to the register allocator (min, max waves per SIMD).  Measured on 64 x 2048 keypoints,
 // first launch: register-squeezed to 6-7 waves 228 us, unconstrained (5 waves) 209 us, capped at 3 / 4 / 5 waves
 // 204 / 203.5 / 205 us -- the kernel is issue-bound, extra waves only add pressure, so the allocator gets room.
-#define KLT_WAVES(W, G) 1, 4
+#ifndef KLT_WAVE_CAP
+#define KLT_WAVE_CAP 4
+#endif
+#define KLT_WAVES(W, G) 1, KLT_WAVE_CAP
 
 // 64 threads = 64 / GL keypoints.  grid = ceil(n / (64 / GL))
 template <int WIN, int KLT_GL>

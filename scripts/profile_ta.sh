@@ -6,12 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_ta
 rm -rf $O && mkdir -p $O
-rocprofv3 --list-avail > $O/avail.txt 2>&1 || true
-grep -o "TA_[A-Z_a-z0-9]*\|TCP_[A-Z_a-z0-9]*\|SQ_INSTS_VMEM[A-Z_]*\|SQ_INSTS_LDS\|SQ_INST_CYCLES_VMEM[A-Z_]*\|SQ_ACTIVE_INST_VMEM\|SQ_ACTIVE_INST_LDS" $O/avail.txt | sort -u > $O/names.txt
-wc -l $O/names.txt
-for SET in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+# (a set with a counter this build does not know aborts rocprofv3 and then hangs: only sets that were seen to work)
+for SET in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   tag=$(echo $SET | cut -d' ' -f1)
-  rocprofv3 --pmc $SET --output-format csv -d $O/$tag -- python3 $R/scripts/klt_time.py 64 > $O/$tag.log 2>&1 || { echo "set failed: $SET"; tail -3 $O/$tag.log; continue; }
+  timeout -k 10 150 rocprofv3 --pmc $SET --output-format csv -d $O/$tag -- python3 $R/scripts/klt_time.py 64 > $O/$tag.log 2>&1 || { echo "set failed: $SET"; tail -3 $O/$tag.log; continue; }
 done
 python3 - <<PY
 import csv, glob, collections, re
