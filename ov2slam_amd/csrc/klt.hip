@@ -8,14 +8,15 @@
 // fp32 once (order independent, so the lane reduction is bit-identical to the oracle's scalar loop), fp32
 // 2x2 solve with contraction off, fp64 for the two comparisons OpenCV does in double.
 //
-// Mapping (round-1 measurement: the one-keypoint-per-wave version spent ~200 wave-instructions per LK iteration,
-// most of them wave-uniform scalar work replicated on 64 lanes, and was VALU-issue bound): one keypoint per DPP
-// row of 16 lanes, lane = window column (win <= 11 of 16 lanes busy), each lane walks the win rows of its column.
-//   - every "scalar" of the LK update is per-row vector math, so the 4 keypoints of a wave share each instruction;
-//   - a column needs win+1 two-byte loads per iteration (row y+1's load is row y's lower neighbours);
-//   - sums over the window = DPP row reduction (quad_perm, row_half_mirror, row_mirror), no readlane, no LDS;
-//   - template (I, Ix, Iy per window pixel) stays in registers for the whole level;
-//   - 24-bit multiplies (v_mad_u32_u24 / v_mad_i32_i24) for the fixed-point bilinear taps.
+// Mapping: one keypoint per group of 8 or 16 lanes (8 or 4 keypoints per wave), lane = window column walking the win
+// rows of its column.
+//   - every "scalar" of the LK update is per-group vector math, so the keypoints of a wave share each instruction;
+//   - the windows (template I + its Scharr gradients, search window J) are fetched row-wise with 16-byte loads into LDS
+//     and read from there as pixel pairs: the kernel was bound by the texture addresser when every lane gathered two
+//     bytes per row (see klt_lds below);
+//   - sums over the window = DPP reduction (quad_perm, row_half_mirror, row_mirror), no readlane;
+//   - template (I, Ix, Iy per window pixel) stays in registers for the whole level, two pixels per register;
+//   - bilinear taps as v_dot2_i32_i16 on v_perm_b32-spread pixel pairs.
 // The whole pyramid loop, the gates and the backward pass run inside one launch; no host round trip.
 #include "ov2_internal.h"
 
