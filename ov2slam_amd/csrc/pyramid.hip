@@ -69,7 +69,39 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__r
 #pragma unroll
     for (int k = 0; k < 16; ++k) hist[tid][k] = 0;
     __syncthreads();
-    {
+    const int x0 = tx * tw, y0 = ty * th;
+    if (x0 + tw <= w && y0 + th <= h) {
+        // tile inside the image (all but the last tile row / column, which reach into the REFLECT_101 extension): walk the
+        // tile's rows as ALIGNED dwords -- one 4-byte load per 4 pixels instead of four byte gathers, no reflection, and
+        // a thread's loads are all issued before its atomics.  Pixels of the first / last dword outside [x0, x0 + tw)
+        // are masked.
+        const int xa = x0 & ~3, ndw = (x0 + tw - xa + 3) >> 2;      // dwords per tile row
+        const int total = ndw * th, copy = lane & 15;
+        const int q = 256 / ndw, r = 256 - q * ndw;
+        int yy = tid / ndw, dd = tid - yy * ndw;
+        const unsigned char *base = img + (size_t)y0 * sstride + xa;
+        constexpr int CH = 4;   // 4 dwords = 16 pixels per thread cover a 51 x 54 tile in one chunk
+        for (int i0 = tid; i0 < total; i0 += 256 * CH) {
+            unsigned v[CH];
+            int xs[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                xs[k] = -1000;
+                v[k] = 0;
+                if (yy < th) {
+                    v[k] = *reinterpret_cast<const unsigned *>(base + (size_t)yy * sstride + 4 * dd);
+                    xs[k] = xa + 4 * dd - x0;     // tile-relative x of the dword's first byte
+                }
+                yy += q; dd += r;
+                if (dd >= ndw) { dd -= ndw; ++yy; }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(xs[k] + j) < (unsigned)tw) atomicAdd(&hist[(v[k] >> (8 * j)) & 255][copy], 1);
+        }
+    } else {
         // pixel i = tid, tid + 256, ... of the tile in row-major order, kept as (yy, xx) without per-pixel divisions
         const int q = 256 / tw, r = 256 - q * tw;
         int yy = tid / tw, xx = tid - yy * tw;
