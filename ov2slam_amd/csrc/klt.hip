@@ -149,13 +149,24 @@ __device__ __forceinline__ void stage_grad(const int *src, int gstride, unsigned
     }
 }
 
-// (p[0], p[1]) of an LDS byte address with ALIGNED reads: the dword pair around it + v_alignbyte (odd-address
-// ds_read_u16 is legal but slow)
-__device__ __forceinline__ unsigned lds_u8x2(const unsigned char *p)
+// Pixel pairs (p[x], p[x+1]) from a staged window with ALIGNED LDS reads: the dword pair around the column + v_alignbyte
+// (an odd-address ds_read_u16 is legal but slow).  The column's dword and byte shift are the same for every row of the
+// window (rows are 16 B apart), so they are formed once and the rows become immediate offsets.
+struct lds_col {
+    const unsigned *q;   // dword holding the column's first byte, row 0
+    unsigned sh;         // byte shift inside it
+};
+__device__ __forceinline__ lds_col lds_col_of(const unsigned char *row0 /* 16-byte aligned */, int byte_off)
 {
-    const unsigned a = (unsigned)(size_t)p;
-    const unsigned *q = reinterpret_cast<const unsigned *>(p - (a & 3u));
-    return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+    lds_col c;
+    c.q = reinterpret_cast<const unsigned *>(row0 + (byte_off & ~3));
+    c.sh = (unsigned)byte_off & 3u;
+    return c;
+}
+__device__ __forceinline__ unsigned lds_pair(const lds_col &c, int row)
+{
+    const unsigned *q = c.q + 4 * row;
+    return __builtin_amdgcn_alignbyte(q[1], q[0], c.sh);
 }
 
 typedef short ov2_s16x2 __attribute__((ext_vector_type(2)));
@@ -253,9 +264,9 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             stage_u8<WIN, GL>(J.img + (size_t)((in0 ? iny0 : 0) + pad) * J.istride + (jx0 & ~3), J.istride, lwJ, sub);
             __syncthreads();
         }
-        const unsigned char *ip = lwI + (bx0 & 3) + sc;
+        const lds_col ci = lds_col_of(lwI, (bx0 & 3) + sc);
         const int *gp = reinterpret_cast<const int *>(lg) + sc;
-        unsigned T = spread_u8x2(lds_u8x2(ip));
+        unsigned T = spread_u8x2(lds_pair(ci, 0));
         unsigned GX, GY;
         {
             const unsigned g0 = (unsigned)gp[0], g1 = (unsigned)gp[1];
@@ -265,8 +276,8 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         unsigned piv = 0, pix = 0, piy = 0;
 #pragma unroll
         for (int y = 0; y < WIN; ++y) {
-            ip += 16; gp += GROW;
-            const unsigned B = spread_u8x2(lds_u8x2(ip));
+            gp += GROW;
+            const unsigned B = spread_u8x2(lds_pair(ci, y + 1));
             const unsigned h0 = (unsigned)gp[0], h1 = (unsigned)gp[1];
             const unsigned HX = pack_lo16(h0, h1), HY = pack_hi16(h0, h1);
             const unsigned iv = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
@@ -291,9 +302,9 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             const int ec = ev ? e : 0;
             const int ecol = OC + ec / WIN, erow = ec - (ec / WIN) * WIN;
             eoff[r] = erow * 16 + ecol;
-            const unsigned char *ipe = lwI + (bx0 & 3) + eoff[r];
+            const lds_col ce = lds_col_of(lwI + erow * 16, (bx0 & 3) + ecol);
             const int *gpe = reinterpret_cast<const int *>(lg) + erow * GROW + ecol;
-            const unsigned T0 = spread_u8x2(lds_u8x2(ipe)), T1 = spread_u8x2(lds_u8x2(ipe + 16));
+            const unsigned T0 = spread_u8x2(lds_pair(ce, 0)), T1 = spread_u8x2(lds_pair(ce, 1));
             const unsigned g0 = (unsigned)gpe[0], g1 = (unsigned)gpe[1];
             const unsigned h0 = (unsigned)gpe[GROW], h1 = (unsigned)gpe[GROW + 1];
             const unsigned iv = (unsigned)dot2(T1, W23, dot2(T0, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
@@ -342,22 +353,20 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             stage_u8<WIN, GL>(J.img + (size_t)((run ? iny : 0) + pad) * J.istride + ((OV2_LM + (run ? inx : 0)) & ~3), J.istride, lwJ, sub);
             __syncthreads();
         }
-        const unsigned char *jb = lwJ + ((run ? inx : 0) & 3);   // OV2_LM is a multiple of 4
-        const unsigned char *jp = jb + sc;
+        const int jo = (run ? inx : 0) & 3;   // OV2_LM is a multiple of 4
+        const lds_col cj = lds_col_of(lwJ, jo + sc);
         const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
         int pb1 = 0, pb2 = 0;
-        unsigned T = spread_u8x2(lds_u8x2(jp));
+        unsigned T = spread_u8x2(lds_pair(cj, 0));
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            jp += 16;
-            unsigned B = spread_u8x2(lds_u8x2(jp));
+            unsigned B = spread_u8x2(lds_pair(cj, 2 * q + 1));
             // taps + rounding >= 1 (w11 >= -1), so the logical shift is the arithmetic one
             const unsigned j0 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             T = B;
             unsigned j1 = 0;
             if (2 * q + 1 < WIN) {
-                jp += 16;
-                B = spread_u8x2(lds_u8x2(jp));
+                B = spread_u8x2(lds_pair(cj, 2 * q + 2));
                 j1 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
                 T = B;
             }
@@ -368,14 +377,14 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         }
 #pragma unroll
         for (int q = 0; q < NRP; ++q) {   // the lane's pixels of the ownerless columns, two rounds per register
-            const unsigned char *pe = jb + eoff[2 * q];
-            const unsigned j0 = (unsigned)dot2(spread_u8x2(lds_u8x2(pe + 16)), W23,
-                                               dot2(spread_u8x2(lds_u8x2(pe)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const lds_col pe = lds_col_of(lwJ + (eoff[2 * q] & ~15), jo + (eoff[2 * q] & 15));
+            const unsigned j0 = (unsigned)dot2(spread_u8x2(lds_pair(pe, 1)), W23,
+                                               dot2(spread_u8x2(lds_pair(pe, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             unsigned j1 = 0;
             if (2 * q + 1 < NR) {
-                const unsigned char *pf = jb + eoff[2 * q + 1];
-                j1 = (unsigned)dot2(spread_u8x2(lds_u8x2(pf + 16)), W23,
-                                    dot2(spread_u8x2(lds_u8x2(pf)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                const lds_col pf = lds_col_of(lwJ + (eoff[2 * q + 1] & ~15), jo + (eoff[2 * q + 1] & 15));
+                j1 = (unsigned)dot2(spread_u8x2(lds_pair(pf, 1)), W23,
+                                    dot2(spread_u8x2(lds_pair(pf, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             }
             const unsigned d2 = pk_sub16(j0 | (j1 << 16), IvE[q]);
             pb1 = dot2(d2, IxE[q], pb1);
