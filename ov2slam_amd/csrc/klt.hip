@@ -176,6 +176,14 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(ov2_s16x2, a), __builtin_bit_cast(ov2_s16x2, b), c, false);
 }
+// first tap of a chain, accumulator = a rounding CONSTANT: the VOP3P form reads it from an SGPR; the two-address
+// v_dot2c the compiler prefers would need a v_mov of the constant per chain (13 per LK iteration)
+__device__ __forceinline__ int dot2k(unsigned a, unsigned b, int k)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
 // v_perm_b32 byte shuffles: (byte0, byte1) of a two-pixel load -> two zero-extended 16-bit halves
 __device__ __forceinline__ unsigned spread_u8x2(unsigned t) { return __builtin_amdgcn_perm(0u, t, 0x0c010c00u); }
 // (a.lo16, b.lo16) and (a.hi16, b.hi16)
@@ -280,9 +288,9 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             const unsigned B = spread_u8x2(lds_pair(ci, y + 1));
             const unsigned h0 = (unsigned)gp[0], h1 = (unsigned)gp[1];
             const unsigned HX = pack_lo16(h0, h1), HY = pack_hi16(h0, h1);
-            const unsigned iv = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            int ix = dot2(HX, W23, dot2(GX, W01, 1 << (W_BITS - 1))) >> W_BITS;
-            int iy = dot2(HY, W23, dot2(GY, W01, 1 << (W_BITS - 1))) >> W_BITS;
+            const unsigned iv = (unsigned)dot2(B, W23, dot2k(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            int ix = dot2(HX, W23, dot2k(GX, W01, 1 << (W_BITS - 1))) >> W_BITS;
+            int iy = dot2(HY, W23, dot2k(GY, W01, 1 << (W_BITS - 1))) >> W_BITS;
             if (!on) { ix = 0; iy = 0; }
             sA11 += __mul24(ix, ix); sA12 += __mul24(ix, iy); sA22 += __mul24(iy, iy);
             if (y & 1) {
@@ -307,9 +315,9 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             const unsigned T0 = spread_u8x2(lds_pair(ce, 0)), T1 = spread_u8x2(lds_pair(ce, 1));
             const unsigned g0 = (unsigned)gpe[0], g1 = (unsigned)gpe[1];
             const unsigned h0 = (unsigned)gpe[GROW], h1 = (unsigned)gpe[GROW + 1];
-            const unsigned iv = (unsigned)dot2(T1, W23, dot2(T0, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            int ix = dot2(pack_lo16(h0, h1), W23, dot2(pack_lo16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
-            int iy = dot2(pack_hi16(h0, h1), W23, dot2(pack_hi16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
+            const unsigned iv = (unsigned)dot2(T1, W23, dot2k(T0, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            int ix = dot2(pack_lo16(h0, h1), W23, dot2k(pack_lo16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
+            int iy = dot2(pack_hi16(h0, h1), W23, dot2k(pack_hi16(g0, g1), W01, 1 << (W_BITS - 1))) >> W_BITS;
             if (!(run && ev)) { ix = 0; iy = 0; }
             sA11 += __mul24(ix, ix); sA12 += __mul24(ix, iy); sA22 += __mul24(iy, iy);
             if (r & 1) {
@@ -362,12 +370,12 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         for (int q = 0; q < NP; ++q) {
             unsigned B = spread_u8x2(lds_pair(cj, 2 * q + 1));
             // taps + rounding >= 1 (w11 >= -1), so the logical shift is the arithmetic one
-            const unsigned j0 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const unsigned j0 = (unsigned)dot2(B, W23, dot2k(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             T = B;
             unsigned j1 = 0;
             if (2 * q + 1 < WIN) {
                 B = spread_u8x2(lds_pair(cj, 2 * q + 2));
-                j1 = (unsigned)dot2(B, W23, dot2(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                j1 = (unsigned)dot2(B, W23, dot2k(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
                 T = B;
             }
             // |jv - I| <= 8160 fits int16: v_pk_sub_i16 on the row pair, then one dot2 per gradient component
@@ -379,12 +387,12 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
         for (int q = 0; q < NRP; ++q) {   // the lane's pixels of the ownerless columns, two rounds per register
             const lds_col pe = lds_col_of(lwJ + (eoff[2 * q] & ~15), jo + (eoff[2 * q] & 15));
             const unsigned j0 = (unsigned)dot2(spread_u8x2(lds_pair(pe, 1)), W23,
-                                               dot2(spread_u8x2(lds_pair(pe, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                                               dot2k(spread_u8x2(lds_pair(pe, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             unsigned j1 = 0;
             if (2 * q + 1 < NR) {
                 const lds_col pf = lds_col_of(lwJ + (eoff[2 * q + 1] & ~15), jo + (eoff[2 * q + 1] & 15));
                 j1 = (unsigned)dot2(spread_u8x2(lds_pair(pf, 1)), W23,
-                                    dot2(spread_u8x2(lds_pair(pf, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                                    dot2k(spread_u8x2(lds_pair(pf, 0)), W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             }
             const unsigned d2 = pk_sub16(j0 | (j1 << 16), IvE[q]);
             pb1 = dot2(d2, IxE[q], pb1);
