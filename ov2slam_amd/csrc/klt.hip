@@ -291,8 +291,6 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
             const unsigned iv = (unsigned)dot2(B, W23, dot2k(T, W01, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
             int ix = dot2(HX, W23, dot2k(GX, W01, 1 << (W_BITS - 1))) >> W_BITS;
             int iy = dot2(HY, W23, dot2k(GY, W01, 1 << (W_BITS - 1))) >> W_BITS;
-            if (!on) { ix = 0; iy = 0; }
-            sA11 += __mul24(ix, ix); sA12 += __mul24(ix, iy); sA22 += __mul24(iy, iy);
             if (y & 1) {
                 Iv2[y >> 1] = pack_lo16(piv, iv); Ix2[y >> 1] = pack_lo16(pix, (unsigned)ix); Iy2[y >> 1] = pack_lo16(piy, (unsigned)iy);
             } else if (y == WIN - 1) {   // odd window: the phantom last row has zero gradients
@@ -301,6 +299,16 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
                 piv = iv; pix = (unsigned)ix; piy = (unsigned)iy;
             }
             T = B; GX = HX; GY = HY;
+        }
+        // idle lanes / groups hold zero gradients; Hessian sums from the packed pairs: one dot2 per row PAIR and term
+        // (|Ix|,|Iy| <= 4080: two products stay below 2^26)
+        {
+            const unsigned onm = on ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                Ix2[q] &= onm; Iy2[q] &= onm;
+                sA11 = dot2(Ix2[q], Ix2[q], sA11); sA12 = dot2(Ix2[q], Iy2[q], sA12); sA22 = dot2(Iy2[q], Iy2[q], sA22);
+            }
         }
         // pixels of the columns without an owner lane
 #pragma unroll
