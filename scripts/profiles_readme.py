@@ -19,7 +19,7 @@ hdr = f'''* **{b["value"]:.0f} tracked frames/s** ({b["ms_per_step"]:.3f} ms per
   {ba["value"]:.0f} LM iterations/s = {ba["solves_per_sec"]:.1f} solves/s (stand-alone: 6.4 ms per solve), CPU port {ba["cpu_baseline"]["value"]:.1f} iterations/s;
   local-BA set-up (`local_ba.setup`): hash-map walk {ba["setup"]["hash_map_walk_ms"]:.2f} ms, device map scans {ba["setup"]["device_map_scans_ms"]:.2f} ms.
 * `roofline`: dominant kernel `klt_stage1_kernel` (the combined KLT launch: keypoints with a prior on 2 levels + keypoints without
-  on the full pyramid), {rl["achieved"]:.0f} GB/s of algorithmic bytes = {100 * rl["frac"]:.1f} % of 8 TB/s at {rl["avg_launch_us"]:.0f} µs per launch (177 µs isolated);
+  on the full pyramid), {rl["achieved"]:.0f} GB/s of algorithmic bytes = {100 * rl["frac"]:.1f} % of 8 TB/s at {rl["avg_launch_us"]:.0f} µs per launch (161 µs isolated);
   measured HBM traffic {rl["traffic"] / 1e6:.0f} MB per launch vs {rl["alg_bytes_per_launch"] / 1e6:.0f} MB algorithmic ({rl["traffic"] / rl["alg_bytes_per_launch"]:.2f}x: no wasted re-reads — at 64 x 2 MB
   per pyramid the working set no longer fits the caches, so the window rows do come from HBM). The kernel is bound by integer
   VALU issue (76 % of the SIMD cycles busy; it was texture-addresser bound before the windows went through LDS, DESIGN.md §7):
