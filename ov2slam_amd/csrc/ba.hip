@@ -261,11 +261,19 @@ __device__ inline double block_sum_256(double v, double *sh)
 // ------------------------------------------------------------------------------------------------------
 // K_EVAL: residual (+ jacobian), loss, corrector, Jacobi scaling; cost partial per workgroup
 
+// The solver's kernels are few, short waves on a high-priority stream that share their CUs with the front-end's long
+// KLT waves: raising the wave priority lets them win the SIMD issue arbitration instead of taking turns
+// (s_setprio is per wave and costs one scalar instruction; measured: 467 -> 475 LM it/s concurrent, front-end unchanged).
+#ifndef BA_WAVE_PRIO
+#define BA_WAVE_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 template <bool JAC, int E>
 __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
                                                       const double *__restrict__ lms, int use_loss, double huber_a,
                                                       int apply_scale, double *__restrict__ part)
 {
+    BA_WAVE_PRIO();
     __shared__ double sh[256];
     const int row = blockIdx.x * 256 + threadIdx.x;
     double c = 0.0;
@@ -353,6 +361,7 @@ __global__ void ba_copy2_kernel(double *__restrict__ d1, const double *__restric
 struct ba_red3 { const double *in[3]; int n[3]; double *out[3]; double sign[3]; };
 __global__ __launch_bounds__(256) void ba_reduce3_kernel(ba_red3 r)
 {
+    BA_WAVE_PRIO();
     __shared__ double sh[256];
     const int k = blockIdx.x;
     double v = 0.0;
@@ -386,6 +395,7 @@ __global__ void ba_make_scale_kernel(ba_dev d)
 
 __global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
 {
+    BA_WAVE_PRIO();
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= d.n_rows) return;
     const int e = d.e, ne = d.n_e * e, eb = d.eb[row], fk = d.fk[row], fa = d.fa[row];
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
 // threads of this launch write.
 __global__ void ba_lmdiag_sinit_kernel(ba_dev d, int refresh_diag, double min_d, double max_d, double radius)
 {
+    BA_WAVE_PRIO();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)d.nc) {
         if (refresh_diag) d.diag[i] = fmin(fmax(d.sqn[i], min_d), max_d);
@@ -474,6 +485,7 @@ __device__ __forceinline__ void invert_ete(const double *ete, double *ie)
 // column norms + gradient of the landmark (E) columns: 16 lanes per landmark, no atomics
 __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d)
 {
+    BA_WAVE_PRIO();
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const bool live = l < d.n_e;
     const int e = d.e;
@@ -498,6 +510,7 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d)
 __global__ __launch_bounds__(256) void ba_colnorm_pose_kernel(ba_dev d, const int *__restrict__ pose_ptr,
                                                               const int *__restrict__ pose_ent)
 {
+    BA_WAVE_PRIO();
     __shared__ double sh[4][12];
     const int f = blockIdx.x, tid = threadIdx.x;
     double acc[12];
@@ -534,6 +547,7 @@ __constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2
 template <int E>
 __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__restrict__ part)
 {
+    BA_WAVE_PRIO();
     {   // the pose part of the step is -z (z = the reduced solve's result in rhs); written here to save a launch
         const int gi = blockIdx.x * 256 + threadIdx.x;
         if (gi < d.m) d.step[d.n_e * d.e + gi] = -d.rhs[gi];
@@ -595,6 +609,7 @@ template <int NB>
 __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restrict__ A, double *__restrict__ rhs, int m,
                                                        int *__restrict__ flags)
 {
+    BA_WAVE_PRIO();
     extern __shared__ __attribute__((aligned(16))) double lds[];   // the only LDS object of this kernel
     const int tid = threadIdx.x, nth = blockDim.x;
     const int M1 = m + 1;               // augmented row count (row m = right-hand side)
@@ -774,6 +789,7 @@ typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ A, double *__restrict__ rhs,
                                                            double *__restrict__ Dbuf, int m, int k0, int *__restrict__ flags)
 {
+    BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
     __shared__ double LD[NB][NB + 1];
     if (*(volatile int *)flags) return;
@@ -840,6 +856,7 @@ __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ 
 __global__ __launch_bounds__(64) void ba_chol_syrk_kernel(double *__restrict__ A, double *__restrict__ rhs, int m, int k0,
                                                           const int *__restrict__ flags)
 {
+    BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
     if (*(volatile const int *)flags) return;
     const int t0 = k0 + NB, t = m - t0;
@@ -886,6 +903,7 @@ __global__ __launch_bounds__(256) void ba_chol_backward_kernel(const double *__r
                                                               const double *__restrict__ Dbuf, int m,
                                                               const int *__restrict__ flags)
 {
+    BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (*(volatile const int *)flags) return;
@@ -965,6 +983,7 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
                                                       double chi2_th, double *__restrict__ chi2,
                                                       unsigned char *__restrict__ depth, unsigned char *__restrict__ active)
 {
+    BA_WAVE_PRIO();
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= d.n_rows) return;
     row_eval ev;
@@ -1241,6 +1260,7 @@ __global__ __launch_bounds__(256) void bs_segs_kernel(const unsigned long long *
 template <int E>
 __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
 {
+    BA_WAVE_PRIO();
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int l = blockIdx.x * 16 + grp;
     const bool live = l < d.n_e;
@@ -1477,6 +1497,7 @@ __global__ __launch_bounds__(256) void bs_gather_kernel(ba_dev d, ba_cells C, co
                                                         const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
                                                         const unsigned long long *__restrict__ pk)
 {
+    BA_WAVE_PRIO();
     __shared__ double red[4][27];
     if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, pcell_ent, blockIdx.x, red);
     else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pk, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6));
