@@ -96,6 +96,31 @@ def test_fb_klt_bit_exact(ctx, oracle, stream, nlevels, t1):
         assert np.median(np.linalg.norm(out[st] - gt[st], axis=1)) < 0.2
 
 
+@pytest.mark.parametrize("win", [5, 7, 9, 11])
+def test_fb_klt_random_sweep(ctx, oracle, stream, win):
+    """keypoints anywhere in (and a little outside) the image with priors up to 6 px off, every pyramid depth, several
+    frame pairs: the staged-window loads (16-byte rows from the dword below the window, padding on all sides) against the
+    scalar oracle, bit for bit"""
+    rng = np.random.default_rng(100 + win)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for t0, t1 in ((0, 2), (3, 9), (14, 5)):
+        I0, I1 = stream.left(t0), stream.left(t1)
+        g0 = fe.preprocess_image(ctx, I0, use_clahe=True, klt_win_size=11)
+        g1 = fe.preprocess_image(ctx, I1, use_clahe=True, klt_win_size=11)
+        o0 = oracle.Pyramid(oracle.clahe(I0, 3.0, 15, 9), 11, 3)
+        o1 = oracle.Pyramid(oracle.clahe(I1, 3.0, 15, 9), 11, 3)
+        n = 1500
+        kps = np.stack([rng.uniform(-2, 754, n), rng.uniform(-2, 482, n)], 1).astype(np.float32)
+        kps[:200, 0] = rng.choice([0.0, 0.5, 3.0, 748.2, 751.0], 200)      # columns next to the left / right padding
+        kps[200:400, 1] = rng.choice([0.0, 0.7, 2.0, 477.4, 479.0], 200)   # rows next to the top / bottom padding
+        pri = (kps + rng.uniform(-6, 6, kps.shape)).astype(np.float32)
+        for nl in (0, 1, 2, 3):
+            out, st = trk.fbKltTracking(g0, g1, win, nl, 30.0, 0.5, kps, pri)
+            eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, pri, win, nl, 30.0, 0.5, 30, 0.01)
+            assert np.array_equal(st, est.astype(bool)), (t0, t1, nl)
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), (t0, t1, nl)
+
+
 def test_fb_klt_edge_cases(ctx, oracle, stream):
     """points on/over the border, in flat (min-eig reject) regions, priors far outside, empty input."""
     I0 = stream.left(0).copy()
