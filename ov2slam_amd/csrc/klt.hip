@@ -229,7 +229,7 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
     constexpr int NP = (WIN + 1) / 2;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const float half = (float)(WIN - 1) * 0.5f;
-    const float lscale = 1.f / (float)(1 << level);
+    const float lscale = __builtin_ldexpf(1.f, -level);   // 1.f / (1 << level), exactly; one v_ldexp_f32 instead of an IEEE division
     float px = kx * lscale, py = ky * lscale;
     float nx, ny;
     if (level == max_level) { nx = nx_io * lscale; ny = ny_io * lscale; }
