@@ -275,7 +275,8 @@ ov2_status ov2_pnp_solve_batch_dev(ov2_ctx *ctx, int B, const int32_t *d_off, co
  * MapManager by the hooks below, so that the set-up stage of Optimizer::localBA (src/optimizer.cpp:43-430: the walk
  * over Frame::map_covkfs_, Frame::mapkps_, MapPoint::set_kfids_ and the two hash maps of the MapManager) becomes a
  * handful of linear scans over the observation table.  kfid / lmid index the tables directly (both are small dense
- * counters in the reference: src/map_manager.cpp:621-690), capacities are fixed at creation.
+ * counters in the reference: src/map_manager.cpp:621-690); the capacities given at creation are initial sizes, the
+ * tables grow (x1.5, device copies) when an id or the observation count passes them.
  *
  *   hook                          reference mutation it mirrors
  *   ov2_map_add_keyframe          MapManager::addKeyframe + addMapPointKfObs   src/map_manager.cpp:621-634,769-799

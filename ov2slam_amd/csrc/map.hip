@@ -4,7 +4,7 @@
 // include/frame.hpp mapkps_/map_covkfs_, include/map_point.hpp set_kfids_) and assembles every local BA by walking
 // them (src/optimizer.cpp:43-430): ~4.4 ms for 40 keyframes / 3 k landmarks / 38 k residual blocks in the C++ mirror
 // of that walk (ov2slam_amd/host), the same order as the solve itself.  Here the map is three SoA tables in HBM
-// (keyframes, landmarks, observations; kfid and lmid index them directly) and the set-up is a dozen scans of the
+// (keyframes, landmarks, observations; kfid and lmid index them directly; the tables grow on demand) and the set-up is a dozen scans of the
 // observation table -- HBM-bound integer work: at 8 TB/s a million observations (40 B each) are a 5 us read, so no
 // per-landmark adjacency needs to be maintained incrementally, the table itself is the adjacency.
 #include <hip/hip_runtime.h>
@@ -439,17 +439,12 @@ struct stager {
 
 }  // namespace
 
-extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max_obs, ov2_map **out)
+// every device array whose size follows the capacities (tables + set-up scratch); pointers must be null on entry
+static ov2_status alloc_tables(ov2_map *m)
 {
-    if (!c || !out || max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return OV2_ERR_INVALID;
-    *out = nullptr;
-    OV2_HIP(c, hipSetDevice(c->device));
-    ov2_map *m = new (std::nothrow) ov2_map();
-    if (!m) return OV2_ERR_NOMEM;
-    memset(m, 0, sizeof(*m));
-    m->c = c; m->max_kf = max_kf; m->max_lm = max_lm; m->max_obs = max_obs;
+    ov2_ctx *c = m->c;
     ov2_status s = OV2_OK;
-    const size_t K = max_kf, L = max_lm, N = max_obs;
+    const size_t K = m->max_kf, L = m->max_lm, N = m->max_obs;
 #define A(p, n) if (s == OV2_OK) s = dmalloc(c, &m->p, (n))
     A(kf_pose, 7 * K); A(kf_state, K); A(lm_xyz, 3 * L); A(lm_state, L);
     A(obs_kf, N); A(obs_lm, N); A(obs_scale, N); A(obs_uv, 2 * N); A(obs_ruv, 2 * N); A(obs_flag, N);
@@ -463,12 +458,65 @@ extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max
     }
     A(obs_cnt, N); A(obs_off, N); A(blk, (std::max(N, L) + 1023) / 1024 + 1);
 #undef A
+    return s;
+}
+
+static void free_capacity_arrays(ov2_map *m)
+{
+    void *dev[] = {m->kf_pose, m->kf_state, m->lm_xyz, m->lm_state, m->obs_kf, m->obs_lm, m->obs_scale, m->obs_uv, m->obs_ruv,
+                   m->obs_flag, m->zero_blk, m->kf_idx, m->lm_anchor, m->lm_idx, m->lm_flag, m->bad_idx, m->obs_cnt, m->obs_off,
+                   m->blk};
+    for (void *p : dev) if (p) (void)hipFree(p);
+}
+
+// The tables grow by doubling when an id or the observation count passes the capacity: fresh arrays, device copies of
+// the live prefixes, old arrays freed (a rare event; one synchronisation).
+static ov2_status ensure_capacity(ov2_map *m, int need_kf, int need_lm, int need_obs)
+{
+    if (need_kf <= m->max_kf && need_lm <= m->max_lm && need_obs <= m->max_obs) return OV2_OK;
+    ov2_ctx *c = m->c;
+    ov2_map old = *m;
+    auto grown = [](int have, int need) { return need <= have ? have : std::max(need, have + have / 2 + 16); };
+    m->max_kf = grown(old.max_kf, need_kf); m->max_lm = grown(old.max_lm, need_lm); m->max_obs = grown(old.max_obs, need_obs);
+    m->kf_pose = nullptr; m->kf_state = nullptr; m->lm_xyz = nullptr; m->lm_state = nullptr;
+    m->obs_kf = m->obs_lm = m->obs_scale = nullptr; m->obs_uv = m->obs_ruv = nullptr; m->obs_flag = nullptr;
+    m->zero_blk = nullptr; m->kf_idx = m->lm_anchor = m->lm_idx = m->lm_flag = m->bad_idx = m->obs_cnt = m->obs_off = m->blk = nullptr;
+    ov2_status s = alloc_tables(m);
+    if (s != OV2_OK) {
+        free_capacity_arrays(m);
+        *m = old;
+        return s;
+    }
+    hipStream_t st = c->stream;
+    const size_t K = old.max_kf, L = old.max_lm, N = old.n_obs;
+    OV2_HIP(c, hipMemsetAsync(m->kf_state, 0, (size_t)m->max_kf, st));
+    OV2_HIP(c, hipMemsetAsync(m->lm_state, 0, (size_t)m->max_lm, st));
+    OV2_HIP(c, hipMemsetAsync(m->obs_flag, 0, (size_t)m->max_obs, st));
+#define CP(p, n) if ((n) > 0) OV2_HIP(c, hipMemcpyAsync(m->p, old.p, (n) * sizeof(*m->p), hipMemcpyDeviceToDevice, st))
+    CP(kf_pose, 7 * K); CP(kf_state, K); CP(lm_xyz, 3 * L); CP(lm_state, L);
+    CP(obs_kf, N); CP(obs_lm, N); CP(obs_scale, N); CP(obs_uv, 2 * N); CP(obs_ruv, 2 * N); CP(obs_flag, N);
+#undef CP
+    OV2_HIP(c, hipStreamSynchronize(st));
+    free_capacity_arrays(&old);
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max_obs, ov2_map **out)
+{
+    if (!c || !out || max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return OV2_ERR_INVALID;
+    *out = nullptr;
+    OV2_HIP(c, hipSetDevice(c->device));
+    ov2_map *m = new (std::nothrow) ov2_map();
+    if (!m) return OV2_ERR_NOMEM;
+    memset(m, 0, sizeof(*m));
+    m->c = c; m->max_kf = max_kf; m->max_lm = max_lm; m->max_obs = max_obs;
+    ov2_status s = alloc_tables(m);
     if (s == OV2_OK && hipHostMalloc((void **)&m->hdr_host, MH_N * sizeof(int), hipHostMallocDefault) != hipSuccess)
         s = ov2_set_err(c, OV2_ERR_NOMEM, "map header hipHostMalloc");
     if (s != OV2_OK) { ov2_map_destroy(m); return s; }
-    OV2_HIP(c, hipMemsetAsync(m->kf_state, 0, K, c->stream));
-    OV2_HIP(c, hipMemsetAsync(m->lm_state, 0, L, c->stream));
-    OV2_HIP(c, hipMemsetAsync(m->obs_flag, 0, N, c->stream));
+    OV2_HIP(c, hipMemsetAsync(m->kf_state, 0, (size_t)max_kf, c->stream));
+    OV2_HIP(c, hipMemsetAsync(m->lm_state, 0, (size_t)max_lm, c->stream));
+    OV2_HIP(c, hipMemsetAsync(m->obs_flag, 0, (size_t)max_obs, c->stream));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     { std::lock_guard<std::mutex> g(c->mu); c->maps.push_back(m); }
     *out = m;
@@ -477,10 +525,8 @@ extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max
 
 static void free_tables(ov2_map *m)
 {
-    void *dev[] = {m->kf_pose, m->kf_state, m->lm_xyz, m->lm_state, m->obs_kf, m->obs_lm, m->obs_scale, m->obs_uv, m->obs_ruv,
-                   m->obs_flag, m->zero_blk, m->kf_idx, m->lm_anchor, m->lm_idx, m->lm_flag, m->bad_idx, m->obs_cnt, m->obs_off,
-                   m->blk, m->out_dev};
-    for (void *p : dev) if (p) (void)hipFree(p);
+    free_capacity_arrays(m);
+    if (m->out_dev) (void)hipFree(m->out_dev);
     if (m->out_host) (void)hipHostFree(m->out_host);
     if (m->hdr_host) (void)hipHostFree(m->hdr_host);
 }
@@ -516,11 +562,17 @@ extern "C" ov2_status ov2_map_add_keyframe(ov2_map *m, int kfid, const double *T
     if (!m || !m->c) return OV2_ERR_INVALID;
     ov2_ctx *c = m->c;
     if (!Twc || n < 0 || (n && (!lmid || !unpx))) return ov2_set_err(c, OV2_ERR_INVALID, "ov2_map_add_keyframe: null argument");
-    if (kfid < 0 || kfid >= m->max_kf) return ov2_set_err(c, OV2_ERR_INVALID, "kfid %d outside the map capacity %d", kfid, m->max_kf);
-    if (m->n_obs + n > m->max_obs) return ov2_set_err(c, OV2_ERR_NOMEM, "observation table full (%d + %d > %d)", m->n_obs, n, m->max_obs);
-    for (int i = 0; i < n; ++i)
-        if (lmid[i] < 0 || lmid[i] >= m->max_lm) return ov2_set_err(c, OV2_ERR_INVALID, "lmid %d outside the map capacity", lmid[i]);
+    if (kfid < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative kfid %d", kfid);
+    int top_lm = -1;
+    for (int i = 0; i < n; ++i) {
+        if (lmid[i] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative lmid %d", lmid[i]);
+        top_lm = std::max(top_lm, lmid[i]);
+    }
     OV2_HIP(c, hipSetDevice(c->device));
+    {
+        const ov2_status gs = ensure_capacity(m, kfid + 1, top_lm + 1, m->n_obs + n);
+        if (gs != OV2_OK) return gs;
+    }
     // the rows are appended as they are: assemble them in the staging block, then plain copies into the tables
     stager S{c};
     ov2_status s = S.begin((size_t)n * (3 * sizeof(int) + 4 * sizeof(double) + 1) + 7 * sizeof(double) + 256);
@@ -568,9 +620,16 @@ extern "C" ov2_status ov2_map_set_landmarks(ov2_map *m, int n, const int32_t *lm
     ov2_ctx *c = m->c;
     if (n < 0 || (n && (!lmid || !state))) return ov2_set_err(c, OV2_ERR_INVALID, "ov2_map_set_landmarks: null argument");
     if (!n) return OV2_OK;
-    for (int i = 0; i < n; ++i)
-        if (lmid[i] < 0 || lmid[i] >= m->max_lm) return ov2_set_err(c, OV2_ERR_INVALID, "lmid %d outside the map capacity", lmid[i]);
+    int top_lm = -1;
+    for (int i = 0; i < n; ++i) {
+        if (lmid[i] < 0) return ov2_set_err(c, OV2_ERR_INVALID, "negative lmid %d", lmid[i]);
+        top_lm = std::max(top_lm, lmid[i]);
+    }
     OV2_HIP(c, hipSetDevice(c->device));
+    {
+        const ov2_status gs = ensure_capacity(m, 0, top_lm + 1, 0);
+        if (gs != OV2_OK) return gs;
+    }
     stager S{c};
     ov2_status s = S.begin((size_t)n * (sizeof(int) + 3 * sizeof(double) + 1) + 256);
     if (s != OV2_OK) return s;

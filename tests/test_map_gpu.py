@@ -125,7 +125,7 @@ def test_local_ba_through_the_mirror_equals_the_walk(ctx, inv_depth):
     assert_same(h0, h1, tol=1e-8)
 
 
-def test_capacity_and_argument_errors(ctx):
+def test_growth_and_argument_errors(ctx):
     L = ctx.lib
     m = C.c_void_p()
     assert L.ov2_map_create(ctx.h, 4, 8, 16, C.byref(m)) == 0
@@ -133,14 +133,25 @@ def test_capacity_and_argument_errors(ctx):
     lm = np.arange(10, dtype=np.int32)
     uv = np.zeros((10, 2))
     vp = lambda a: a.ctypes.data
-    assert L.ov2_map_add_keyframe(m, 7, vp(T), 0, None, None, None, None, None) != 0        # kfid beyond capacity
-    assert L.ov2_map_add_keyframe(m, 1, vp(T), 10, vp(lm), vp(uv), None, None, None) != 0    # lmid 8, 9 beyond capacity
-    assert L.ov2_map_add_keyframe(m, 1, vp(T), 8, vp(lm), vp(uv), None, None, None) == 0
-    assert L.ov2_map_add_keyframe(m, 2, vp(T), 8, vp(lm), vp(uv), None, None, None) == 0
-    assert L.ov2_map_add_keyframe(m, 3, vp(T), 1, vp(lm), vp(uv), None, None, None) != 0     # observation table full
+    neg = np.array([-1], np.int32)
+    assert L.ov2_map_add_keyframe(m, -1, vp(T), 0, None, None, None, None, None) != 0
+    assert L.ov2_map_add_keyframe(m, 1, vp(T), 1, vp(neg), vp(uv), None, None, None) != 0
+    # ids and counts beyond the initial capacities grow the tables
+    assert L.ov2_map_add_keyframe(m, 7, vp(T), 0, None, None, None, None, None) == 0
+    for k in (1, 2, 3):
+        assert L.ov2_map_add_keyframe(m, k, vp(T), 10, vp(lm), vp(uv), None, None, None) == 0
     out = (C.c_byte * 256)()
-    assert L.ov2_map_local_ba_setup(m, 9, 25, 1, 1, None, out) != 0
+    assert L.ov2_map_local_ba_setup(m, 900, 25, 1, 1, None, out) != 0      # unknown keyframe
     # no landmark is alive yet: nb3dkps = 0 < nmin_covscore -> aborted, not an error
     assert L.ov2_map_local_ba_setup(m, 2, 25, 1, 1, None, out) == 0
     assert np.frombuffer(out, np.int32, 1)[0] == 1
     L.ov2_map_destroy(m)
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_tables_grow_from_tiny_capacities(ctx, inv_depth):
+    P = synth_ba.make_window(14, 900, inv_depth=inv_depth, seed=12, max_obs=6)
+    hm = host_map.HostMap(P)
+    hm.attach_device(ctx, max_kf=2, max_lm=3, max_obs=5)     # everything has to grow, several times
+    a = assert_same(hm)
+    assert len(a["res_type"]) > 5000
