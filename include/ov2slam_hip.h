@@ -341,6 +341,40 @@ ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_covscore, int 
                                   const double *calib_l /* fx fy cx cy: anchor depth needs no intrinsics; reserved */,
                                   ov2_local_ba_setup *out);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Two-view triangulation of keypoint pairs + the mapper's acceptance gates (second half).
+ * Replaces the per-keypoint bodies of Mapper::triangulateStereo (src/mapper.cpp:346-461) and
+ * Mapper::triangulateTemporal (:191-344): MultiViewGeometry::triangulate(Tlr, bvl, bvr)
+ * (include/multi_view_geometry.hpp:46, src/multi_view_geometry.cpp:53-61 -> opengvTriangulate2 :85-99, the mid-point
+ * method) or the rectified disparity form (:411-422), the depth gate (z < 0.1 in either view, :428 / :316), the
+ * reprojection gate against max_reproj_err in both views (:433-446 / :322-336), Frame::projCamToWorld (:449 / :339) and,
+ * for the temporal case, the rotation-compensated parallax (:301-302).
+ *   view a = left camera / older keyframe, view b = right camera / new keyframe
+ *   T_ab    G x 7   pose of b in a [t, qx qy qz qw]: Tlr (stereo) or Tcicj (temporal, one per source keyframe)
+ *   Twc_a   G x 7   (may be NULL) world pose of view a -> wpt
+ *   grp     n       (may be NULL = all 0) which of the G pose pairs a keypoint pair uses
+ *   bv_a, bv_b  n x 3 bearing vectors (Keypoint::bv_ / rbv_)      unpx_a, unpx_b  n x 2 undistorted pixels (float)
+ *   K_a, K_b    fx fy cx cy of the two views
+ *   pt_a    n x 3   the point in view a (left_pt)                  wpt  n x 3 (may be NULL)
+ *   parallax n      (may be NULL) |unpx_a - proj_b(R_ab bv_b)|
+ *   status  n       OV2_TRI_OK / _BEHIND / _REPROJ / _NEG_DISP (the reference removes the observation / skips the point)
+ * Host pointers; ov2_triangulate_pairs_dev takes the same arrays in HBM and synchronises nothing. */
+#define OV2_TRI_MIDPOINT  0
+#define OV2_TRI_RECTIFIED 1
+#define OV2_TRI_OK        0
+#define OV2_TRI_BEHIND    1
+#define OV2_TRI_REPROJ    2
+#define OV2_TRI_NEG_DISP  3
+ov2_status ov2_triangulate_pairs(ov2_ctx *ctx, int n, int method, int G, const double *T_ab, const double *Twc_a,
+                                 const int32_t *grp, const double *bv_a, const double *bv_b, const float *unpx_a,
+                                 const float *unpx_b, const double *K_a, const double *K_b, float max_reproj_err,
+                                 double *pt_a, double *wpt, double *parallax, uint8_t *status);
+ov2_status ov2_triangulate_pairs_dev(ov2_ctx *ctx, int n, int method, int G, const double *d_T_ab, const double *d_Twc_a,
+                                     const int32_t *d_grp, const double *d_bv_a, const double *d_bv_b,
+                                     const float *d_unpx_a, const float *d_unpx_b, const double *K_a, const double *K_b,
+                                     float max_reproj_err, double *d_pt_a, double *d_wpt, double *d_parallax,
+                                     uint8_t *d_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,6 +255,34 @@ def pnp_solve(unpx, wpts, K, Twc, scales=None, max_iters=5, chi2th=5.9915, use_r
     return bool(ok), T, out[:n].astype(bool), (int(it[0]), int(it[1]))
 
 
+def triangulate_pairs(T_ab, bv_a, bv_b, unpx_a, unpx_b, K_a, K_b, max_reproj_err, method=0, Twc_a=None, grp=None,
+                      want_parallax=False):
+    """Mapper::triangulateStereo / triangulateTemporal bodies. returns dict(pt_a, wpt, parallax, status)."""
+    L = lib()
+    f32p = C.POINTER(C.c_float)
+    L.ov2o_triangulate_pairs.argtypes = [C.c_int, C.c_int, C.c_int, f64p, f64p, i32p, f64p, f64p, f32p, f32p, f64p, f64p,
+                                         C.c_float, f64p, f64p, f64p, u8p]
+    L.ov2o_triangulate_pairs.restype = C.c_int
+    T_ab = np.ascontiguousarray(T_ab, np.float64).reshape(-1, 7)
+    G = len(T_ab)
+    bv_a, bv_b = np.ascontiguousarray(bv_a, np.float64).reshape(-1, 3), np.ascontiguousarray(bv_b, np.float64).reshape(-1, 3)
+    ua, ub = np.ascontiguousarray(unpx_a, np.float32).reshape(-1, 2), np.ascontiguousarray(unpx_b, np.float32).reshape(-1, 2)
+    n = len(bv_a)
+    W = None if Twc_a is None else np.ascontiguousarray(Twc_a, np.float64).reshape(-1, 7)
+    g = None if grp is None else np.ascontiguousarray(grp, np.int32)
+    Ka, Kb = np.ascontiguousarray(K_a, np.float64), np.ascontiguousarray(K_b, np.float64)
+    pt, st = np.zeros((max(n, 1), 3)), np.zeros(max(n, 1), np.uint8)
+    wpt = None if W is None else np.zeros((max(n, 1), 3))
+    par = np.zeros(max(n, 1)) if want_parallax else None
+    rc = L.ov2o_triangulate_pairs(n, int(method), G, _p(T_ab, f64p), None if W is None else _p(W, f64p),
+                                  None if g is None else _p(g, i32p), _p(bv_a, f64p), _p(bv_b, f64p), _p(ua, f32p), _p(ub, f32p),
+                                  _p(Ka, f64p), _p(Kb, f64p), float(max_reproj_err), _p(pt, f64p),
+                                  None if wpt is None else _p(wpt, f64p), None if par is None else _p(par, f64p), _p(st, u8p))
+    if rc != 0:
+        raise ValueError("pose-pair index out of range")
+    return dict(pt_a=pt[:n], wpt=None if wpt is None else wpt[:n], parallax=None if par is None else par[:n], status=st[:n])
+
+
 # ---------------------------------------------------------------------------------------------------
 # detectors (keyframe rate)
 

@@ -99,6 +99,13 @@ void ov2o_draw_disc_u8(uint8_t *mask, int w, int h, int cx, int cy, int radius, 
 void ov2o_min_eig_cell(const uint8_t *img, int w, int h, int stride, int x0, int y0, int cell, float *hmap);
 int ov2o_fast_score(const uint8_t *img, int stride, int x, int y, int threshold);   /* cornerScore<16>, 0 if not a corner */
 
+
+/* ov2_oracle_tri.c: two-view triangulation + the mapper's acceptance gates (src/mapper.cpp:191-461); returns 0, -1 on a bad group index */
+int ov2o_triangulate_pairs(int n, int method, int G, const double *T_ab, const double *Twc_a, const int *grp,
+                           const double *bv_a, const double *bv_b, const float *unpx_a, const float *unpx_b,
+                           const double *K_a, const double *K_b, float max_reproj_err, double *pt_a, double *wpt,
+                           double *parallax, unsigned char *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,10 @@ SIGNATURES = {
     "ov2_map_remove_landmarks": (C.c_int, [vp, C.c_int, vp]),
     "ov2_map_remove_keyframe": (C.c_int, [vp, C.c_int]),
     "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ov2_triangulate_pairs": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
+                                        vp, vp, vp, vp]),
+    "ov2_triangulate_pairs_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
+                                            vp, vp, vp, vp]),
     "ov2_pnp_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                       vp, vp, vp]),
 }

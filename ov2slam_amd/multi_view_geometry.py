@@ -25,6 +25,30 @@ class MultiViewGeometry:
                                             None if vscales is None else [vscales])
         return bool(ok[0]), T[0], np.flatnonzero(out[0]).astype(np.int32)
 
+    def triangulate_pairs(self, T_ab, bv_a, bv_b, unpx_a, unpx_b, K_a, K_b, max_reproj_err, method=0, Twc_a=None, grp=None,
+                          want_parallax=False):
+        """per-keypoint bodies of Mapper::triangulateStereo / triangulateTemporal (src/mapper.cpp:191-461) through
+        ov2_triangulate_pairs: MultiViewGeometry::triangulate (mid-point, method 0) or the rectified disparity form
+        (method 1) + depth / reprojection gates + world projection + parallax. returns dict(pt_a, wpt, parallax, status)."""
+        T_ab = np.ascontiguousarray(T_ab, np.float64).reshape(-1, 7)
+        bv_a, bv_b = np.ascontiguousarray(bv_a, np.float64).reshape(-1, 3), np.ascontiguousarray(bv_b, np.float64).reshape(-1, 3)
+        if len(bv_a) != len(bv_b):
+            raise ValueError("bv_a / bv_b sizes differ")
+        ua, ub = np.ascontiguousarray(unpx_a, np.float32).reshape(-1, 2), np.ascontiguousarray(unpx_b, np.float32).reshape(-1, 2)
+        n = len(bv_a)
+        W = None if Twc_a is None else np.ascontiguousarray(Twc_a, np.float64).reshape(-1, 7)
+        g = None if grp is None else np.ascontiguousarray(grp, np.int32)
+        Ka, Kb = np.ascontiguousarray(K_a, np.float64), np.ascontiguousarray(K_b, np.float64)
+        pt, st = np.zeros((max(n, 1), 3)), np.zeros(max(n, 1), np.uint8)
+        wpt = None if W is None else np.zeros((max(n, 1), 3))
+        par = np.zeros(max(n, 1)) if want_parallax else None
+        c = self.ctx
+        _check(c.h, c.lib.ov2_triangulate_pairs(c.h, n, int(method), len(T_ab), _vp(T_ab), None if W is None else _vp(W),
+                                                None if g is None else _vp(g), _vp(bv_a), _vp(bv_b), _vp(ua), _vp(ub), _vp(Ka),
+                                                _vp(Kb), float(max_reproj_err), _vp(pt), None if wpt is None else _vp(wpt),
+                                                None if par is None else _vp(par), _vp(st)))
+        return dict(pt_a=pt[:n], wpt=None if wpt is None else wpt[:n], parallax=None if par is None else par[:n], status=st[:n])
+
     def ceresPnP_batch_dev(self, B, d_off, d_unpx, d_wpts, d_scales, d_K, d_Twc, nmaxiter, chi2th, buse_robust,
                            bapply_l2_after_robust, d_outlier, d_removed, d_success, d_iters=None):
         """device-resident, asynchronous form (ov2_pnp_solve_batch_dev): DeviceArrays in, nothing synchronised."""
