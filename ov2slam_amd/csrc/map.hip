@@ -26,11 +26,12 @@ struct ov2_map {
     // set-up scratch
     int *hdr;                                                       // MH_N ints
     int *cov, *kf_role, *kf_idx;                                    // [max_kf]
-    int *lm_nobs, *lm_sel, *lm_anchor, *lm_idx, *lm_flag, *bad_idx; // [max_lm]; lm_sel: 0 none, 1 local, 2 bad
+    int *lm_nobs, *lm_sel, *lm_anchor, *lm_flag;                    // [max_lm]; lm_sel: 0 none, 1 local, 2 bad
+    unsigned long long *lm_pack, *lm_pidx;                          // [max_lm] (flag | bad << 32) and its exclusive scan: (lm index | bad index << 32)
     unsigned char *lm_new;                                          // [max_lm] observed by the new keyframe
     int *obs_cnt, *obs_off;                                         // [max_obs]
     int *blk;                                                       // block sums of the scans
-    unsigned char *zero_blk; size_t zero_bytes;                     // hdr | cov | kf_role | lm_nobs | lm_sel | lm_new: one memset per set-up
+    unsigned char *zero_blk; size_t zero_bytes;                     // hdr | cov | kf_role | lm_nobs | lm_sel | lm_anchor | lm_new: one memset per set-up
     // outputs: device image + pinned host image of the flat problem
     unsigned char *out_dev, *out_host;
     size_t out_cap;
@@ -39,7 +40,8 @@ struct ov2_map {
 
 namespace {
 
-enum { MH_NBKPS = 0, MH_NB3D, MH_ABORT, MH_NMAXKF, MH_NPOSE, MH_NLM, MH_NRES, MH_NBAD, MH_N = 16 };
+enum { MH_NBKPS = 0, MH_NB3D, MH_ABORT, MH_NMAXKF, MH_NPOSE, MH_NRES, MH_NLM, MH_NBAD, MH_N = 16 };   // NLM|NBAD: one 64-bit scan total
+#define ANCH_TOP 0x40000000   // anchor keyframe stored as ANCH_TOP - kfid under atomicMax: 0 = none, so the array lives in the zeroed block
 enum { OBS_ALIVE = 1, OBS_STEREO = 2 };
 
 struct map_view {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void ms_observers_kernel(map_view M, const int
     if (hdr[MH_ABORT] || i >= M.n_obs || !obs_live(M, i, kf, lm)) return;
     if (lm_sel[lm] != 1 || kf > hdr[MH_NMAXKF]) return;
     if (kf_role[kf] == 0) kf_role[kf] = 2;     // every writer stores the same value
-    atomicMin(&lm_anchor[lm], kf);
+    atomicMax(&lm_anchor[lm], ANCH_TOP - kf);   // the smallest kfid wins
 }
 
 // gauge (:394-407) + dense pose numbering in ascending kfid.  One workgroup.
@@ -235,16 +237,18 @@ __global__ __launch_bounds__(1024) void ms_poses_kernel(int max_kf, int nmin_cst
     if (tid == 0) hdr[MH_NPOSE] = carry_s;
 }
 
-// flags of the landmark numbering: local and (with inverse depth) anchored; bad ones go to their own list
+// flags of the landmark numbering: local and (with inverse depth) anchored; bad ones go to their own list.  Both flags
+// ride one 64-bit word so that one scan numbers both lists.
 __global__ __launch_bounds__(256) void ms_lm_flags_kernel(int max_lm, int inv, const int *__restrict__ lm_sel,
                                                           const int *__restrict__ lm_anchor, int *__restrict__ lm_flag,
-                                                          int *__restrict__ bad_flag)
+                                                          unsigned long long *__restrict__ lm_pack)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= max_lm) return;
     const int s = lm_sel[l];
-    lm_flag[l] = (s == 1 && (!inv || lm_anchor[l] != 0x7f7f7f7f)) ? 1 : 0;
-    bad_flag[l] = s == 2;
+    const int f = (s == 1 && (!inv || lm_anchor[l] != 0)) ? 1 : 0;
+    lm_flag[l] = f;
+    lm_pack[l] = (unsigned long long)f | ((unsigned long long)(s == 2) << 32);
 }
 
 // residual blocks per observation (:251-391): anchor observation 1 if stereo (right-anchor block) else 0; any other
@@ -258,44 +262,57 @@ __global__ __launch_bounds__(256) void ms_res_count_kernel(map_view M, int inv, 
     int kf, lm, c = 0;
     if (!hdr[MH_ABORT] && obs_live(M, i, kf, lm) && lm_flag[lm] && kf <= hdr[MH_NMAXKF]) {
         const bool stereo = M.obs_flag[i] & OBS_STEREO;
-        if (inv && lm_anchor[lm] == kf) c = stereo ? 1 : 0;
+        if (inv && lm_anchor[lm] == ANCH_TOP - kf) c = stereo ? 1 : 0;
         else c = stereo ? 2 : 1;
     }
     obs_cnt[i] = c;
 }
 
-// ---- exclusive scan of an int array in three launches (block sums -> their scan -> block offsets) -------------
-__global__ __launch_bounds__(1024) void scan_block_kernel(const int *__restrict__ in, int n, int *__restrict__ out,
-                                                          int *__restrict__ blk)
+// ---- exclusive scan of an array (int, or two counters packed in 64 bits) in three launches:
+// block sums -> their scan -> block offsets
+template <typename T>
+__device__ __forceinline__ T shfl_up_t(T v, int o)
 {
-    __shared__ int wsum[16];
+    if constexpr (sizeof(T) == 8) {
+        const unsigned lo = (unsigned)__shfl_up((int)(v & 0xffffffffull), o), hi = (unsigned)__shfl_up((int)(v >> 32), o);
+        return ((T)hi << 32) | lo;
+    } else {
+        return __shfl_up(v, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_block_kernel(const T *__restrict__ in, int n, T *__restrict__ out, T *__restrict__ blk)
+{
+    __shared__ T wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = blockIdx.x * 1024 + tid;
-    const int v = i < n ? in[i] : 0;
-    int x = v;
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    const T v = i < n ? in[i] : (T)0;
+    T x = v;
+    for (int o = 1; o < 64; o <<= 1) { const T y = shfl_up_t(x, o); if (lane >= o) x += y; }
     if (lane == 63) wsum[wv] = x;
     __syncthreads();
-    int off = 0;
+    T off = 0;
     for (int w = 0; w < wv; ++w) off += wsum[w];
     if (i < n) out[i] = off + x - v;
     if (tid == 1023) blk[blockIdx.x] = off + x;
 }
 
-__global__ __launch_bounds__(1024) void scan_top_kernel(int *__restrict__ blk, int nb, int *__restrict__ total)
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_top_kernel(T *__restrict__ blk, int nb, T *__restrict__ total)
 {
-    __shared__ int wsum[16], carry_s;
+    __shared__ T wsum[16], carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < nb; base += 1024) {
         const int i = base + tid;
-        const int v = i < nb ? blk[i] : 0;
-        int x = v;
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        const T v = i < nb ? blk[i] : (T)0;
+        T x = v;
+        for (int o = 1; o < 64; o <<= 1) { const T y = shfl_up_t(x, o); if (lane >= o) x += y; }
         if (lane == 63) wsum[wv] = x;
         __syncthreads();
-        int off = carry_s;
+        T off = carry_s;
         for (int w = 0; w < wv; ++w) off += wsum[w];
         if (i < nb) blk[i] = off + x - v;
         __syncthreads();
@@ -305,7 +322,8 @@ __global__ __launch_bounds__(1024) void scan_top_kernel(int *__restrict__ blk, i
     if (tid == 0) *total = carry_s;
 }
 
-__global__ __launch_bounds__(1024) void scan_add_kernel(int *__restrict__ out, int n, const int *__restrict__ blk)
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_add_kernel(T *__restrict__ out, int n, const T *__restrict__ blk)
 {
     const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i < n) out[i] += blk[blockIdx.x];
@@ -319,10 +337,9 @@ struct flat_out {
     int *bad_lmid;
 };
 
-__global__ __launch_bounds__(256) void me_poses_kernel(map_view M, const int *__restrict__ kf_role, const int *__restrict__ kf_idx,
-                                                       flat_out O)
+__device__ __forceinline__ void me_poses(const map_view &M, int k, const int *__restrict__ kf_role, const int *__restrict__ kf_idx,
+                                         const flat_out &O)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= M.max_kf || kf_role[k] == 0) return;
     const int j = kf_idx[k];
     O.pose_kfid[j] = k;
@@ -330,14 +347,14 @@ __global__ __launch_bounds__(256) void me_poses_kernel(map_view M, const int *__
     for (int t = 0; t < 7; ++t) O.pose[7 * j + t] = M.kf_pose[7 * k + t];
 }
 
-__global__ __launch_bounds__(256) void me_lms_kernel(map_view M, int inv, const int *__restrict__ lm_flag, const int *__restrict__ lm_idx,
-                                                     const int *__restrict__ bad_flag, const int *__restrict__ bad_idx, flat_out O)
+__device__ __forceinline__ void me_lms(const map_view &M, int l, int inv, const int *__restrict__ lm_sel,
+                                       const int *__restrict__ lm_flag, const unsigned long long *__restrict__ lm_pidx, const flat_out &O)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= M.max_lm) return;
-    if (bad_flag[l]) O.bad_lmid[bad_idx[l]] = l;
+    const unsigned long long pi = lm_pidx[l];
+    if (lm_sel[l] == 2) O.bad_lmid[(int)(pi >> 32)] = l;
     if (!lm_flag[l]) return;
-    const int j = lm_idx[l];
+    const int j = (int)(pi & 0xffffffffull);
     O.lm_lmid[j] = l;
     if (!inv) {
         for (int t = 0; t < 3; ++t) O.lm[3 * j + t] = M.lm_xyz[3 * l + t];
@@ -356,16 +373,15 @@ __device__ __forceinline__ double depth_in_kf(const double *T, const double *p)
     return r02 * dx + r12 * dy + r22 * dz;
 }
 
-__global__ __launch_bounds__(256) void me_res_kernel(map_view M, int inv, const int *__restrict__ lm_flag, const int *__restrict__ lm_idx,
-                                                     const int *__restrict__ lm_anchor, const int *__restrict__ kf_idx,
-                                                     const int *__restrict__ obs_cnt, const int *__restrict__ obs_off,
-                                                     const int *__restrict__ hdr, flat_out O)
+__device__ __forceinline__ void me_res(const map_view &M, int i, int inv, const int *__restrict__ lm_flag,
+                                       const unsigned long long *__restrict__ lm_pidx, const int *__restrict__ lm_anchor,
+                                       const int *__restrict__ kf_idx, const int *__restrict__ obs_off, const int *__restrict__ hdr,
+                                       const flat_out &O)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M.n_obs) return;
     int kf, lm;
     if (hdr[MH_ABORT] || !obs_live(M, i, kf, lm) || !lm_flag[lm] || kf > hdr[MH_NMAXKF]) return;
-    const int j = lm_idx[lm], pj = kf_idx[kf];
+    const int j = (int)(lm_pidx[lm] & 0xffffffffull), pj = kf_idx[kf];
     const bool stereo = M.obs_flag[i] & OBS_STEREO;
     const double sigma = (double)(1 << M.obs_scale[i]);   // std::pow(2., kp.scale_)
     int o = obs_off[i];
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(256) void me_res_kernel(map_view M, int inv, const 
         O.res_uv[2 * o] = uv[0]; O.res_uv[2 * o + 1] = uv[1]; O.res_sigma[o] = sigma;
         ++o;
     };
-    if (inv && lm_anchor[lm] == kf) {
+    if (inv && lm_anchor[lm] == ANCH_TOP - kf) {
         O.lm[j] = 1.0 / depth_in_kf(M.kf_pose + 7 * kf, M.lm_xyz + 3 * lm);
         O.lm_anchor_pose[j] = pj;
         O.lm_anchor_uv[2 * j] = M.obs_uv[2 * i]; O.lm_anchor_uv[2 * j + 1] = M.obs_uv[2 * i + 1];
@@ -383,6 +399,19 @@ __global__ __launch_bounds__(256) void me_res_kernel(map_view M, int inv, const 
     }
     put(inv ? OV2_BA_L_INV : OV2_BA_L_XYZ, M.obs_uv + 2 * i);
     if (stereo) put(inv ? OV2_BA_R_INV : OV2_BA_R_XYZ, M.obs_ruv + 2 * i);
+}
+
+// one launch: blocks [0, gK) write the poses, [gK, gK + gL) the landmarks and the bad list, the rest the residual blocks
+__global__ __launch_bounds__(256) void me_all_kernel(map_view M, int gK, int gL, int inv, const int *__restrict__ kf_role,
+                                                     const int *__restrict__ kf_idx, const int *__restrict__ lm_sel,
+                                                     const int *__restrict__ lm_flag, const unsigned long long *__restrict__ lm_pidx,
+                                                     const int *__restrict__ lm_anchor, const int *__restrict__ obs_off,
+                                                     const int *__restrict__ hdr, flat_out O)
+{
+    const int blk = blockIdx.x, t = threadIdx.x;
+    if (blk < gK) me_poses(M, blk * 256 + t, kf_role, kf_idx, O);
+    else if (blk < gK + gL) me_lms(M, (blk - gK) * 256 + t, inv, lm_sel, lm_flag, lm_pidx, O);
+    else me_res(M, (blk - gK - gL) * 256 + t, inv, lm_flag, lm_pidx, lm_anchor, kf_idx, obs_off, hdr, O);
 }
 
 map_view view_of(const ov2_map *m)
@@ -395,14 +424,16 @@ map_view view_of(const ov2_map *m)
     return v;
 }
 
-ov2_status exclusive_scan(ov2_map *m, const int *in, int n, int *out, int *total)
+template <typename T>
+ov2_status exclusive_scan(ov2_map *m, const T *in, int n, T *out, T *total)
 {
     ov2_ctx *c = m->c;
     const int nb = (n + 1023) / 1024;
-    if (n <= 0) { OV2_HIP(c, hipMemsetAsync(total, 0, sizeof(int), c->stream)); return OV2_OK; }
-    OV2_LAUNCH(c, OV2_K_MAP, scan_block_kernel, dim3(nb), dim3(1024), 0, c->stream, in, n, out, m->blk);
-    OV2_LAUNCH(c, OV2_K_MAP, scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, m->blk, nb, total);
-    OV2_LAUNCH(c, OV2_K_MAP, scan_add_kernel, dim3(nb), dim3(1024), 0, c->stream, out, n, (const int *)m->blk);
+    if (n <= 0) { OV2_HIP(c, hipMemsetAsync(total, 0, sizeof(T), c->stream)); return OV2_OK; }
+    T *blk = reinterpret_cast<T *>(m->blk);
+    OV2_LAUNCH(c, OV2_K_MAP, scan_block_kernel<T>, dim3(nb), dim3(1024), 0, c->stream, in, n, out, blk);
+    OV2_LAUNCH(c, OV2_K_MAP, scan_top_kernel<T>, dim3(1), dim3(1024), 0, c->stream, blk, nb, total);
+    OV2_LAUNCH(c, OV2_K_MAP, scan_add_kernel<T>, dim3(nb), dim3(1024), 0, c->stream, out, n, (const T *)blk);
     return OV2_OK;
 }
 
@@ -448,15 +479,16 @@ static ov2_status alloc_tables(ov2_map *m)
 #define A(p, n) if (s == OV2_OK) s = dmalloc(c, &m->p, (n))
     A(kf_pose, 7 * K); A(kf_state, K); A(lm_xyz, 3 * L); A(lm_state, L);
     A(obs_kf, N); A(obs_lm, N); A(obs_scale, N); A(obs_uv, 2 * N); A(obs_ruv, 2 * N); A(obs_flag, N);
-    A(kf_idx, K); A(lm_anchor, L); A(lm_idx, L); A(lm_flag, L); A(bad_idx, L);
-    m->zero_bytes = sizeof(int) * (MH_N + 2 * K + 2 * L) + L;
+    A(kf_idx, K); A(lm_flag, L); A(lm_pack, L); A(lm_pidx, L);
+    m->zero_bytes = sizeof(int) * (MH_N + 2 * K + 3 * L) + L;
     A(zero_blk, m->zero_bytes);
     if (s == OV2_OK) {
         int *z = reinterpret_cast<int *>(m->zero_blk);
         m->hdr = z; m->cov = z + MH_N; m->kf_role = m->cov + K; m->lm_nobs = m->kf_role + K; m->lm_sel = m->lm_nobs + L;
-        m->lm_new = reinterpret_cast<unsigned char *>(m->lm_sel + L);
+        m->lm_anchor = m->lm_sel + L;
+        m->lm_new = reinterpret_cast<unsigned char *>(m->lm_anchor + L);
     }
-    A(obs_cnt, N); A(obs_off, N); A(blk, (std::max(N, L) + 1023) / 1024 + 1);
+    A(obs_cnt, N); A(obs_off, N); A(blk, 2 * ((std::max(N, L) + 1023) / 1024 + 1));   // block sums, up to 64-bit
 #undef A
     return s;
 }
@@ -464,8 +496,7 @@ static ov2_status alloc_tables(ov2_map *m)
 static void free_capacity_arrays(ov2_map *m)
 {
     void *dev[] = {m->kf_pose, m->kf_state, m->lm_xyz, m->lm_state, m->obs_kf, m->obs_lm, m->obs_scale, m->obs_uv, m->obs_ruv,
-                   m->obs_flag, m->zero_blk, m->kf_idx, m->lm_anchor, m->lm_idx, m->lm_flag, m->bad_idx, m->obs_cnt, m->obs_off,
-                   m->blk};
+                   m->obs_flag, m->zero_blk, m->kf_idx, m->lm_flag, m->lm_pack, m->lm_pidx, m->obs_cnt, m->obs_off, m->blk};
     for (void *p : dev) if (p) (void)hipFree(p);
 }
 
@@ -480,7 +511,7 @@ static ov2_status ensure_capacity(ov2_map *m, int need_kf, int need_lm, int need
     m->max_kf = grown(old.max_kf, need_kf); m->max_lm = grown(old.max_lm, need_lm); m->max_obs = grown(old.max_obs, need_obs);
     m->kf_pose = nullptr; m->kf_state = nullptr; m->lm_xyz = nullptr; m->lm_state = nullptr;
     m->obs_kf = m->obs_lm = m->obs_scale = nullptr; m->obs_uv = m->obs_ruv = nullptr; m->obs_flag = nullptr;
-    m->zero_blk = nullptr; m->kf_idx = m->lm_anchor = m->lm_idx = m->lm_flag = m->bad_idx = m->obs_cnt = m->obs_off = m->blk = nullptr;
+    m->zero_blk = nullptr; m->kf_idx = m->lm_flag = m->obs_cnt = m->obs_off = m->blk = nullptr; m->lm_pack = m->lm_pidx = nullptr;
     ov2_status s = alloc_tables(m);
     if (s != OV2_OK) {
         free_capacity_arrays(m);
@@ -733,7 +764,6 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     const map_view M = view_of(m);
     const dim3 gN((std::max(N, 1) + 255) / 256), gL((L + 255) / 256), gK((K + 255) / 256), b(256);
     OV2_HIP(c, hipMemsetAsync(m->zero_blk, 0, m->zero_bytes, st));
-    OV2_HIP(c, hipMemsetAsync(m->lm_anchor, 0x7f, sizeof(int) * L, st));   // 0x7f7f7f7f: larger than any kfid
     OV2_LAUNCH(c, OV2_K_MAP, ms_count_kernel, gN, b, 0, st, M, newkf, m->lm_nobs, m->lm_new, m->hdr);
     OV2_LAUNCH(c, OV2_K_MAP, ms_cov_kernel, gN, b, 0, st, M, newkf, (const unsigned char *)m->lm_new, m->cov);
     OV2_LAUNCH(c, OV2_K_MAP, ms_select_kernel, dim3(1), dim3(64), 0, st, M, newkf, nmin_covscore, (const int *)m->cov, m->kf_role, m->hdr);
@@ -741,15 +771,14 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
                (const int *)m->hdr);
     OV2_LAUNCH(c, OV2_K_MAP, ms_observers_kernel, gN, b, 0, st, M, (const int *)m->lm_sel, m->kf_role, m->lm_anchor, (const int *)m->hdr);
     OV2_LAUNCH(c, OV2_K_MAP, ms_poses_kernel, dim3(1), dim3(1024), 0, st, K, nmin_cst_kfs, m->kf_role, m->kf_idx, m->hdr);
-    // lm_nobs is free from here: it carries the bad-landmark flags
-    int *bad_flag = m->lm_nobs;
-    OV2_LAUNCH(c, OV2_K_MAP, ms_lm_flags_kernel, gL, b, 0, st, L, inv, (const int *)m->lm_sel, (const int *)m->lm_anchor, m->lm_flag, bad_flag);
+    OV2_LAUNCH(c, OV2_K_MAP, ms_lm_flags_kernel, gL, b, 0, st, L, inv, (const int *)m->lm_sel, (const int *)m->lm_anchor, m->lm_flag, m->lm_pack);
     ov2_status s;
-    if ((s = exclusive_scan(m, m->lm_flag, L, m->lm_idx, m->hdr + MH_NLM)) != OV2_OK) return s;
-    if ((s = exclusive_scan(m, bad_flag, L, m->bad_idx, m->hdr + MH_NBAD)) != OV2_OK) return s;
+    // one 64-bit scan numbers the landmarks (low word) and the bad list (high word); its total lands on NLM | NBAD
+    if ((s = exclusive_scan<unsigned long long>(m, m->lm_pack, L, m->lm_pidx, reinterpret_cast<unsigned long long *>(m->hdr + MH_NLM))) != OV2_OK)
+        return s;
     OV2_LAUNCH(c, OV2_K_MAP, ms_res_count_kernel, gN, b, 0, st, M, inv, (const int *)m->lm_flag, (const int *)m->lm_anchor, m->obs_cnt,
                (const int *)m->hdr);
-    if ((s = exclusive_scan(m, m->obs_cnt, N, m->obs_off, m->hdr + MH_NRES)) != OV2_OK) return s;
+    if ((s = exclusive_scan<int>(m, m->obs_cnt, N, m->obs_off, m->hdr + MH_NRES)) != OV2_OK) return s;
     OV2_HIP(c, hipMemcpyAsync(m->hdr_host, m->hdr, MH_N * sizeof(int), hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipStreamSynchronize(st));
     const int *H = m->hdr_host;
@@ -779,11 +808,9 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     O.lm_lmid = (int *)at(D, o_ll); O.lm = (double *)at(D, o_lm); O.lm_anchor_pose = (int *)at(D, o_la); O.lm_anchor_uv = (double *)at(D, o_lu);
     O.res_type = at(D, o_rt); O.res_pose = (int *)at(D, o_rp); O.res_lm = (int *)at(D, o_rl); O.res_uv = (double *)at(D, o_ru);
     O.res_sigma = (double *)at(D, o_rs); O.bad_lmid = (int *)at(D, o_bl);
-    OV2_LAUNCH(c, OV2_K_MAP, me_poses_kernel, gK, b, 0, st, M, (const int *)m->kf_role, (const int *)m->kf_idx, O);
-    OV2_LAUNCH(c, OV2_K_MAP, me_lms_kernel, gL, b, 0, st, M, inv, (const int *)m->lm_flag, (const int *)m->lm_idx, (const int *)bad_flag,
-               (const int *)m->bad_idx, O);
-    OV2_LAUNCH(c, OV2_K_MAP, me_res_kernel, gN, b, 0, st, M, inv, (const int *)m->lm_flag, (const int *)m->lm_idx, (const int *)m->lm_anchor,
-               (const int *)m->kf_idx, (const int *)m->obs_cnt, (const int *)m->obs_off, (const int *)m->hdr, O);
+    OV2_LAUNCH(c, OV2_K_MAP, me_all_kernel, dim3(gK.x + gL.x + gN.x), b, 0, st, M, (int)gK.x, (int)gL.x, inv, (const int *)m->kf_role,
+               (const int *)m->kf_idx, (const int *)m->lm_sel, (const int *)m->lm_flag, (const unsigned long long *)m->lm_pidx,
+               (const int *)m->lm_anchor, (const int *)m->obs_off, (const int *)m->hdr, O);
     OV2_HIP(c, hipMemcpyAsync(m->out_host, m->out_dev, off, hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipStreamSynchronize(st));
     unsigned char *Hh = m->out_host;
