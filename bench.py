@@ -52,6 +52,9 @@ def parse():
                     help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
                          "device-resident; off by default: the BASELINE metric is the tracking path")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mapper-ctx", type=int, default=0,
+                    help="1: the keyframe's right-image pyramid + stereo KLT run on a second context (the reference's mapper "
+                         "thread, src/mapper.cpp:76-97), overlapping the front-end's next frames")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for the real multi-GPU run; gloo rehearses the N > 1 control flow with "
                          "several ranks sharing one GPU")
@@ -149,6 +152,16 @@ class Workload:
 
     detect = True
     pnp = None
+    mctx = None
+
+    def enable_mapper_ctx(self, device):
+        """Mapper::run's share of a keyframe (right pyramid + stereoMatching) on its own context / streams"""
+        fe = self.fe
+        self.mctx = fe.Context(device)
+        self.mtrk = fe.FeatureTracker(self.mctx, 30, 0.01)
+        self.m_out_xy = self.mctx.empty((self.n, 2), np.float32)
+        self.m_out_st = self.mctx.empty((self.n,), np.uint8)
+        self.m_p3p = self.mctx.empty((self.B,), np.int32)
 
     def enable_pnp(self, seed):
         """per-frame computePose stand-in: one synthetic pose-refinement problem per sequence (kps points, 10 % outliers,
@@ -181,7 +194,14 @@ class Workload:
                                             True, q["outl"], q["rem"], q["ok"])
         self.prev = cur
         is_kf = (self.step_no % kf_every) == 0
-        if is_kf:                                                                    # 1.KF_stereoMatching
+        if is_kf and self.mctx is not None:                                          # 1.KF_stereoMatching on the mapper's context
+            kfpyr = cur.retain()                                                      # Keyframe keeps the pyramid (src/ov2slam.cpp:175-180)
+            rp = fe.preprocess_images(self.mctx, self.right[c], True, 3.0, WIN, NLVL)
+            self.mtrk.kltTracking_dev(kfpyr, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
+                                      self.m_out_xy, self.m_out_st, self.n, self.img_idx, self.m_p3p, None)
+            rp.release()
+            kfpyr.release_from(self.mctx)
+        elif is_kf:                                                                  # 1.KF_stereoMatching
             rp = fe.preprocess_images(ctx, self.right[c], True, 3.0, WIN, NLVL)
             self.trk.kltTracking_dev(cur, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
                                      self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, None)
@@ -290,6 +310,8 @@ def main():
     ctx = fe.Context(local)
     wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank)
 
+    if a.mapper_ctx:
+        wl.enable_mapper_ctx(local)
     if a.pnp:
         wl.enable_pnp(seed=777 + rank)
     ba = None
@@ -312,6 +334,8 @@ def main():
             ba.submit_all()                     # Mapper::run -> Estimator::addNewKf
     t_enq = time.perf_counter() - t0   # host time to enqueue the K steps (the detector's D2H syncs included)
     gpu_ms = ctx.timer_stop()     # synchronises the ctx stream
+    if wl.mctx is not None:
+        wl.mctx.synchronize()
     barrier()
     el = time.perf_counter() - t0
     if ba:

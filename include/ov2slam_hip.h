@@ -88,6 +88,10 @@ ov2_status ov2_pyramid_build_images(ov2_ctx *ctx, const ov2_images *imgs, int wi
                                     float clahe_clip, int tiles_x, int tiles_y, ov2_pyr **out);
 void ov2_pyr_retain(ov2_pyr *p);
 void ov2_pyr_release(ov2_pyr *p);
+/* release a reference whose readers were enqueued on ANOTHER context's stream (the mapper thread's context: Keyframe
+ * holds the pyramids for Mapper::run, include/mapper.hpp:39-85, src/mapper.cpp:76-97): the buffer is not reused before
+ * those readers have run.  One foreign consumer context per pyramid. */
+void ov2_pyr_release_from(ov2_ctx *user, ov2_pyr *p);
 int ov2_pyr_batch(const ov2_pyr *p);
 int ov2_pyr_nlevels(const ov2_pyr *p);
 ov2_status ov2_pyr_level_size(const ov2_pyr *p, int level, int *w, int *h, int *pad);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ov2_pyramid_build_images": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vpp]),
     "ov2_pyr_retain": (None, [vp]),
     "ov2_pyr_release": (None, [vp]),
+    "ov2_pyr_release_from": (None, [vp, vp]),
     "ov2_pyr_batch": (C.c_int, [vp]),
     "ov2_pyr_nlevels": (C.c_int, [vp]),
     "ov2_pyr_level_size": (C.c_int, [vp, C.c_int, ip, ip, ip]),

@@ -96,6 +96,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     for (ov2_pyr_buf *b : c->pool) {
         (void)hipEventDestroy(b->ready_ev);
         (void)hipEventDestroy(b->free_ev);
+        (void)hipEventDestroy(b->free_ev2);
         (void)hipFree(b->base);
         if (b->lut) (void)hipFree(b->lut);
         delete b;

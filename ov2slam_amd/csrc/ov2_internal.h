@@ -43,6 +43,8 @@ struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,ba
     hipEvent_t ready_ev; // recorded on the ctx pyramid stream when the build is enqueued; consumers wait on it
     hipEvent_t free_ev;  // recorded on the ctx main stream when the last handle is released; the next build waits on it
     bool has_free_ev;
+    hipEvent_t free_ev2; // recorded on ANOTHER context's main stream by ov2_pyr_release_from (the mapper's readers); the next build waits on it too
+    bool has_free_ev2;
     ov2_pyr_view view;
 };
 

@@ -448,7 +448,8 @@ ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int bat
             ov2_pyr_buf *b = c->pool[i];
             if (!(b->w == w && b->h == h && b->pad == pad && b->max_level == max_level && b->batch == batch)) continue;
             ++same;
-            if (!b->has_free_ev || hipEventQuery(b->free_ev) == hipSuccess) {
+            if ((!b->has_free_ev || hipEventQuery(b->free_ev) == hipSuccess) &&
+                (!b->has_free_ev2 || hipEventQuery(b->free_ev2) == hipSuccess)) {
                 c->pool.erase(c->pool.begin() + i);
                 *out = b;
                 return OV2_OK;
@@ -499,12 +500,14 @@ ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int bat
         return ov2_set_err(c, OV2_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (hipEventCreateWithFlags(&b->ready_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->free_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&b->free_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->free_ev2, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(b->base);
         delete b;
         return ov2_set_err(c, OV2_ERR_HIP, "hipEventCreate failed");
     }
     b->has_free_ev = false;
+    b->has_free_ev2 = false;
     v.base = b->base;
     *out = b;
     return OV2_OK;
@@ -532,6 +535,10 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
     hipStream_t sp = c->stream_pyr;
     // a pooled buffer may still be read by kernels of the main stream (its last consumers): wait for their release mark
     if (buf->has_free_ev) OV2_HIP(c, hipStreamWaitEvent(sp, buf->free_ev, 0));
+    if (buf->has_free_ev2) {   // readers another context enqueued on its own stream (ov2_pyr_release_from)
+        OV2_HIP(c, hipStreamWaitEvent(sp, buf->free_ev2, 0));
+        buf->has_free_ev2 = false;
+    }
 
     float inv_tw = 0.f, inv_th = 0.f;
     if (use_clahe) {
@@ -636,6 +643,20 @@ extern "C" void ov2_pyr_release(ov2_pyr *p)
         p->ctx->pool.push_back(p->buf);
         delete p;
     }
+}
+
+// A consumer on ANOTHER context (the reference's mapper thread works on the keyframe's pyramid while the front-end
+// moves on, src/mapper.cpp:76-97) enqueued its readers on `user`'s main stream: mark that point on the buffer, so
+// the next build into it waits for them, then drop the reference.  One foreign consumer stream per pyramid.
+extern "C" void ov2_pyr_release_from(ov2_ctx *user, ov2_pyr *p)
+{
+    if (!p) return;
+    if (user && user != p->ctx) {
+        (void)hipSetDevice(user->device);
+        std::lock_guard<std::mutex> g(p->ctx->mu);
+        if (hipEventRecord(p->buf->free_ev2, user->stream) == hipSuccess) p->buf->has_free_ev2 = true;
+    }
+    ov2_pyr_release(p);
 }
 
 extern "C" int ov2_pyr_batch(const ov2_pyr *p) { return p ? p->buf->batch : 0; }

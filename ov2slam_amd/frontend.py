@@ -144,6 +144,17 @@ class Pyramid:
             self.ctx.lib.ov2_pyr_release(self.h)
         self.h = None
 
+    def retain(self):
+        """a second owner (the Keyframe handed to the mapper thread, src/ov2slam.cpp:175-180): returns a new handle object"""
+        self.ctx.lib.ov2_pyr_retain(self.h)
+        return Pyramid(self.ctx, self.h)
+
+    def release_from(self, user_ctx):
+        """release a reference whose readers ran on another context's stream (ov2_pyr_release_from)"""
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.ov2_pyr_release_from(user_ctx.h, self.h)
+        self.h = None
+
     def __del__(self):
         self.release()
 

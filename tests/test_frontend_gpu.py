@@ -121,6 +121,42 @@ def test_fb_klt_random_sweep(ctx, oracle, stream, win):
             assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), (t0, t1, nl)
 
 
+def test_pyramids_consumed_by_another_context(ctx, oracle, stream):
+    """the mapper thread's pattern (src/ov2slam.cpp:175-180, src/mapper.cpp:76-97): a second context tracks on pyramids
+    the front-end context built and has already released on its side; the front-end keeps building into its pool in the
+    meantime.  ov2_pyr_release_from marks the consumer's stream on the buffer, so no build overwrites what the
+    consumer still reads -- results stay bit-identical to the oracle."""
+    ctx2 = fe.Context(0)
+    try:
+        trk2 = fe.FeatureTracker(ctx2, 30, 0.01)
+        kps = synth.grid_keypoints(1500)
+        frames = [(0, 3), (5, 2), (9, 12), (4, 7)]
+        want = {}
+        for t0, t1 in frames:
+            o0, o1 = oracle.Pyramid(oracle.clahe(stream.left(t0), 3.0, 15, 9), 9, 3), oracle.Pyramid(oracle.clahe(stream.left(t1), 3.0, 15, 9), 9, 3)
+            want[(t0, t1)] = oracle.fb_klt_tracking(o0, o1, kps, kps, 9, 3, 30.0, 0.5, 30, 0.01)
+        d_k = ctx2.to_device(kps)
+        for rep in range(6):
+            outs = []
+            for t0, t1 in frames:
+                p0, p1 = fe.preprocess_image(ctx, stream.left(t0)), fe.preprocess_image(ctx, stream.left(t1))
+                k0, k1 = p0.retain(), p1.retain()        # the keyframe's share
+                p0.release(); p1.release()               # the front-end moves on ...
+                d_p, d_s = ctx2.to_device(kps), ctx2.empty((len(kps),), np.uint8)
+                trk2.fbKltTracking_dev(k0, k1, 9, 3, 30.0, 0.5, d_k, d_p, d_s, len(kps))
+                k0.release_from(ctx2); k1.release_from(ctx2)
+                for t in (1, 6, 11):                      # ... and keeps its pyramid pool busy
+                    fe.preprocess_image(ctx, stream.left(t)).release()
+                outs.append((d_p, d_s))
+            ctx2.synchronize()
+            for (t0, t1), (d_p, d_s) in zip(frames, outs):
+                eout, est, _ = want[(t0, t1)]
+                assert np.array_equal(d_s.get().astype(bool), est.astype(bool)), (rep, t0, t1)
+                assert np.array_equal(d_p.get().view(np.uint32), eout.view(np.uint32)), (rep, t0, t1)
+    finally:
+        ctx2.close()
+
+
 def test_fb_klt_edge_cases(ctx, oracle, stream):
     """points on/over the border, in flat (min-eig reject) regions, priors far outside, empty input."""
     I0 = stream.left(0).copy()
