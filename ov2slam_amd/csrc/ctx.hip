@@ -76,7 +76,10 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
         e2 = hipExtStreamCreateWithCUMask(&c->stream_pyr, (uint32_t)words, mask.data());
     } else {
         e1 = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
-        e2 = hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
+        // experiment hook: OV2_SINGLE_STREAM=1 builds the pyramids on the main stream (no overlap with the tracking)
+        const char *one = getenv("OV2_SINGLE_STREAM");
+        if (one && atoi(one) > 0) { c->stream_pyr = c->stream; e2 = hipSuccess; }
+        else e2 = hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
     }
     if (e1 != hipSuccess || e2 != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
@@ -114,7 +117,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
-    (void)hipStreamDestroy(c->stream_pyr);
+    if (c->stream_pyr != c->stream) (void)hipStreamDestroy(c->stream_pyr);
     delete c;
 }
 
