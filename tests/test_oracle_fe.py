@@ -3,6 +3,7 @@ brute-force numpy re-derivation of the integer stages.  OpenCV is not in the con
 holds no fixture for this path, so the KLT oracle is 'parity unpinned' (see oracle/ov2_oracle.h); these
 tests pin it against independent numpy formulas of the published algorithm instead."""
 import numpy as np
+import pytest
 
 from ov2slam_amd import synth
 
@@ -64,6 +65,61 @@ def test_clahe_properties(oracle):
     assert (np.diff(o2.ravel()[order].astype(int)) >= 0).all()
 
 
+def _clahe_numpy(img, clip, tiles_x, tiles_y):
+    """independent numpy restatement of cv::CLAHE::apply for 8-bit images (OpenCV modules/imgproc/src/clahe.cpp as
+    described in SURVEY Appendix A): REFLECT_101 extension to a multiple of the tile grid, per-tile histogram, clip +
+    uniform redistribution + residual stride, cumulative LUT scaled by 255 / tile area (round half to even, saturate),
+    bilinear blend of the four surrounding tile LUTs in float32."""
+    h, w = img.shape
+    ew, eh = w, h
+    if w % tiles_x or h % tiles_y:
+        ew, eh = w + (tiles_x - w % tiles_x), h + (tiles_y - h % tiles_y)
+    ext = np.pad(img, ((0, eh - h), (0, ew - w)), mode="reflect")
+    tw, th = ew // tiles_x, eh // tiles_y
+    area = tw * th
+    limit = max(int(float(clip) * area / 256), 1) if clip > 0 else 0
+    luts = np.zeros((tiles_y, tiles_x, 256), np.uint8)
+    scale = np.float32(255.0) / np.float32(area)
+    for ty in range(tiles_y):
+        for tx in range(tiles_x):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if limit > 0:
+                excess = int(np.maximum(hist - limit, 0).sum())
+                hist = np.minimum(hist, limit)
+                hist += excess // 256
+                res = excess % 256
+                if res:
+                    step = max(256 // res, 1)
+                    idx = np.arange(0, 256, step)[:res]
+                    hist[idx] += 1
+            cdf = np.cumsum(hist).astype(np.float32) * scale
+            luts[ty, tx] = np.clip(np.rint(cdf), 0, 255).astype(np.uint8)
+    inv_tw, inv_th = np.float32(1.0) / np.float32(tw), np.float32(1.0) / np.float32(th)
+    xs, ys = np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32)
+    txf, tyf = xs * inv_tw - np.float32(0.5), ys * inv_th - np.float32(0.5)
+    tx1, ty1 = np.floor(txf).astype(np.int32), np.floor(tyf).astype(np.int32)
+    xa, ya = (txf - tx1.astype(np.float32)), (tyf - ty1.astype(np.float32))
+    xa1, ya1 = np.float32(1.0) - xa, np.float32(1.0) - ya
+    tx2, ty2 = np.minimum(tx1 + 1, tiles_x - 1), np.minimum(ty1 + 1, tiles_y - 1)
+    tx1, ty1 = np.maximum(tx1, 0), np.maximum(ty1, 0)
+    v = img.astype(np.int64)
+    Y1, Y2 = ty1[:, None], ty2[:, None]
+    X1, X2 = tx1[None, :], tx2[None, :]
+    f = lambda Y, X: luts[Y, X, v].astype(np.float32)
+    top = f(Y1, X1) * xa1[None, :] + f(Y1, X2) * xa[None, :]
+    bot = f(Y2, X1) * xa1[None, :] + f(Y2, X2) * xa[None, :]
+    res = top * ya1[:, None] + bot * ya[:, None]
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,tiles,clip", [(752, 480, (15, 9), 3.0), (320, 240, (8, 8), 2.0), (97, 61, (3, 2), 40.0),
+                                            (128, 96, (4, 4), 0.5), (200, 120, (4, 3), 0.0)])
+def test_clahe_against_independent_numpy(oracle, w, h, tiles, clip):
+    rng = np.random.default_rng(w + h)
+    img = (np.linspace(0, 255, w)[None, :] * 0.6 + rng.integers(0, 100, size=(h, w))).clip(0, 255).astype(np.uint8)
+    assert np.array_equal(oracle.clahe(img, clip, tiles[0], tiles[1]), _clahe_numpy(img, clip, tiles[0], tiles[1]))
+
+
 def test_lk_recovers_known_subpixel_shift(oracle, stream):
     I0, I1 = stream.left(0), stream.left(10)
     P0, P1 = oracle.Pyramid(oracle.clahe(I0)), oracle.Pyramid(oracle.clahe(I1))
@@ -76,6 +132,88 @@ def test_lk_recovers_known_subpixel_shift(oracle, stream):
     # identity pair: zero motion, every point survives the forward-backward gate
     out2, st2, _ = oracle.fb_klt_tracking(P0, P0, kps, kps)
     assert st2.all() and np.abs(out2 - kps).max() < 1e-3
+
+
+def _lk_numpy_level0(Ii, Ig, Ji, pad, w, h, pt, guess, win=9, max_iter=30, eps=0.01, min_eig_thr=1e-4):
+    """independent restatement of one LKTrackerInvoker level in numpy: float32 scalars in the order
+    the C expressions evaluate, exact integer sums converted to float32 once (the oracle's documented choice).
+    Ii / Ji: padded u8 planes, Ig: padded (Ix, Iy) int16 plane.  returns (x, y) float32, status, err."""
+    f = np.float32
+    half = f((win - 1) * 0.5)
+    scale = f(1.0) / f(1 << 20)
+
+    def weights(fx, fy):
+        w00 = int(np.rint((f(1) - fx) * (f(1) - fy) * f(1 << 14)))
+        w01 = int(np.rint(fx * (f(1) - fy) * f(1 << 14)))
+        w10 = int(np.rint((f(1) - fx) * fy * f(1 << 14)))
+        return w00, w01, w10, (1 << 14) - w00 - w01 - w10
+
+    px, py = f(pt[0]) - half, f(pt[1]) - half
+    ipx, ipy = int(np.floor(px)), int(np.floor(py))
+    if ipx < -win or ipx >= w or ipy < -win or ipy >= h:
+        return (f(guess[0]), f(guess[1])), 0, f(0)
+    w00, w01, w10, w11 = weights(px - f(ipx), py - f(ipy))
+    ys, xs = np.mgrid[0:win, 0:win]
+    r, c = ipy + pad + ys, ipx + pad + xs
+    tap = lambda P: P[r, c].astype(np.int64) * w00 + P[r, c + 1].astype(np.int64) * w01 + P[r + 1, c].astype(np.int64) * w10 + \
+        P[r + 1, c + 1].astype(np.int64) * w11
+    I = (tap(Ii) + (1 << 8)) >> 9
+    Ix = (tap(Ig[..., 0]) + (1 << 13)) >> 14
+    Iy = (tap(Ig[..., 1]) + (1 << 13)) >> 14
+    tof = lambda v: f(float(int(v))) * scale           # exact integer -> double -> float32, then the 2^-20 scale
+    A11, A12, A22 = tof((Ix * Ix).sum()), tof((Ix * Iy).sum()), tof((Iy * Iy).sum())
+    D = A11 * A22 - A12 * A12
+    min_eig = (A22 + A11 - np.sqrt((A11 - A22) * (A11 - A22) + f(4) * A12 * A12)) / f(2 * win * win)
+    if min_eig < f(min_eig_thr) or D < f(1.1920929e-07):
+        return (f(guess[0]), f(guess[1])), 0, min_eig
+    D = f(1) / D
+    nx, ny = f(guess[0]) - half, f(guess[1]) - half
+    ox, oy = f(guess[0]), f(guess[1])
+    e = float(np.float32(eps))
+    pdx = pdy = f(0)
+    for j in range(max_iter):
+        inx, iny = int(np.floor(nx)), int(np.floor(ny))
+        if inx < -win or inx >= w or iny < -win or iny >= h:
+            return (ox, oy), 0, min_eig
+        w00, w01, w10, w11 = weights(nx - f(inx), ny - f(iny))
+        r, c = iny + pad + ys, inx + pad + xs
+        Jv = (tap(Ji) + (1 << 8)) >> 9
+        diff = Jv - I
+        b1, b2 = tof((diff * Ix).sum()), tof((diff * Iy).sum())
+        dx, dy = (A12 * b2 - A22 * b1) * D, (A12 * b1 - A11 * b2) * D
+        nx, ny = nx + dx, ny + dy
+        ox, oy = nx + half, ny + half
+        if float(dx) * float(dx) + float(dy) * float(dy) <= e * e:
+            break
+        if j > 0 and abs(dx + pdx) <= f(0.01) and abs(dy + pdy) <= f(0.01):
+            ox, oy = ox - dx * f(0.5), oy - dy * f(0.5)
+            break
+        pdx, pdy = dx, dy
+    return (ox, oy), 1, min_eig
+
+
+@pytest.mark.parametrize("win", [5, 9, 11])
+def test_lk_level_against_independent_numpy(oracle, stream, win):
+    """one pyramid level of calcOpticalFlowPyrLK (maxLevel = 0): positions bit-equal, status and min-eigenvalue equal"""
+    rng = np.random.default_rng(win)
+    I0, I1 = stream.left(0), stream.left(4)
+    I0 = I0.copy(); I0[200:260, 300:420] = 90            # a flat block: min-eigenvalue rejection
+    P0, P1 = oracle.Pyramid(I0, 11, 0), oracle.Pyramid(I1, 11, 0)
+    i0, g0, w, h, pad = P0.level(0)
+    i1, _, _, _, _ = P1.level(0)
+    n = 90
+    pts = np.stack([rng.uniform(-3, w + 3, n), rng.uniform(-3, h + 3, n)], 1).astype(np.float32)
+    pts[:6] = [[330, 230], [0, 0], [w - 1, h - 1], [0.4, h - 0.6], [w + 20, 50], [-14, 100]]
+    guess = (pts + rng.uniform(-1.5, 1.5, pts.shape)).astype(np.float32)
+    guess[7] = [w + 40, 10]                                # the search window leaves the image: status 0
+    out, st, err, _ = oracle.calc_optical_flow_pyr_lk(P0, P1, pts, guess, win=win, max_level=0)
+    for k in range(n):
+        (x, y), s, e = _lk_numpy_level0(i0, g0, i1, pad, w, h, pts[k], guess[k], win=win)
+        assert s == st[k], k
+        if s:
+            assert np.float32(e) == err[k], k
+        assert (np.float32(x), np.float32(y)) == (out[k, 0], out[k, 1]), (k, x, y, out[k])
+    assert st.sum() > 40 and st[0] == 0
 
 
 def test_fb_wrapper_gates(oracle, stream):
