@@ -216,6 +216,39 @@ def test_lk_level_against_independent_numpy(oracle, stream, win):
     assert st.sum() > 40 and st[0] == 0
 
 
+def test_lk_pyramid_chain_against_independent_numpy(oracle, stream):
+    """the coarse-to-fine chaining of calcOpticalFlowPyrLK (prev = kp / 2^l, the guess enters at maxLevel as
+    prior / 2^l and is doubled between levels, status can only be cleared at level 0, err = min-eigenvalue of the last
+    level that ran) on top of the per-level numpy restatement above"""
+    rng = np.random.default_rng(3)
+    P0, P1 = oracle.Pyramid(stream.left(0), 9, 3), oracle.Pyramid(stream.left(9), 9, 3)
+    lv0 = [P0.level(l) for l in range(4)]
+    lv1 = [P1.level(l) for l in range(4)]
+    n = 60
+    pts = np.stack([rng.uniform(2, 750, n), rng.uniform(2, 478, n)], 1).astype(np.float32)
+    pts[:4] = [[0, 0], [751, 479], [1.5, 470.2], [749.0, 3.0]]
+    guess = (pts + rng.uniform(-4, 4, pts.shape)).astype(np.float32)
+    out, st, err, _ = oracle.calc_optical_flow_pyr_lk(P0, P1, pts, guess, win=9, max_level=3)
+    f = np.float32
+    for k in range(n):
+        status, e, nxt = 1, f(0), None
+        for l in (3, 2, 1, 0):
+            sc = f(1.0) / f(1 << l)
+            i0, g0, w, h, pad = lv0[l]
+            i1 = lv1[l][0]
+            p = (pts[k, 0] * sc, pts[k, 1] * sc)
+            g = (guess[k, 0] * sc, guess[k, 1] * sc) if l == 3 else (nxt[0] * f(2), nxt[1] * f(2))
+            nxt, s, el = _lk_numpy_level0(i0, g0, i1, pad, w, h, p, g)
+            if s or el != 0:
+                e = el
+            if l == 0 and not s:
+                status = 0
+        assert status == st[k], k
+        assert (f(nxt[0]), f(nxt[1])) == (out[k, 0], out[k, 1]), (k, nxt, out[k])
+        if status:
+            assert f(e) == err[k], k
+
+
 def test_fb_wrapper_gates(oracle, stream):
     I0 = stream.left(0).copy()
     I0[200:300, 200:400] = 90
