@@ -130,3 +130,63 @@ def test_corner_subpix_converges_on_a_synthetic_corner(oracle):
     assert np.abs(out - [cx, cy]).max() < 0.6
     far = oracle.corner_subpix(img, np.array([[10.0, 10.0]], np.float32))     # flat: singular system -> unchanged
     assert np.allclose(far, [[10.0, 10.0]])
+
+
+def _corner_subpix_numpy(img, pt, hw=3, max_iter=30, eps=0.01):
+    """independent numpy restatement of cv::cornerSubPix (win = (hw, hw), no zero zone) from its published algorithm:
+    getRectSubPix of a (2hw+3)^2 float patch around the current estimate (bilinear, BORDER_REPLICATE), central
+    differences, weights exp(-x^2/hw^2) exp(-y^2/hw^2), gradient-orthogonality normal equations in double; float64
+    sums in natural order (the oracle's strided 16-leaf order differs in the last bits only)."""
+    h, w = img.shape
+    win = 2 * hw + 1
+    bw = win + 2
+    m1 = np.exp(-((np.arange(win) - hw) ** 2).astype(np.float32) * np.float32(1.0 / (hw * hw))).astype(np.float32)
+    mask = np.outer(m1, m1).astype(np.float32)
+    cT = np.array(pt, np.float32)
+    cI = cT.copy()
+    it = 0
+    while True:
+        c = cI - np.float32((bw - 1) * 0.5)
+        ip = np.floor(c).astype(np.int64)
+        a, b = np.float32(c[0] - ip[0]), np.float32(c[1] - ip[1])
+        ys = np.clip(ip[1] + np.arange(bw + 1), 0, h - 1)
+        xs = np.clip(ip[0] + np.arange(bw + 1), 0, w - 1)
+        src = img[np.ix_(ys, xs)].astype(np.float32)
+        one = np.float32(1)
+        a11, a12, a21, a22 = (one - a) * (one - b), a * (one - b), (one - a) * b, a * b
+        patch = src[:-1, :-1] * a11 + src[:-1, 1:] * a12 + src[1:, :-1] * a21 + src[1:, 1:] * a22
+        gx = (patch[1:-1, 2:] - patch[1:-1, :-2]).astype(np.float64)
+        gy = (patch[2:, 1:-1] - patch[:-2, 1:-1]).astype(np.float64)
+        m = mask.astype(np.float64)
+        gxx, gxy, gyy = gx * gx * m, gx * gy * m, gy * gy * m
+        py, px = np.mgrid[-hw:hw + 1, -hw:hw + 1].astype(np.float64)
+        A, B, Cc = gxx.sum(), gxy.sum(), gyy.sum()
+        bb1, bb2 = (gxx * px + gxy * py).sum(), (gxy * px + gyy * py).sum()
+        det = A * Cc - B * B
+        if abs(det) <= np.finfo(np.float64).eps ** 2:
+            break
+        sc = 1.0 / det
+        n = np.array([cI[0] + Cc * sc * bb1 - B * sc * bb2, cI[1] - B * sc * bb1 + A * sc * bb2]).astype(np.float32)
+        d = n - cI
+        err = float(d[0] * d[0] + d[1] * d[1])
+        cI = n
+        if cI[0] < 0 or cI[0] >= w or cI[1] < 0 or cI[1] >= h:
+            break
+        it += 1
+        if not (it < max_iter and err > eps * eps):
+            break
+    if abs(cI[0] - cT[0]) > hw or abs(cI[1] - cT[1]) > hw:
+        cI = cT
+    return cI
+
+
+def test_corner_subpix_against_independent_numpy(oracle, stream):
+    img = stream.left(2)
+    det, _ = oracle.detect_single_scale(img, 35, np.zeros((0, 2), np.float32), 0.001, subpix=False)
+    assert len(det) > 100
+    pts = det[:120].astype(np.float32)
+    pts[:4] = [[1.0, 1.0], [750.0, 478.0], [0.0, 240.0], [375.5, 0.2]]          # patches reaching over the border: REPLICATE
+    got = oracle.corner_subpix(img, pts)
+    want = np.stack([_corner_subpix_numpy(img, p) for p in pts])
+    d = np.abs(got - want).max(1)
+    assert np.median(d) < 1e-5 and d.max() < 2e-3, (np.median(d), d.max())
