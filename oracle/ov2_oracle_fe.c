@@ -11,6 +11,9 @@
  *   ov2o_klt_tracking_frame <- VisualFrontEnd::kltTracking src/visual_front_end.cpp:132-275
  * OpenCV itself is not in the container (parity unpinned, see header): the arithmetic follows OpenCV's
  * published lkpyramid.cpp / pyramids.cpp / clahe.cpp semantics as written down in SURVEY.md Appendix A.
+ * Pinned instead by independent numpy restatements written from that specification (tests/test_oracle_fe.py):
+ * pyrDown / Scharr / borders, the whole of CLAHE (byte-equal), one LKTrackerInvoker level and the coarse-to-fine
+ * chaining (bit-equal positions, status, err).
  *
  * One deliberate choice: the LK sums (A11,A12,A22,b1,b2) are accumulated EXACTLY in int64 and
  * converted to float once.  OpenCV does that on ARM (acctype=int64) and uses order-dependent float
