@@ -2,8 +2,11 @@
 """bench.py -- tracked frames/s (+ localBA iterations/s) of the MI355X front-end + local-BA hot path.
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launched with torch.distributed.run,
-one rank per GPU.  W untimed steps, then EXACTLY K timed steps bracketed by barrier + synchronize, MAX over
-ranks, rank 0 prints ONE JSON line.
+one rank per GPU.  W untimed steps, then EXACTLY K timed steps, MAX over ranks, rank 0 prints ONE JSON line.
+One bench STEP = `--chunk` (100) frame-batches (= 100 consecutive stereo frames of every sequence), so the driver's
+--steps 20 is ~1 s of steady state.  The region starts after barrier + torch.cuda.synchronize(); it ends when the
+front-end context's own streams have drained (NOT a device-wide sync, which would also wait for the concurrent
+local-BA worker's in-flight batch); the barrier + device sync of the contract follow right after the clock stops.
 
 Workload (BASELINE.json north_star; synthetic because no EuRoC data exists here or on the GPU box):
   synthetic 752x480 stereo streams, `--kps` (2048) keypoints per frame, `--seqs` independent sequences per GPU
@@ -34,13 +37,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--chunk", type=int, default=100,
+                    help="frame-batches per bench step: one step = `chunk` consecutive stereo frames of every sequence, so that "
+                         "the driver's --steps 20 --warmup 5 times a steady-state region of ~1 s instead of 17 ms of launch tail")
     ap.add_argument("--seqs", type=int, default=64, help="independent sequences per GPU (batched per launch); 64 x 2048 keypoints keep the KLT kernels several wave-rounds deep (16: 58k, 64: 97k, 128: 105k, 256: 111k frames/s on one MI355X)")
     ap.add_argument("--kps", type=int, default=2048, help="keypoints per frame (north_star: ~2k)")
     ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per stream (ping-pong cycle)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH cpu_baseline leg (1 thread, N threads)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the N-thread LK leg (0 = host CPU share, at most 16)")
+    ap.add_argument("--instr-batches", type=int, default=300, help="frame-batches of the instrumented (per-kernel hipEvent) pass")
     ap.add_argument("--ba-kfs", type=int, default=50, help="keyframes in the local-BA window (north_star: ~50)")
     ap.add_argument("--ba-lms", type=int, default=10000, help="landmarks in the local-BA window")
     ap.add_argument("--no-ba", action="store_true", help="front-end only (no concurrent localBA worker)")
@@ -230,6 +238,8 @@ class BaWorker:
             w.submit_all()                        # warm-up (allocations, code objects); not counted
         self.solves = self.iters = self.dropped = self.submitted = 0
         self.busy_s = 0.0
+        self.mode = ("Estimator-like native worker threads, each on its own high-priority HIP stream, concurrent with the "
+                     "front-end (reference: src/estimator.cpp:32-98); robust solve (<=5 it) + L2 (<=10 it)")
 
     def submit_all(self):
         for w in self.ws:
@@ -256,33 +266,40 @@ class BaWorker:
             w.close()
 
 
-def cpu_baseline(workload, kf_every, budget_s):
-    """the oracle (a scalar C port of the OpenCV path) timed on this host, 1 thread, on a bounded sample of the
-    SAME workload (one sequence).  Reported beside the GPU number, never the thing measured or shipped."""
+def cpu_baseline(workload, kf_every, budget_s, threads=1):
+    """the oracle (a C port of the OpenCV path) timed on this host on a bounded sample of the SAME workload (one
+    sequence); `threads` > 1 splits the points of every LK call over a persistent thread pool, as OpenCV's
+    parallel_for_ does (CLAHE + pyramid stay on one thread).  Reported beside the GPU number, never shipped."""
     from oracle import oracle_py as O
+    O.set_num_threads(threads)
     left, right, order, base, S = workload.host_frames
     from ov2slam_amd import synth
     L = len(order)
+    # priors of every cycle position, made before the clock starts (numpy; not part of the path)
+    tpri, spri = [], []
+    for s in range(L):
+        cur_i, prv_i = order[s % L], order[(s - 1) % L]
+        tpri.append(synth.make_priors(base, S.flow(3 * prv_i, 3 * cur_i, base), seed=1 + s))
+        spri.append(synth.make_priors(base, S.stereo_gt(base), seed=2 + s))
     t0 = time.perf_counter()
     prev, frames, s = None, 0, 0
     while True:
-        cur_i, prv_i = order[s % L], order[(s - 1) % L]
+        cur_i = order[s % L]
         cur = O.Pyramid(O.clahe(left[cur_i], 3.0, 15, 9), WIN, NLVL)
         if prev is not None:
-            gt = S.flow(3 * prv_i, 3 * cur_i, base)
-            pri, has = synth.make_priors(base, gt, seed=1 + s)
+            pri, has = tpri[s % L]
             O.klt_tracking_frame(prev, cur, base, pri, has, WIN, NLVL, 30.0, 0.5, 30, 0.01)
         if s % kf_every == 0:
             rp = O.Pyramid(O.clahe(right[cur_i], 3.0, 15, 9), WIN, NLVL)
-            spri, shas = synth.make_priors(base, S.stereo_gt(base), seed=2 + s)
-            O.klt_tracking_frame(cur, rp, base, spri, shas, WIN, NLVL, 30.0, 0.5, 30, 0.01)
+            pri, has = spri[s % L]
+            O.klt_tracking_frame(cur, rp, base, pri, has, WIN, NLVL, 30.0, 0.5, 30, 0.01)
         prev = cur
         frames += 1
         s += 1
         el = time.perf_counter() - t0
         if el > budget_s and frames >= 2 * kf_every:
             break
-    # subtract the host-side prior generation (numpy) by timing it alone is overkill: it is <2 % of a frame
+    O.set_num_threads(1)
     return frames / el, frames, el
 
 
@@ -317,9 +334,18 @@ def main():
     ba = None
     if not a.no_ba:
         ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers)
+    def run_step():
+        """one bench step = a.chunk frame-batches; returns the number of keyframe batches it held"""
+        k = 0
+        for _ in range(a.chunk):
+            kf = wl.step(a.kf_every)
+            k += kf
+            if kf and ba:
+                ba.submit_all()                 # Mapper::run -> Estimator::addNewKf
+        return k
+
     for _ in range(a.warmup):
-        if wl.step(a.kf_every) and ba:
-            ba.submit_all()
+        run_step()
     ctx.synchronize()
     barrier()
     if ba:
@@ -328,33 +354,23 @@ def main():
     ctx.timer_start()
     nkf = 0
     for _ in range(a.steps):
-        kf = wl.step(a.kf_every)
-        nkf += kf
-        if kf and ba:
-            ba.submit_all()                     # Mapper::run -> Estimator::addNewKf
-    t_enq = time.perf_counter() - t0   # host time to enqueue the K steps (the detector's D2H syncs included)
-    gpu_ms = ctx.timer_stop()     # synchronises the ctx stream
+        nkf += run_step()
+    t_enq = time.perf_counter() - t0   # host time to enqueue the K steps
+    gpu_ms = ctx.timer_stop()          # synchronises the ctx main stream
+    ctx.synchronize()                  # ... and the pyramid stream: every launch of the K steps has completed
     if wl.mctx is not None:
         wl.mctx.synchronize()
-    barrier()
     el = time.perf_counter() - t0
     if ba:
-        # a timed region shorter than one solve completes none: let the worker finish ONE job after the region and
-        # report its rate over its own busy time instead (flagged as such); the frames/s above is unaffected
-        ba_post_region = False
-        ba.refresh()
-        if ba.solves == 0:
-            ba_post_region = True
-            ba.submit_all()
-            t_wait = time.perf_counter()
-            while ba.refresh()["solves"] == 0 and time.perf_counter() - t_wait < 60.0:
-                time.sleep(0.002)
-        ba.set_counting(False)
+        ba.set_counting(False)         # solves that complete after this instant do not count
         ba.refresh()
         ba.stop()
+    barrier()                          # the contract's closing barrier + device sync, outside the clock (it would wait for
+                                       # the BA worker's in-flight batch, which is not front-end work)
+    nbatches = a.steps * a.chunk
 
     # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
-    el_max, cnt = dist_util.aggregate(el, [a.steps * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
+    el_max, cnt = dist_util.aggregate(el, [nbatches * a.seqs, ba.iters if ba else 0, ba.solves if ba else 0,
                                            ba.submitted if ba else 0, ba.dropped if ba else 0],
                                        device="cuda" if a.dist_backend == "nccl" else "cpu")
     frames_all, ba_iters_all, ba_solves_all, ba_sub_all, ba_drop_all = cnt
@@ -367,26 +383,29 @@ def main():
         "config": {"workload": "synthetic 752x480 stereo streams, CLAHE + 4-level pyramid + 2-stage fwd-bwd KLT "
                                f"(win 9, 30 it, eps 0.01) on {a.kps} kps/frame; every {a.kf_every}th frame is a keyframe: "
                                f"right-image pyramid + stereo KLT + grid detector (min-eig, cell {wl.det_cell} px) + "
-                               f"cornerSubPix; {a.seqs} sequences per GPU in lock-step"
+                               f"cornerSubPix; {a.seqs} sequences per GPU in lock-step; one bench step = {a.chunk} "
+                               f"consecutive frames of every sequence ({a.chunk * a.seqs} frames per GPU)"
                                + ("; per-frame ceresPnP pose refinement on the same stream" if a.pnp else ""),
                    "sequences_per_gpu": a.seqs, "keypoints_per_frame": a.kps, "kf_every": a.kf_every,
+                   "frame_batches_per_step": a.chunk, "frames_per_step_per_gpu": a.chunk * a.seqs,
                    "image": [W, H], "parallelism": f"replicas x{world} (one batch of sequences per GPU)"},
-        "gpu_stream_ms_per_step": gpu_ms / a.steps,
-        "host_enqueue_ms_per_step": 1e3 * t_enq / a.steps,
-        "keyframes_per_step": nkf / a.steps,
+        "ms_per_frame_batch": 1e3 * el_max / nbatches,
+        "gpu_stream_ms_per_frame_batch": gpu_ms / nbatches,
+        "host_enqueue_ms_per_frame_batch": 1e3 * t_enq / nbatches,
+        "keyframe_batches_per_frame_batch": nkf / nbatches,
+        "timed_region_s": el_max,
     }
     if ba:
-        ba_den = el_max if not ba_post_region else max(ba.busy_s, 1e-9)
-        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / ba_den, "unit": "iters/s",
-                           "solves_per_sec": ba_solves_all / ba_den, "solves": ba_solves_all,
-                           "measured_over": "timed region (concurrent with the front-end)" if not ba_post_region else
-                                            "one solve finished after the timed region (region shorter than a solve)",
+        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
+                           "solves_per_sec": ba_solves_all / el_max, "solves": ba_solves_all,
+                           "measured_over": "timed region (solves that started and completed inside it, concurrent with the "
+                                            "front-end)",
                            "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
+                           "replaced_fraction": (ba_drop_all / ba_sub_all) if ba_sub_all else 0.0,
                            "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
                                       "parametrisation": "anchored inverse depth (buse_inv_depth: 1)"},
                            "workers_per_gpu": len(ba.ws),
-                           "mode": "Estimator-like native worker threads, each on its own high-priority HIP stream, concurrent with the "
-                                   "front-end (reference: src/estimator.cpp:32-98); robust solve (<=5 it) + L2 (<=10 it)",
+                           "mode": ba.mode,
                            "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
         out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"
 
@@ -395,7 +414,8 @@ def main():
         ctx.kernel_timing(True)
         ctx.kernel_times()
         t1 = time.perf_counter()
-        for _ in range(a.steps):
+        n_instr = max(2 * a.kf_every, min(nbatches, a.instr_batches))
+        for _ in range(n_instr):
             wl.step(a.kf_every)
         ctx.synchronize()
         el_instr = time.perf_counter() - t1
@@ -439,31 +459,48 @@ def main():
                 rl[k]["achieved_Tops"] = ops[k] / avg_s / 1e12
                 rl[k]["valu_frac"] = rl[k]["achieved_Tops"] / VALU_PEAK_TOPS
         dom = max(times, key=lambda k: times[k][0])
-        traffic = None
+        # HBM traffic cannot be counted from inside the process: the figure comes from the committed rocprofv3 PMC passes of
+        # this same command (profiles/pmc_summary.json, FETCH_SIZE / WRITE_SIZE in separate runs) and is labelled as such
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_summary.json (rocprofv3 --pmc passes of this command, not measured in this run)"
             except Exception:
                 traffic = None
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": rl[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": rl[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src,
+                           "limiter": "integer VALU issue, not HBM (profiles/*_klt_counters.md); the HBM fraction is reported "
+                                      "because the contract asks for it, `valu` is the fraction that bounds the kernel",
                            "avg_launch_us": rl[dom]["avg_us"], "alg_bytes_per_launch": rl[dom]["alg_bytes_per_launch"]}
         if "valu_frac" in rl[dom]:
             out["roofline"]["valu"] = {"achieved": rl[dom]["achieved_Tops"], "peak": VALU_PEAK_TOPS, "unit": "Tiop/s",
                                        "frac": rl[dom]["valu_frac"]}
         out["kernels"] = rl
-        out["ms_per_step_instrumented"] = 1e3 * el_instr / a.steps
+        out["ms_per_frame_batch_instrumented"] = 1e3 * el_instr / n_instr
 
     do_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline   # the CPU leg is reported at N = 1 only
     if do_cpu:
-        fps, nfr, sec = cpu_baseline(wl, a.kf_every, a.cpu_seconds)
-        out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"{nfr} frames of one sequence of the same workload ({sec:.1f} s), "
-                                         "oracle/ C port of the OpenCV path, 1 thread; host has "
-                                         f"{os.cpu_count()} logical cores"}
-    if do_cpu and ba:
         from oracle import oracle_py as O
+        native = O.use_native(True)        # same sources at -O3 -march=native for this host
+        try:
+            share = len(os.sched_getaffinity(0))
+        except Exception:
+            share = os.cpu_count() or 1
+        nthr = a.cpu_threads if a.cpu_threads > 0 else max(1, min(share, 16))   # a one-GPU box gives 16 cores
+        fps1, nfr1, sec1 = cpu_baseline(wl, a.kf_every, a.cpu_seconds, threads=1)
+        fpsn, nfrn, secn = cpu_baseline(wl, a.kf_every, a.cpu_seconds, threads=nthr)
+        build = "-O3 -march=native" if native else "-O2 (native build failed)"
+        out["cpu_baseline"] = {"value": fpsn, "unit": "frames/s", "cores": nthr, "kind": "port",
+                               "sample": f"{nfrn} frames of one sequence of the same workload ({secn:.1f} s), oracle/ C port of "
+                                         f"the OpenCV path built {build}, {nthr} threads over the points of every LK call and "
+                                         "the rows / tiles of CLAHE, pyrDown and Scharr (cv::parallel_for_); host has "
+                                         f"{os.cpu_count()} logical cores, {share} usable",
+                               "single_thread": {"value": fps1, "unit": "frames/s", "cores": 1,
+                                                 "sample": f"{nfr1} frames ({sec1:.1f} s), same build, 1 thread"}}
+    if do_cpu and ba:
         Pc = ba.P0.copy()
         t1 = time.perf_counter()
         Rc = O.ba_solve(Pc)

@@ -27,10 +27,29 @@ def build(force=False):
     return so
 
 
-def lib():
+def use_native(on=True):
+    """bench.py's cpu_baseline leg only: switch to a build of the same sources with -O3 -march=native for THIS host
+    (made on demand by `make native`; SURVEY.md 8d asks for the CPU restatement at -O3 -march=native).  The default
+    build stays the checker of the tests (-O2, portable).  Returns True if the native build is in use."""
+    global _LIB
+    so = os.path.join(_HERE, "libov2oracle_native.so")
+    if on:
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        except Exception:
+            return False
+        _LIB = None
+        lib(so)
+        return True
+    _LIB = None
+    lib()
+    return False
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libov2oracle.so")
+        so = path or os.path.join(_HERE, "libov2oracle.so")
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -50,8 +69,14 @@ def lib():
                                            C.c_int, C.c_float, C.c_int, f32p, f32p, u8p, i64p]
         L.ov2o_klt_tracking_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_int, C.c_float, C.c_int, f32p, f32p, u8p, f32p, u8p, i32p]
+        L.ov2o_set_num_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+def set_num_threads(n):
+    """threads over the points of one LK call (OpenCV's parallel_for_); results do not depend on it"""
+    lib().ov2o_set_num_threads(int(n))
 
 
 def _p(a, t):

@@ -63,6 +63,11 @@ void ov2o_calc_optical_flow_pyr_lk(const ov2o_pyr *prev, const ov2o_pyr *next, i
                                    int win, int max_level, int max_iter, float eps,
                                    float min_eig_thr, int *iters);
 
+/* worker threads of the call above (cv::parallel_for_ over the points of one calcOpticalFlowPyrLK call); default 1.
+ * Results do not depend on it.  Used by bench.py for the N-thread CPU baseline. */
+void ov2o_set_num_threads(int n);
+int ov2o_get_num_threads(void);
+
 /* FeatureTracker::fbKltTracking (src/feature_tracker.cpp:35-137). priors_xy in/out, status out. */
 void ov2o_fb_klt_tracking(const ov2o_pyr *prev, const ov2o_pyr *cur, int win, int nlevels,
                           float err_th, float fb_th, int max_iter, float eps, int n,

@@ -20,9 +20,12 @@
  * lanes on x86; the exact sum is the order-independent member of that family and is what lets a
  * 64-lane wave reduction agree bit for bit with this scalar loop.
  */
+#define _GNU_SOURCE
 #include "ov2_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +45,105 @@ static inline int cv_floor(float v) { return (int)floorf(v); }
 static inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 /* ------------------------------------------------------------------------------------------ */
+/* worker pool (OpenCV's parallel_for_): ov2o_set_num_threads(n > 1) keeps n - 1 pthreads, created once and pinned
+ * one per allowed CPU (threads created per call start on the caller's core and are only migrated by the next
+ * load-balancing tick, i.e. after a millisecond-scale call has already finished); the caller works too.  Used by the
+ * loops OpenCV parallelises on this path: CLAHE tiles / rows, pyrDown / Scharr rows, the points of one LK call.  Every
+ * index is computed independently of the others, so results do not depend on n.  For the N-thread CPU baseline of
+ * bench.py; default 1 thread. */
+typedef void (*ov2o_range_fn)(void *ctx, int i0, int i1);
+typedef struct { ov2o_range_fn fn; void *ctx; int i0, i1; } pool_span;
+
+#define POOL_MAX_THREADS 1024
+static struct {
+    pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
+    pthread_t th[POOL_MAX_THREADS];
+    int n_workers;            /* live worker threads (excluding the caller) */
+    int want;                 /* threads requested by ov2o_set_num_threads */
+    int n_spans, next_span, pending, stop;
+    pool_span *spans;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 1, 0, 0, 0, 0, NULL};
+
+static void *pool_worker(void *arg)
+{
+    (void)arg;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (!g_pool.stop && g_pool.next_span >= g_pool.n_spans) pthread_cond_wait(&g_pool.cv_go, &g_pool.mu);
+        if (g_pool.stop) break;
+        const pool_span sp = g_pool.spans[g_pool.next_span++];
+        pthread_mutex_unlock(&g_pool.mu);
+        sp.fn(sp.ctx, sp.i0, sp.i1);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+    }
+    pthread_mutex_unlock(&g_pool.mu);
+    return NULL;
+}
+
+void ov2o_set_num_threads(int n)
+{
+    if (n < 1) n = 1;
+    if (n > POOL_MAX_THREADS) n = POOL_MAX_THREADS;
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.want = n;
+    cpu_set_t allowed;
+    const int have_aff = sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+    int cpu = -1;
+    for (int k = 0; k < g_pool.n_workers && have_aff; ++k)      /* CPUs already handed out */
+        do { cpu = (cpu + 1) % CPU_SETSIZE; } while (!CPU_ISSET(cpu, &allowed));
+    while (g_pool.n_workers < n - 1) {
+        if (pthread_create(&g_pool.th[g_pool.n_workers], NULL, pool_worker, NULL) != 0) break;
+        if (have_aff && CPU_COUNT(&allowed) > 0) {   /* worker k on the (k+1)-th allowed CPU, wrapping */
+            do { cpu = (cpu + 1) % CPU_SETSIZE; } while (!CPU_ISSET(cpu, &allowed));
+            cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpu, &one);
+            (void)pthread_setaffinity_np(g_pool.th[g_pool.n_workers], sizeof(one), &one);
+        }
+        ++g_pool.n_workers;
+    }
+    pthread_mutex_unlock(&g_pool.mu);
+}
+int ov2o_get_num_threads(void) { return g_pool.want; }
+
+/* fn(ctx, i0, i1) over [0, n) in spans of at least `grain` indices */
+static void ov2o_parallel_for(int n, int grain, ov2o_range_fn fn, void *ctx)
+{
+    if (n <= 0) return;
+    int nt = g_pool.want < g_pool.n_workers + 1 ? g_pool.want : g_pool.n_workers + 1;
+    if (grain < 1) grain = 1;
+    if (nt > (n + grain - 1) / grain) nt = (n + grain - 1) / grain;
+    if (nt <= 1) { fn(ctx, 0, n); return; }
+    int ns = nt * 4;          /* a few spans per thread: indices differ in cost */
+    if (ns > (n + grain - 1) / grain) ns = (n + grain - 1) / grain;
+    pool_span *sp = (pool_span *)malloc((size_t)ns * sizeof(pool_span));
+    if (!sp) { fn(ctx, 0, n); return; }
+    for (int t = 0; t < ns; ++t) {
+        sp[t].fn = fn; sp[t].ctx = ctx;
+        sp[t].i0 = (int)((long long)n * t / ns); sp[t].i1 = (int)((long long)n * (t + 1) / ns);
+    }
+    pthread_mutex_lock(&g_pool.mu);
+    if (g_pool.spans) {       /* a parallel region is already running (nested or concurrent caller): stay serial */
+        pthread_mutex_unlock(&g_pool.mu);
+        free(sp);
+        fn(ctx, 0, n);
+        return;
+    }
+    g_pool.spans = sp; g_pool.n_spans = ns; g_pool.next_span = 0; g_pool.pending = ns;
+    pthread_cond_broadcast(&g_pool.cv_go);
+    while (g_pool.next_span < g_pool.n_spans) {      /* the caller works too */
+        const pool_span me = sp[g_pool.next_span++];
+        pthread_mutex_unlock(&g_pool.mu);
+        me.fn(me.ctx, me.i0, me.i1);
+        pthread_mutex_lock(&g_pool.mu);
+        --g_pool.pending;
+    }
+    while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    g_pool.spans = NULL; g_pool.n_spans = 0; g_pool.next_span = 0;
+    pthread_mutex_unlock(&g_pool.mu);
+    free(sp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* pyramid                                                                                      */
 
 static void fill_border_reflect(ov2o_level *L)
@@ -59,10 +161,13 @@ static void fill_border_reflect(ov2o_level *L)
 }
 
 /* pyrDown: [1 4 6 4 1]x[1 4 6 4 1], (sum+128)>>8, REFLECT_101, dst=((w+1)/2,(h+1)/2). */
-static void pyr_down(const ov2o_level *S, ov2o_level *D)
+typedef struct { const ov2o_level *S; ov2o_level *D; } pyr_down_job;
+static void pyr_down_rows(void *ctx, int y0, int y1)
 {
     static const int k[5] = {1, 4, 6, 4, 1};
-    for (int y = 0; y < D->h; ++y) {
+    const ov2o_level *S = ((pyr_down_job *)ctx)->S;
+    ov2o_level *D = ((pyr_down_job *)ctx)->D;
+    for (int y = y0; y < y1; ++y) {
         for (int x = 0; x < D->w; ++x) {
             int acc = 0;
             for (int j = 0; j < 5; ++j) {
@@ -76,13 +181,19 @@ static void pyr_down(const ov2o_level *S, ov2o_level *D)
         }
     }
 }
+static void pyr_down(const ov2o_level *S, ov2o_level *D)
+{
+    pyr_down_job j = {S, D};
+    ov2o_parallel_for(D->h, 8, pyr_down_rows, &j);
+}
 
 /* calcSharrDeriv: Ix = t0[x+1]-t0[x-1], t0 = 3(r-1 + r+1) + 10 r0 ; Iy = 3(t1[x-1]+t1[x+1]) + 10 t1[x],
  * t1 = r+1 - r-1 ; rows/cols REFLECT_101 ; padding of the gradient plane stays zero. */
-static void scharr(ov2o_level *L)
+static void scharr_rows(void *ctx, int y0, int y1)
 {
+    ov2o_level *L = (ov2o_level *)ctx;
     const int p = L->pad, w = L->w, h = L->h, s = L->stride;
-    for (int y = 0; y < h; ++y) {
+    for (int y = y0; y < y1; ++y) {
         const uint8_t *r0 = L->img + (size_t)(reflect101(y - 1, h) + p) * s + p;
         const uint8_t *r1 = L->img + (size_t)(y + p) * s + p;
         const uint8_t *r2 = L->img + (size_t)(reflect101(y + 1, h) + p) * s + p;
@@ -99,6 +210,7 @@ static void scharr(ov2o_level *L)
         }
     }
 }
+static void scharr(ov2o_level *L) { ov2o_parallel_for(L->h, 8, scharr_rows, L); }
 
 static int level_alloc(ov2o_level *L, int w, int h, int pad)
 {
@@ -152,6 +264,82 @@ const int16_t *ov2o_pyr_grad(const ov2o_pyr *p, int l) { return p->lv[l].grad; }
 /* ------------------------------------------------------------------------------------------ */
 /* CLAHE (8-bit, one channel)                                                                   */
 
+typedef struct {
+    const uint8_t *src; uint8_t *dst, *lut;
+    int w, h, stride, dst_stride, tiles_x, tiles_y, tw, th, clip_limit;
+    float lut_scale;
+} clahe_job;
+
+/* CLAHE_CalcLut_Body: clipped histogram + LUT of tiles [t0, t1) (tile index = ty * tiles_x + tx) */
+static void clahe_tiles(void *ctx, int t0, int t1)
+{
+    const clahe_job *J = (const clahe_job *)ctx;
+    const int hist_size = 256, w = J->w, h = J->h, tw = J->tw, th = J->th;
+    for (int t = t0; t < t1; ++t) {
+        const int ty = t / J->tiles_x, tx = t - ty * J->tiles_x;
+        int hist[256];
+        memset(hist, 0, sizeof(hist));
+        for (int y = ty * th; y < (ty + 1) * th; ++y) {
+            /* copyMakeBorder(src, ext, 0, eh-h, 0, ew-w, REFLECT_101): ext(y,x)=src(refl(y),refl(x)) */
+            const uint8_t *row = J->src + (size_t)reflect101(y, h) * J->stride;
+            for (int x = tx * tw; x < (tx + 1) * tw; ++x) hist[row[reflect101(x, w)]]++;
+        }
+        if (J->clip_limit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < hist_size; ++i)
+                if (hist[i] > J->clip_limit) { clipped += hist[i] - J->clip_limit; hist[i] = J->clip_limit; }
+            const int batch = clipped / hist_size;
+            int residual = clipped - batch * hist_size;
+            for (int i = 0; i < hist_size; ++i) hist[i] += batch;
+            if (residual != 0) {
+                int step = hist_size / residual;
+                if (step < 1) step = 1;
+                for (int i = 0; i < hist_size && residual > 0; i += step, residual--) hist[i]++;
+            }
+        }
+        uint8_t *tl = J->lut + (size_t)t * hist_size;
+        int sum = 0;
+        for (int i = 0; i < hist_size; ++i) {
+            sum += hist[i];
+            tl[i] = sat_u8(cv_round((float)sum * J->lut_scale));
+        }
+    }
+}
+
+/* CLAHE_Interpolation_Body: rows [y0, y1) */
+static void clahe_rows(void *ctx, int y0, int y1)
+{
+    const clahe_job *J = (const clahe_job *)ctx;
+    const int hist_size = 256, w = J->w, tiles_x = J->tiles_x, tiles_y = J->tiles_y;
+    const float inv_tw = 1.0f / (float)J->tw;
+    const float inv_th = 1.0f / (float)J->th;
+    for (int y = y0; y < y1; ++y) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = cv_floor(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1;
+        const float ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > tiles_y - 1) ty2 = tiles_y - 1;
+        const uint8_t *p1 = J->lut + (size_t)ty1 * tiles_x * hist_size;
+        const uint8_t *p2 = J->lut + (size_t)ty2 * tiles_x * hist_size;
+        for (int x = 0; x < w; ++x) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = cv_floor(txf);
+            int tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1;
+            const float xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
+            const int v = J->src[(size_t)y * J->stride + x];
+            const int i1 = tx1 * hist_size + v, i2 = tx2 * hist_size + v;
+            const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 +
+                              ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
+            J->dst[(size_t)y * J->dst_stride + x] = sat_u8(cv_round(res));
+        }
+    }
+}
+
 void ov2o_clahe(const uint8_t *src, int w, int h, int stride, float clipf, int tiles_x, int tiles_y,
                 uint8_t *dst, int dst_stride)
 {
@@ -164,7 +352,6 @@ void ov2o_clahe(const uint8_t *src, int w, int h, int stride, float clipf, int t
     }
     const int tw = ew / tiles_x, th = eh / tiles_y;
     const int tile_total = tw * th;
-    const float lut_scale = (float)(hist_size - 1) / (float)tile_total;
     const double clip = (double)clipf;
     int clip_limit = 0;
     if (clip > 0.0) {
@@ -172,65 +359,10 @@ void ov2o_clahe(const uint8_t *src, int w, int h, int stride, float clipf, int t
         if (clip_limit < 1) clip_limit = 1;
     }
     uint8_t *lut = (uint8_t *)malloc((size_t)tiles_x * tiles_y * hist_size);
-
-    for (int ty = 0; ty < tiles_y; ++ty) {
-        for (int tx = 0; tx < tiles_x; ++tx) {
-            int hist[256];
-            memset(hist, 0, sizeof(hist));
-            for (int y = ty * th; y < (ty + 1) * th; ++y) {
-                /* copyMakeBorder(src, ext, 0, eh-h, 0, ew-w, REFLECT_101): ext(y,x)=src(refl(y),refl(x)) */
-                const uint8_t *row = src + (size_t)reflect101(y, h) * stride;
-                for (int x = tx * tw; x < (tx + 1) * tw; ++x) hist[row[reflect101(x, w)]]++;
-            }
-            if (clip_limit > 0) {
-                int clipped = 0;
-                for (int i = 0; i < hist_size; ++i)
-                    if (hist[i] > clip_limit) { clipped += hist[i] - clip_limit; hist[i] = clip_limit; }
-                const int batch = clipped / hist_size;
-                int residual = clipped - batch * hist_size;
-                for (int i = 0; i < hist_size; ++i) hist[i] += batch;
-                if (residual != 0) {
-                    int step = hist_size / residual;
-                    if (step < 1) step = 1;
-                    for (int i = 0; i < hist_size && residual > 0; i += step, residual--) hist[i]++;
-                }
-            }
-            uint8_t *tl = lut + (size_t)(ty * tiles_x + tx) * hist_size;
-            int sum = 0;
-            for (int i = 0; i < hist_size; ++i) {
-                sum += hist[i];
-                tl[i] = sat_u8(cv_round((float)sum * lut_scale));
-            }
-        }
-    }
-
-    const float inv_tw = 1.0f / (float)tw;
-    const float inv_th = 1.0f / (float)th;
-    for (int y = 0; y < h; ++y) {
-        const float tyf = (float)y * inv_th - 0.5f;
-        int ty1 = cv_floor(tyf);
-        int ty2 = ty1 + 1;
-        const float ya = tyf - (float)ty1;
-        const float ya1 = 1.0f - ya;
-        if (ty1 < 0) ty1 = 0;
-        if (ty2 > tiles_y - 1) ty2 = tiles_y - 1;
-        const uint8_t *p1 = lut + (size_t)ty1 * tiles_x * hist_size;
-        const uint8_t *p2 = lut + (size_t)ty2 * tiles_x * hist_size;
-        for (int x = 0; x < w; ++x) {
-            const float txf = (float)x * inv_tw - 0.5f;
-            int tx1 = cv_floor(txf);
-            int tx2 = tx1 + 1;
-            const float xa = txf - (float)tx1;
-            const float xa1 = 1.0f - xa;
-            if (tx1 < 0) tx1 = 0;
-            if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
-            const int v = src[(size_t)y * stride + x];
-            const int i1 = tx1 * hist_size + v, i2 = tx2 * hist_size + v;
-            const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 +
-                              ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
-            dst[(size_t)y * dst_stride + x] = sat_u8(cv_round(res));
-        }
-    }
+    clahe_job J = {src, dst, lut, w, h, stride, dst_stride, tiles_x, tiles_y, tw, th, clip_limit,
+                   (float)(hist_size - 1) / (float)tile_total};
+    ov2o_parallel_for(tiles_x * tiles_y, 1, clahe_tiles, &J);
+    ov2o_parallel_for(h, 8, clahe_rows, &J);
     free(lut);
 }
 
@@ -340,6 +472,28 @@ static int lk_level(const ov2o_level *I, const ov2o_level *J, int level, int max
     return j;
 }
 
+/* cv::parallel_for_ of calcOpticalFlowPyrLK: OpenCV splits the POINTS of one call over its worker pool
+ * (LKTrackerInvoker is the parallel body); same here through ov2o_parallel_for. */
+typedef struct {
+    const ov2o_pyr *prev, *next;
+    int win, max_level, max_iter;
+    const float *prev_xy; float *next_xy; uint8_t *status; float *err; int *iters;
+    double eps2; float min_eig_thr;
+} lk_job;
+
+static void lk_points(void *ctx, int i0, int i1)
+{
+    const lk_job *s = (const lk_job *)ctx;
+    for (int i = i0; i < i1; ++i) {
+        s->status[i] = 1; s->err[i] = 0.f;
+        for (int l = s->max_level; l >= 0; --l) {
+            const int it = lk_level(&s->prev->lv[l], &s->next->lv[l], l, s->max_level, s->prev_xy + 2 * i, s->next_xy + 2 * i,
+                                    s->status + i, s->err + i, s->win, s->max_iter, s->eps2, s->min_eig_thr);
+            if (s->iters) s->iters[(size_t)i * (s->max_level + 1) + l] = it;
+        }
+    }
+}
+
 void ov2o_calc_optical_flow_pyr_lk(const ov2o_pyr *prev, const ov2o_pyr *next, int n,
                                    const float *prev_xy, float *next_xy, uint8_t *status, float *err,
                                    int win, int max_level, int max_iter, float eps, float min_eig_thr,
@@ -351,15 +505,9 @@ void ov2o_calc_optical_flow_pyr_lk(const ov2o_pyr *prev, const ov2o_pyr *next, i
     if (max_iter < 0) max_iter = 0;
     if (max_iter > 100) max_iter = 100;
     double e = eps; if (e < 0.) e = 0.; if (e > 10.) e = 10.;
-    const double eps2 = e * e;   /* criteria.epsilon *= criteria.epsilon (double) */
-    for (int i = 0; i < n; ++i) {
-        status[i] = 1; err[i] = 0.f;
-        for (int l = max_level; l >= 0; --l) {
-            const int it = lk_level(&prev->lv[l], &next->lv[l], l, max_level, prev_xy + 2 * i, next_xy + 2 * i,
-                                    status + i, err + i, win, max_iter, eps2, min_eig_thr);
-            if (iters) iters[(size_t)i * (max_level + 1) + l] = it;
-        }
-    }
+    lk_job job = {prev, next, win, max_level, max_iter, prev_xy, next_xy, status, err, iters, e * e /* epsilon *= epsilon (double) */,
+                  min_eig_thr};
+    ov2o_parallel_for(n, 16, lk_points, &job);
 }
 
 /* ------------------------------------------------------------------------------------------ */
