@@ -131,6 +131,43 @@ ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const o
                                       const int32_t *d_img_idx, float *d_out_xy, uint8_t *d_out_status,
                                       int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* 2n work words: [0,n) stage 1, [n,2n) stage 2; may be NULL */);
 
+/* ---- stereo matching (keyframe rate) -------------------------------------------------------------- */
+/* Replaces FeatureTracker::getLineMinSAD(iml, imr, pt, nwinsize, xprior, l1err, bgoleft) (include/feature_tracker.hpp:50,
+ * src/feature_tracker.cpp:140-213) as MapManager::stereoMatching calls it for rectified rigs (src/map_manager.cpp:425-435):
+ * iml / imr = level `level` of the two pyramids (the reference passes vleftpyr.at(2 * nklt_pyr_lvl)), pts_xy = the
+ * keypoints scaled to that level (kp.px_ * 2^-level), nwinsize = 7, go_left = 1.  Per point: cv::getRectSubPix patches
+ * (8U, 16-bit fixed-point bilinear, replicated border) of the left point and of every integer step along the row of the
+ * right image, xprior = the step with the smallest mean absolute difference (first minimum; -1 if the window does not fit
+ * or no step beats 255), l1err = that mean (may be NULL).  Points outside the level image give xprior = -1.
+ * nwinsize odd, <= 15.  Host pointers; the _dev form takes device pointers (+ optional image index per point), is
+ * asynchronous and synchronises nothing. */
+ov2_status ov2_line_min_sad(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int level, int nwinsize, int go_left,
+                            int n, const float *pts_xy, float *xprior, float *l1err);
+ov2_status ov2_line_min_sad_dev(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int level, int nwinsize,
+                                int go_left, int n, const float *d_pts_xy, const int32_t *d_img_idx, float *d_xprior,
+                                float *d_l1err);
+
+/* Replaces the tracking + gating part of MapManager::stereoMatching(frame, vleftpyr, vrightpyr) (include/map_manager.hpp:96,
+ * src/map_manager.cpp:493-604): keypoints with has_prior[i] are tracked left -> right on 2 levels from prior_xy[i]
+ * (:497-541; priors from the 3D point or the neighbours' depth), their failures are re-queued on the full pyramid with the
+ * UPDATED prior (:533-537, no 33 % rule here), the others on the full pyramid from prior_xy[i] (:544-580: kp.px_ or the
+ * SAD prior); then the epipolar gate (:583-604): rectified != 0: |lunpx.y - r.y| <= 2 and the right point is moved onto
+ * the left row (:592); otherwise MultiViewGeometry::computeSampsonDistance(F_rl, lunpx, runpx) <= 2
+ * (src/multi_view_geometry.cpp:798-821; F_rl row-major = Frame::Frl_, src/frame.cpp:62).  Cameras without distortion
+ * (Dcv_.empty(), src/camera_calibration.cpp:317-319: undistortImagePoint is the identity); lunpx_xy = the left undistorted
+ * pixels (NULL = kps_xy).  out_status[i] = 1 where the reference reaches Frame::updateKeypointStereo(id, out_rxy[i]).
+ * Host pointers; the _dev form takes device pointers (F_rl stays a host pointer), is asynchronous, d_iters as in
+ * ov2_klt_tracking_frame_dev. */
+ov2_status ov2_stereo_matching(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
+                               int max_iter, float eps, float err_th, float fb_th, int n, const float *kps_xy,
+                               const float *prior_xy, const uint8_t *has_prior, const float *lunpx_xy, int rectified,
+                               const double *F_rl, float *out_rxy, uint8_t *out_status);
+ov2_status ov2_stereo_matching_dev(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
+                                   int max_iter, float eps, float err_th, float fb_th, int n, const float *d_kps_xy,
+                                   const float *d_prior_xy, const uint8_t *d_has_prior, const int32_t *d_img_idx,
+                                   const float *d_lunpx_xy, int rectified, const double *F_rl, float *d_out_rxy,
+                                   uint8_t *d_out_status, uint32_t *d_iters);
+
 /* ---- detectors (keyframe rate) -------------------------------------------------------------------- */
 enum { OV2_DETECT_FAST = 0, OV2_DETECT_MINEIG = 1 };
 /* Replaces FeatureExtractor::detectGridFAST (mode OV2_DETECT_FAST, `use_fast: 1` configs, src/feature_extractor.cpp:443-570)

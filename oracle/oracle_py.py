@@ -380,3 +380,70 @@ def min_eig_cell(img, x0, y0, cell):
 def fast_score(img, x, y, threshold):
     img = np.ascontiguousarray(img, np.uint8)
     return _det_lib().ov2o_fast_score(_p(img, u8p), img.shape[1], x, y, threshold)
+
+
+# ---------------------------------------------------------------------------------------------------
+# stereo matching pieces (ov2_oracle_stereo.c)
+
+def _st_lib():
+    L = lib()
+    if not getattr(L, "_st_bound", False):
+        L.ov2o_get_rect_sub_pix_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, u8p]
+        L.ov2o_line_min_sad.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
+        L.ov2o_line_min_sad_img.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                            f32p, f32p]
+        L.ov2o_sampson_distance.argtypes = [f64p, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.ov2o_sampson_distance.restype = C.c_float
+        L.ov2o_stereo_matching.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                           C.c_int, f32p, f32p, u8p, f32p, C.c_int, f64p, f32p, u8p]
+        L._st_bound = True
+    return L
+
+
+def get_rect_sub_pix_u8(img, ww, wh, cx, cy):
+    """cv::getRectSubPix 8U -> 8U"""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((wh, ww), np.uint8)
+    _st_lib().ov2o_get_rect_sub_pix_u8(_p(img, u8p), w, h, w, ww, wh, float(cx), float(cy), _p(out, u8p))
+    return out
+
+
+def line_min_sad(left, right, level, pts_xy, nwinsize=7, go_left=True):
+    """FeatureTracker::getLineMinSAD on level `level` of two oracle pyramids. returns (xprior, l1err)."""
+    pts = np.ascontiguousarray(pts_xy, np.float32).reshape(-1, 2)
+    n = len(pts)
+    xp, er = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    _st_lib().ov2o_line_min_sad(left._h, right._h, level, nwinsize, int(bool(go_left)), n, _p(pts, f32p), _p(xp, f32p),
+                                _p(er, f32p))
+    return xp, er
+
+
+def line_min_sad_img(iml, imr, x, y, nwinsize=7, go_left=True):
+    iml, imr = np.ascontiguousarray(iml, np.uint8), np.ascontiguousarray(imr, np.uint8)
+    h, w = iml.shape
+    xp, er = C.c_float(0), C.c_float(0)
+    _st_lib().ov2o_line_min_sad_img(_p(iml, u8p), _p(imr, u8p), w, h, w, float(x), float(y), nwinsize, int(bool(go_left)),
+                                    C.byref(xp), C.byref(er))
+    return xp.value, er.value
+
+
+def sampson_distance(F, l, r):
+    F = np.ascontiguousarray(F, np.float64).reshape(9)
+    return float(_st_lib().ov2o_sampson_distance(_p(F, f64p), float(l[0]), float(l[1]), float(r[0]), float(r[1])))
+
+
+def stereo_matching(left, right, kps_xy, prior_xy, has_prior, win=9, nlevels=3, err_th=30.0, fb_th=0.5, max_iter=30,
+                    eps=0.01, lunpx=None, rectified=True, F_rl=None):
+    """tracking + gate of MapManager::stereoMatching on flat arrays. returns (right pixels, status)."""
+    kps = np.ascontiguousarray(kps_xy, np.float32).reshape(-1, 2)
+    pri = np.ascontiguousarray(prior_xy, np.float32).reshape(-1, 2)
+    hp = np.ascontiguousarray(has_prior, np.uint8)
+    n = len(kps)
+    lu = None if lunpx is None else np.ascontiguousarray(lunpx, np.float32).reshape(-1, 2)
+    F = np.zeros(9) if F_rl is None else np.ascontiguousarray(F_rl, np.float64).reshape(9)
+    out, st = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
+    _st_lib().ov2o_stereo_matching(left._h, right._h, win, nlevels, err_th, fb_th, max_iter, eps, n, _p(kps, f32p),
+                                   _p(pri, f32p), _p(hp, u8p), None if lu is None else _p(lu, f32p), int(bool(rectified)),
+                                   _p(F, f64p), _p(out, f32p), _p(st, u8p))
+    return out, st.astype(bool)

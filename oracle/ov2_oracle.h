@@ -111,6 +111,22 @@ int ov2o_triangulate_pairs(int n, int method, int G, const double *T_ab, const d
                            const double *K_a, const double *K_b, float max_reproj_err, double *pt_a, double *wpt,
                            double *parallax, unsigned char *status);
 
+/* ---- stereo matching pieces (ov2_oracle_stereo.c) ------------------------------------------------- */
+/* cv::getRectSubPix 8U -> 8U (imgproc/samplers.cpp), dst = ww x wh tight */
+void ov2o_get_rect_sub_pix_u8(const uint8_t *src, int w, int h, int stride, int ww, int wh, float cx, float cy, uint8_t *dst);
+/* FeatureTracker::getLineMinSAD (src/feature_tracker.cpp:140-213) on two same-size images / on a pyramid level */
+void ov2o_line_min_sad_img(const uint8_t *iml, const uint8_t *imr, int w, int h, int stride, float x, float y, int nwinsize,
+                           int go_left, float *xprior, float *l1err);
+void ov2o_line_min_sad(const ov2o_pyr *left, const ov2o_pyr *right, int level, int nwinsize, int go_left, int n,
+                       const float *pts_xy, float *xprior, float *l1err);
+/* MultiViewGeometry::computeSampsonDistance (src/multi_view_geometry.cpp:798-821), F row-major */
+float ov2o_sampson_distance(const double F[9], float lx, float ly, float rx, float ry);
+/* tracking + epipolar gate of MapManager::stereoMatching on flat arrays (src/map_manager.cpp:493-604) */
+void ov2o_stereo_matching(const ov2o_pyr *left, const ov2o_pyr *right, int win, int nlevels_full, float err_th, float fb_th,
+                          int max_iter, float eps, int n, const float *kps_xy, const float *prior_xy,
+                          const uint8_t *has_prior, const float *lunpx_xy, int rectified, const double F_rl[9],
+                          float *out_rxy, uint8_t *out_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,8 @@ struct klt_params {
     float err_th;    // nklt_err
     double fb_th;    // fmax_fbklt_dist promoted to double for the cv::norm comparison
     float min_eig_thr;
+    int rule33;      // 1: VisualFrontEnd::kltTracking's "< 33 % good => drop every re-queued prior" (src/visual_front_end.cpp:228-233);
+                     // 0: MapManager::stereoMatching re-queues the failures with the updated prior, no such rule (src/map_manager.cpp:533-537)
 };
 
 #define W_BITS 14
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     constexpr int KLT_KPW = 64 / KLT_GL;
     const int sub = threadIdx.x & (KLT_GL - 1), grp = (int)(threadIdx.x / KLT_GL);
     // the 33 % flag is per image and must be raised even when no failure of that image is re-tracked
-    if (p3p_req) {
+    if (p3p_req && P.rule33) {
         for (int b = blockIdx.x * KLT_KPW + grp; b < batch; b += gridDim.x * KLT_KPW) {
             int n3 = 0, good = 0;
             for (int q = 0; q < 64 / KLT_GL; ++q) {
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
         n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
     }
     n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
-    const bool drop = n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
+    const bool drop = P.rule33 && n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
     const float2 kp = kps[i];
     float2 pr = drop ? kp : out_xy[i];
     unsigned work = 0;
@@ -683,6 +685,7 @@ ov2_status make_params(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int 
     P->err_th = err_th;
     P->fb_th = (double)fb_th;
     P->min_eig_thr = 1e-4f;  // calcOpticalFlowPyrLK default minEigThreshold, not passed by the reference
+    P->rule33 = 1;
     return OV2_OK;
 }
 
@@ -753,6 +756,16 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
                                                  const uint8_t *d_has_prior, const int32_t *d_img_idx, float *d_out_xy,
                                                  uint8_t *d_out_status, int32_t *d_p3p_req, uint32_t *d_iters)
 {
+    return ov2_klt_two_stage_dev(c, prev, cur, win, nlevels_full, max_iter, eps, err_th, fb_th, n, d_kps, d_prior, d_has_prior,
+                                 d_img_idx, d_out_xy, d_out_status, d_p3p_req, d_iters, 1);
+}
+
+// the two-stage batching shared by VisualFrontEnd::kltTracking (rule33 = 1) and MapManager::stereoMatching (rule33 = 0)
+ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels_full, int max_iter,
+                                 float eps, float err_th, float fb_th, int n, const float *d_kps, const float *d_prior,
+                                 const uint8_t *d_has_prior, const int32_t *d_img_idx, float *d_out_xy,
+                                 uint8_t *d_out_status, int32_t *d_p3p_req, uint32_t *d_iters, int rule33)
+{
     if (!c) return OV2_ERR_INVALID;
     if (n == 0) return OV2_OK;
     if (n < 0 || !d_kps || !d_prior || !d_has_prior || !d_out_xy || !d_out_status)
@@ -760,6 +773,7 @@ extern "C" ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *c, const ov2_pyr *prev
     klt_params P;
     ov2_status s = make_params(c, prev, cur, win, nlevels_full, max_iter, eps, err_th, fb_th, &P);
     if (s != OV2_OK) return s;
+    P.rule33 = rule33 ? 1 : 0;
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
     const int B = prev->buf->batch;

@@ -123,6 +123,11 @@ void ov2_ktime_begin(ov2_ctx *c, int id, hipStream_t st);
 void ov2_ktime_end(ov2_ctx *c, hipStream_t st);
 // make the ctx main stream wait for the build of `p` (enqueued on the pyramid stream)
 ov2_status ov2_pyr_wait_ready(ov2_ctx *c, const ov2_pyr *p);
+// klt.hip: two-stage forward-backward tracking (see ov2_klt_tracking_frame_dev); rule33 = 0 for stereo matching
+ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels_full, int max_iter,
+                                 float eps, float err_th, float fb_th, int n, const float *d_kps, const float *d_prior,
+                                 const uint8_t *d_has_prior, const int32_t *d_img_idx, float *d_out_xy,
+                                 uint8_t *d_out_status, int32_t *d_p3p_req, uint32_t *d_iters, int rule33);
 #define OV2_LAUNCH_ON(ctx, id, st, ...)     \
     do {                                    \
         if ((ctx)->ktime_on) ov2_ktime_begin((ctx), (id), (st)); \

@@ -260,6 +260,54 @@ class FeatureTracker:
         return d_o.get(), d_s.get().astype(bool), bool(d_r.get()[0])
 
 
+    def getLineMinSAD(self, vleftpyr, vrightpyr, level, pts_xy, nwinsize=7, bgoleft=True):
+        """FeatureTracker::getLineMinSAD (src/feature_tracker.cpp:140-213) for n points of pyramid level `level`
+        (coordinates of that level).  returns (xprior (n,) f32, l1err (n,) f32)."""
+        ctx = self.ctx
+        pts = np.ascontiguousarray(pts_xy, np.float32).reshape(-1, 2)
+        n = len(pts)
+        xp, er = np.full(n, -1.0, np.float32), np.zeros(n, np.float32)
+        _check(ctx.h, ctx.lib.ov2_line_min_sad(ctx.h, vleftpyr.h, vrightpyr.h, int(level), int(nwinsize), int(bool(bgoleft)), n,
+                                               pts.ctypes.data_as(C.c_void_p), xp.ctypes.data_as(C.c_void_p),
+                                               er.ctypes.data_as(C.c_void_p)))
+        return xp, er
+
+    def stereoMatching(self, vleftpyr, vrightpyr, nwinsize, nklt_pyr_lvl, ferr, fmax_fbklt_dist, vkps, vpriors, has_prior,
+                       lunpx=None, rectified=True, F_rl=None):
+        """tracking + epipolar gate of MapManager::stereoMatching (src/map_manager.cpp:493-604) on flat arrays.
+        returns (right pixels (n,2) f32, status (n,) bool)."""
+        ctx = self.ctx
+        kps = np.ascontiguousarray(vkps, np.float32).reshape(-1, 2)
+        pri = np.ascontiguousarray(vpriors, np.float32).reshape(-1, 2)
+        hp = np.ascontiguousarray(has_prior, np.uint8)
+        n = len(kps)
+        lu = None if lunpx is None else np.ascontiguousarray(lunpx, np.float32).reshape(-1, 2)
+        F = None if F_rl is None else np.ascontiguousarray(F_rl, np.float64).reshape(9)
+        out, st = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
+        _check(ctx.h, ctx.lib.ov2_stereo_matching(ctx.h, vleftpyr.h, vrightpyr.h, nwinsize, nklt_pyr_lvl, self.nmax_iter,
+                                                  self.fmax_px_precision, ferr, fmax_fbklt_dist, n,
+                                                  kps.ctypes.data_as(C.c_void_p), pri.ctypes.data_as(C.c_void_p),
+                                                  hp.ctypes.data_as(C.c_void_p),
+                                                  None if lu is None else lu.ctypes.data_as(C.c_void_p), int(bool(rectified)),
+                                                  None if F is None else F.ctypes.data_as(C.c_void_p),
+                                                  out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
+        return out, st.astype(bool)
+
+    def stereoMatching_dev(self, vleftpyr, vrightpyr, nwinsize, nklt_pyr_lvl, ferr, fmax_fbklt_dist, d_kps, d_prior,
+                           d_has_prior, d_out_rxy, d_out_status, n, d_img_idx=None, d_lunpx=None, rectified=True, F_rl=None,
+                           d_iters=None):
+        """device-resident asynchronous form (ov2_stereo_matching_dev)"""
+        ctx = self.ctx
+        ptr = lambda a: None if a is None else (a.ptr if isinstance(a, DeviceArray) else a)
+        F = None if F_rl is None else np.ascontiguousarray(F_rl, np.float64).reshape(9)
+        _check(ctx.h, ctx.lib.ov2_stereo_matching_dev(ctx.h, vleftpyr.h, vrightpyr.h, nwinsize, nklt_pyr_lvl, self.nmax_iter,
+                                                      self.fmax_px_precision, ferr, fmax_fbklt_dist, n, ptr(d_kps),
+                                                      ptr(d_prior), ptr(d_has_prior), ptr(d_img_idx), ptr(d_lunpx),
+                                                      int(bool(rectified)),
+                                                      None if F is None else F.ctypes.data_as(C.c_void_p), ptr(d_out_rxy),
+                                                      ptr(d_out_status), ptr(d_iters)))
+
+
 class FeatureExtractor:
     """mirror of the reference FeatureExtractor for the two grid detectors (include/feature_extractor.hpp:37-46):
     keeps the adaptive thresholds dmaxquality_ / nfast_th_ across calls exactly as the reference object does."""

@@ -1,0 +1,122 @@
+"""GPU parity tests (through the C ABI) of the left -> right stereo matching path (SURVEY.md 8a row a4,
+MapManager::stereoMatching src/map_manager.cpp:367-611): fbKltTracking / the two-stage batching on (left pyramid,
+right pyramid) with 8-40 px disparities, the SAD line search, the epipolar gate with the row snap / the Sampson distance.
+Bar: status identical, positions bit-identical (float32 bit patterns), SAD priors bit-identical."""
+import numpy as np
+import pytest
+
+from ov2slam_amd import frontend as fe, synth
+
+pytestmark = pytest.mark.gpu
+
+K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]])
+TX = np.array([[0, 0, 0], [0, 0, 0.110074], [0, -0.110074, 0]])
+F_RL = np.linalg.inv(K).T @ TX @ np.linalg.inv(K)      # pure x baseline (the synthetic pair is rectified-like)
+
+
+@pytest.fixture(scope="module")
+def pair(ctx, oracle, stream):
+    L, R = stream.left(2), stream.right(2)
+    gl, gr = fe.preprocess_image(ctx, L), fe.preprocess_image(ctx, R)
+    ol, orr = oracle.Pyramid(oracle.clahe(L)), oracle.Pyramid(oracle.clahe(R))
+    return gl, gr, ol, orr
+
+
+@pytest.mark.parametrize("n", [2048, 4000])
+def test_fb_klt_left_to_right(ctx, oracle, stream, pair, n):
+    """FeatureTracker::fbKltTracking on (left, right): priors = true disparity + N(0, 1 px), 2 levels and full pyramid"""
+    gl, gr, ol, orr = pair
+    kps = synth.grid_keypoints(n, seed=31)
+    gt = stream.stereo_gt(kps).astype(np.float32)
+    pri = (gt + np.random.default_rng(5).normal(0, 1.0, gt.shape)).astype(np.float32)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for nl, p in ((1, pri), (3, pri), (3, kps)):
+        out, st = trk.fbKltTracking(gl, gr, 9, nl, 30.0, 0.5, kps, p)
+        eo, es, _ = oracle.fb_klt_tracking(ol, orr, kps, p, 9, nl, 30.0, 0.5, 30, 0.01)
+        assert np.array_equal(st, es.astype(bool))
+        assert np.array_equal(out.view(np.uint32), eo.view(np.uint32))
+    out, st = trk.fbKltTracking(gl, gr, 9, 1, 30.0, 0.5, kps, pri)
+    assert st.mean() > 0.9 and np.median(np.abs(out[st] - gt[st])) < 0.1
+
+
+@pytest.mark.parametrize("n", [2048, 4000])
+@pytest.mark.parametrize("rectified", [True, False])
+def test_stereo_matching_flat(ctx, oracle, stream, pair, n, rectified):
+    """ov2_stereo_matching: 2-level call on the keypoints with a prior, failures re-queued with the updated prior, the rest
+    on the full pyramid, then the gate (row check + snap | Sampson)"""
+    gl, gr, ol, orr = pair
+    kps = synth.grid_keypoints(n, seed=33)
+    gt = stream.stereo_gt(kps).astype(np.float32)
+    pri, has = synth.make_priors(kps, gt, seed=8)
+    # some hopeless priors so that the re-queue branch (:533-537) and the gate both have work
+    rng = np.random.default_rng(2)
+    bad = rng.uniform(size=n) < 0.08
+    pri[bad & (has > 0)] += rng.normal(0, 25.0, (int((bad & (has > 0)).sum()), 2)).astype(np.float32)
+    lunpx = kps.copy()
+    lunpx[::7, 1] += np.float32(1.9)      # undistorted left pixels that differ from the raw ones (gate input only)
+    lunpx[::11, 1] += np.float32(2.3)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    out, st = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, lunpx=lunpx, rectified=rectified, F_rl=F_RL)
+    eo, es = oracle.stereo_matching(ol, orr, kps, pri, has, 9, 3, 30.0, 0.5, 30, 0.01, lunpx=lunpx, rectified=rectified,
+                                    F_rl=F_RL)
+    assert np.array_equal(st, es)
+    assert np.array_equal(out.view(np.uint32), eo.view(np.uint32))
+    assert 0.5 < st.mean() < 1.0          # the gate removes some
+    if rectified:
+        assert np.array_equal(out[st][:, 1], lunpx[st][:, 1])
+    # lunpx = NULL path
+    out2, st2 = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, rectified=rectified, F_rl=F_RL)
+    eo2, es2 = oracle.stereo_matching(ol, orr, kps, pri, has, 9, 3, 30.0, 0.5, 30, 0.01, rectified=rectified, F_rl=F_RL)
+    assert np.array_equal(st2, es2) and np.array_equal(out2.view(np.uint32), eo2.view(np.uint32))
+
+
+def test_stereo_matching_batched_dev(ctx, oracle, stream):
+    """device-resident form on a batch of 3 stereo pairs with an image index per keypoint"""
+    B, n = 3, 700
+    il, ir = fe.Images(ctx, B, synth.IMG_W, synth.IMG_H), fe.Images(ctx, B, synth.IMG_W, synth.IMG_H)
+    Ls, Rs = [stream.left(3 * b) for b in range(B)], [stream.right(3 * b) for b in range(B)]
+    for b in range(B):
+        il.upload(b, Ls[b]); ir.upload(b, Rs[b])
+    gl, gr = fe.preprocess_images(ctx, il), fe.preprocess_images(ctx, ir)
+    kps = [synth.grid_keypoints(n, seed=40 + b) for b in range(B)]
+    pr = [synth.make_priors(k, stream.stereo_gt(k).astype(np.float32), seed=50 + b) for b, k in enumerate(kps)]
+    d_k, d_p = ctx.to_device(np.concatenate(kps)), ctx.to_device(np.concatenate([p[0] for p in pr]))
+    d_h = ctx.to_device(np.concatenate([p[1] for p in pr]))
+    d_i = ctx.to_device(np.repeat(np.arange(B, dtype=np.int32), n))
+    d_o, d_s = ctx.empty((B * n, 2), np.float32), ctx.empty((B * n,), np.uint8)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    trk.stereoMatching_dev(gl, gr, 9, 3, 30.0, 0.5, d_k, d_p, d_h, d_o, d_s, B * n, d_i, None, True, None)
+    ctx.synchronize()
+    out, st = d_o.get(), d_s.get().astype(bool)
+    for b in range(B):
+        ol, orr = oracle.Pyramid(oracle.clahe(Ls[b])), oracle.Pyramid(oracle.clahe(Rs[b]))
+        eo, es = oracle.stereo_matching(ol, orr, kps[b], pr[b][0], pr[b][1])
+        assert np.array_equal(st[b * n:(b + 1) * n], es)
+        assert np.array_equal(out[b * n:(b + 1) * n].view(np.uint32), eo.view(np.uint32))
+
+
+@pytest.mark.parametrize("level", [3, 2])
+def test_line_min_sad_bit_exact(ctx, oracle, stream, pair, level):
+    """FeatureTracker::getLineMinSAD as stereoMatching calls it: coarsest level, kp.px_ * 2^-level, window 7, going left;
+    border points exercise the shrinking / growing half window and cv::getRectSubPix's replicated border"""
+    gl, gr, ol, orr = pair
+    kps = synth.grid_keypoints(2048, seed=35)
+    pts = (kps * np.float32(1.0 / (1 << level))).astype(np.float32)
+    w, h = gl.level_size(level)[:2]
+    edge = np.float32([[1.5, 30.2], [2.9, 2.9], [w - 1.3, 30.0], [w - 0.1, h - 0.1], [50.0, 0.4], [50.3, h - 0.4], [0.2, 0.2],
+                       [3.0, 3.0], [w - 3.01, h - 3.0], [w - 4.0, 10.0], [40.5, h - 2.2], [-1.0, 5.0], [w + 2.0, 5.0]])
+    pts = np.concatenate([pts, edge])
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    for go_left in (True, False):
+        xp, er = trk.getLineMinSAD(gl, gr, level, pts, 7, go_left)
+        inside = (pts[:, 0] >= 0) & (pts[:, 0] < w) & (pts[:, 1] >= 0) & (pts[:, 1] < h)
+        ex, ee = oracle.line_min_sad(ol, orr, level, pts[inside], 7, go_left)
+        assert np.array_equal(xp[inside].view(np.uint32), ex.view(np.uint32))
+        found = ex >= 0
+        assert np.array_equal(er[inside][found].view(np.uint32), ee[found].view(np.uint32))
+        assert (xp[~inside] == -1).all()           # documented: points outside the level image give -1
+    # the prior it yields is the disparity (rectified pair), as src/map_manager.cpp:431-435 uses it
+    xp, _ = trk.getLineMinSAD(gl, gr, level, pts[:2048], 7, True)
+    gt = stream.stereo_gt(kps)[:, 0] / (1 << level)
+    ok = (xp >= 0) & (pts[:2048, 0] > 40.0 / (1 << level) + 4)
+    assert np.median(np.abs(xp[ok] - gt[ok])) < 1.0
