@@ -102,6 +102,10 @@ void Frame::addKeypoint(const Keypoint &kp)
 {
     if (mapkps_.count(kp.lmid_)) return;
     mapkps_.emplace(kp.lmid_, kp);
+    if (ncellsize_) {   // addKeypointToGrid (src/frame.cpp:508-519)
+        const int idx = getKeypointCellIdx(kp.px_);
+        if (idx >= 0 && idx < (int)vgridkps_.size()) { if (vgridkps_[idx].empty()) noccupcells_++; vgridkps_[idx].push_back(kp.lmid_); }
+    }
     ++nbkps_;
     if (kp.is3d_) ++nb3dkps_; else ++nb2dkps_;
     if (kp.is_stereo_) ++nb_stereo_kps_;
@@ -111,8 +115,18 @@ void Frame::updateKeypoint(int lmid, const Point2f &pt)
 {
     auto it = mapkps_.find(lmid);
     if (it == mapkps_.end()) return;
-    it->second.px_ = pt;
-    it->second.unpx_ = pt;   // pinhole without distortion; the reference undistorts here (src/frame.cpp)
+    if (ncellsize_) {   // updateKeypointInGrid (src/frame.cpp:543-575): move the id when the cell changes
+        const int idx = getKeypointCellIdx(it->second.px_), nidx = getKeypointCellIdx(pt);
+        if (idx != nidx) {
+            if (idx >= 0 && idx < (int)vgridkps_.size()) {
+                auto &cell = vgridkps_[idx];
+                for (size_t k = 0; k < cell.size(); ++k)
+                    if (cell[k] == lmid) { cell.erase(cell.begin() + k); if (cell.empty()) noccupcells_--; break; }
+            }
+            if (nidx >= 0 && nidx < (int)vgridkps_.size()) { if (vgridkps_[nidx].empty()) noccupcells_++; vgridkps_[nidx].push_back(lmid); }
+        }
+    }
+    computeKeypoint(pt, it->second);   // px_, unpx_ (no distortion), bv_
 }
 
 void Frame::removeKeypointById(int lmid)
@@ -122,6 +136,14 @@ void Frame::removeKeypointById(int lmid)
     if (it->second.is3d_) --nb3dkps_; else --nb2dkps_;
     if (it->second.is_stereo_) --nb_stereo_kps_;
     --nbkps_;
+    if (ncellsize_) {   // removeKeypointFromGrid (src/frame.cpp:521-541)
+        const int idx = getKeypointCellIdx(it->second.px_);
+        if (idx >= 0 && idx < (int)vgridkps_.size()) {
+            auto &cell = vgridkps_[idx];
+            for (size_t k = 0; k < cell.size(); ++k)
+                if (cell[k] == lmid) { cell.erase(cell.begin() + k); if (cell.empty()) noccupcells_--; break; }
+        }
+    }
     mapkps_.erase(it);
 }
 
@@ -152,6 +174,110 @@ Point2f Frame::projWorldToImage(const Vec3 &wpt) const
     const Vec3 pc = Tcw_ * wpt;
     const Vec3 px = pcalib_leftcam_->projectCamToImage(pc);
     return {(float)px.x, (float)px.y};
+}
+
+void Frame::initGrid(size_t ncellsize)
+{   // src/frame.cpp:35-72
+    ncellsize_ = ncellsize;
+    nbwcells_ = (size_t)std::ceil((float)pcalib_leftcam_->img_w_ / (float)ncellsize_);
+    nbhcells_ = (size_t)std::ceil((float)pcalib_leftcam_->img_h_ / (float)ncellsize_);
+    noccupcells_ = 0;
+    vgridkps_.assign(nbwcells_ * nbhcells_, {});
+    for (const auto &kv : mapkps_) {
+        const int idx = getKeypointCellIdx(kv.second.px_);
+        if (idx >= 0 && idx < (int)vgridkps_.size()) vgridkps_[idx].push_back(kv.first);
+    }
+    if (pcalib_rightcam_) {   // Frl_ = K_r^-T [t]x R K_l^-1 with T = Tcic0 (:53-62)
+        const SE3 Tcic0 = pcalib_rightcam_->Tc0ci_.inverse();
+        double R[9];
+        Tcic0.rotation(R);
+        const double t[3] = {Tcic0.v[0], Tcic0.v[1], Tcic0.v[2]};
+        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+        const CameraCalibration &cl = *pcalib_leftcam_, &cr = *pcalib_rightcam_;
+        const double Kli[9] = {1 / cl.fx_, 0, -cl.cx_ / cl.fx_, 0, 1 / cl.fy_, -cl.cy_ / cl.fy_, 0, 0, 1};
+        const double Krit[9] = {1 / cr.fx_, 0, 0, 0, 1 / cr.fy_, 0, -cr.cx_ / cr.fx_, -cr.cy_ / cr.fy_, 1};
+        double A[9], B[9];
+        auto mul = [](const double *X, const double *Y, double *Z) {
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Z[3 * i + j] = X[3 * i] * Y[j] + X[3 * i + 1] * Y[3 + j] + X[3 * i + 2] * Y[6 + j];
+        };
+        mul(Krit, tx, A); mul(A, R, B); mul(B, Kli, Frl_);
+    }
+}
+
+int Frame::getKeypointCellIdx(const Point2f &pt) const
+{   // src/frame.cpp: r = floor(y / cell), c = floor(x / cell)
+    if (!ncellsize_) return -1;
+    const int r = (int)std::floor(pt.y / (float)ncellsize_), c = (int)std::floor(pt.x / (float)ncellsize_);
+    return r * (int)nbwcells_ + c;
+}
+
+std::vector<Keypoint> Frame::getKeypoints() const
+{
+    std::vector<Keypoint> v;
+    v.reserve(nbkps_);
+    for (const auto &kv : mapkps_) v.push_back(kv.second);
+    return v;
+}
+
+std::vector<Keypoint> Frame::getSurroundingKeypoints(const Keypoint &kp) const
+{   // src/frame.cpp:594-622 (note the reference's half-open loops: the cell itself and its upper / left neighbours)
+    std::vector<Keypoint> vkps;
+    if (!ncellsize_) return vkps;
+    const int rkp = (int)std::floor(kp.px_.y / (float)ncellsize_), ckp = (int)std::floor(kp.px_.x / (float)ncellsize_);
+    for (int r = rkp - 1; r < rkp + 1; r++)
+        for (int c = ckp - 1; c < ckp + 1; c++) {
+            const int idx = r * (int)nbwcells_ + c;
+            if (r < 0 || c < 0 || idx > (int)vgridkps_.size()) continue;
+            if (idx == (int)vgridkps_.size()) continue;   // the reference's `idx > size` lets idx == size through to .at(): out of range there
+            for (const int id : vgridkps_[idx])
+                if (id != kp.lmid_) {
+                    auto it = mapkps_.find(id);
+                    if (it != mapkps_.end()) vkps.push_back(it->second);
+                }
+        }
+    return vkps;
+}
+
+void Frame::computeKeypoint(const Point2f &pt, Keypoint &kp) const
+{   // src/frame.cpp:246-254; undistortImagePoint is the identity without distortion coefficients
+    kp.px_ = pt;
+    kp.unpx_ = pt;
+    if (!pcalib_leftcam_) return;
+    const CameraCalibration &cl = *pcalib_leftcam_;
+    const double hx = (double)kp.unpx_.x, hy = (double)kp.unpx_.y;
+    Vec3 bv{(hx - cl.cx_) / cl.fx_, (hy - cl.cy_) / cl.fy_, 1.0};   // iK * [unpx, 1]
+    const double nrm = std::sqrt(bv.x * bv.x + bv.y * bv.y + bv.z * bv.z);
+    kp.bv_ = Vec3{bv.x / nrm, bv.y / nrm, bv.z / nrm};
+}
+
+void Frame::updateKeypointStereo(int lmid, const Point2f &pt)
+{   // src/frame.cpp:405-433
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end()) return;
+    Keypoint &kp = it->second;
+    kp.rpx_ = pt;
+    kp.runpx_ = pt;   // undistortImagePoint: identity without distortion coefficients
+    const CameraCalibration &cr = *pcalib_rightcam_;
+    Vec3 bv{((double)kp.runpx_.x - cr.cx_) / cr.fx_, ((double)kp.runpx_.y - cr.cy_) / cr.fy_, 1.0};
+    const double nrm = std::sqrt(bv.x * bv.x + bv.y * bv.y + bv.z * bv.z);
+    kp.rbv_ = Vec3{bv.x / nrm, bv.y / nrm, bv.z / nrm};
+    if (!kp.is_stereo_) { kp.is_stereo_ = true; nb_stereo_kps_++; }
+}
+
+Point2f Frame::projCamToRightImageDist(const Vec3 &pt) const
+{   // src/frame.cpp:796-799 -> CameraCalibration::projectCamToImageDist (src/camera_calibration.cpp:254-264, Dcv_.empty())
+    const CameraCalibration &cr = *pcalib_rightcam_;
+    const Vec3 p = cr.Tc0ci_.inverse() * pt;
+    const double invz = 1. / p.z, x = p.x * invz, y = p.y * invz;
+    return Point2f{(float)(cr.fx_ * x + cr.cx_), (float)(cr.fy_ * y + cr.cy_)};
+}
+
+Point2f Frame::projWorldToRightImageDist(const Vec3 &wpt) const { return projCamToRightImageDist(projWorldToCam(wpt)); }
+
+bool Frame::isInRightImage(const Point2f &pt) const
+{
+    return pt.x >= 0 && pt.y >= 0 && pt.x < pcalib_rightcam_->img_w_ && pt.y < pcalib_rightcam_->img_h_;
 }
 
 // ---------------------------------------------------------------------------------------------- MapPoint / MapManager
@@ -388,85 +514,97 @@ std::vector<Point2f> FeatureExtractor::detectGridFAST(const Pyramid &pyr, int nc
 
 // ---------------------------------------------------------------------------------------------- stereoMatching
 ov2_status MapManager::stereoMatching(Frame &frame, const Pyramid &vleftpyr, const Pyramid &vrightpyr,
-                                      const FeatureTracker &tracker, const SlamParams &st, bool rectified)
-{
-    std::vector<int> v3dkpids, vkpids;
-    std::vector<Point2f> v3dkps, v3dpriors, vkps, vpriors;
-    const CameraCalibration &cr = *frame.pcalib_rightcam_;
-    const SE3 Trl = cr.Tc0ci_.inverse();
-    for (const auto &it : frame.mapkps_) {   // :385-490 priors
-        const Keypoint &kp = it.second;
-        if (kp.is3d_) {
+                                      const FeatureTracker &tracker, const SlamParams &st)
+{   // src/map_manager.cpp:367-611
+    const std::vector<Keypoint> vleftkps = frame.getKeypoints();
+    const size_t nbkps = vleftkps.size();
+    // ZNCC parameters (:376-381)
+    const int nmaxpyrlvl = st.nklt_pyr_lvl_;   // vleftpyr.at(nklt_pyr_lvl_ * 2) = the image of that level
+    const int winsize = 7;
+    const float uppyrcoef = std::pow(2.f, (float)st.nklt_pyr_lvl_);
+    const float downpyrcoef = (float)(1. / uppyrcoef);
+
+    // one flat batch for ov2_stereo_matching: has_prior = 1 <-> the reference's v3dkps / v3dpriors lists
+    std::vector<int> vids;
+    std::vector<Point2f> vkps, vpriors, vlunpx;
+    std::vector<uint8_t> vhas;
+    std::vector<size_t> vsad;            // entries whose prior comes from the SAD line search
+    std::vector<Point2f> vsadpts;
+    vids.reserve(nbkps); vkps.reserve(nbkps); vpriors.reserve(nbkps); vlunpx.reserve(nbkps); vhas.reserve(nbkps);
+    auto push = [&](const Keypoint &kp, const Point2f &prior, bool has) {
+        vids.push_back(kp.lmid_); vkps.push_back(kp.px_); vpriors.push_back(prior); vlunpx.push_back(kp.unpx_);
+        vhas.push_back(has ? 1 : 0);
+    };
+    for (size_t i = 0; i < nbkps; ++i) {
+        const Keypoint &kp = vleftkps[i];
+        if (kp.is3d_) {                                                     // :398-417
             auto plm = getMapPoint(kp.lmid_);
-            if (plm) {   // :398-420 reprojection of the 3D point into the right camera
-                const Vec3 pr = Trl * (frame.getTcw() * plm->getPoint());
-                if (pr.z > 0.1) {
-                    const Vec3 px = cr.projectCamToImage(pr);
-                    const Point2f p{(float)px.x, (float)px.y};
-                    if (p.x >= 0 && p.y >= 0 && p.x < cr.img_w_ && p.y < cr.img_h_) {
-                        v3dkps.push_back(kp.px_); v3dpriors.push_back(p); v3dkpids.push_back(kp.lmid_);
-                        continue;
+            if (plm != nullptr) {
+                const Point2f projpt = frame.projWorldToRightImageDist(plm->getPoint());
+                if (frame.isInRightImage(projpt)) { push(kp, projpt, true); continue; }
+            } else {
+                removeMapPointObs(kp.lmid_, frame.kfid_);
+                continue;
+            }
+        }
+        if (st.bdo_stereo_rect_) {                                          // :419-436: prior from SAD (batched below)
+            vsad.push_back(vids.size());
+            vsadpts.push_back(Point2f{kp.px_.x * downpyrcoef, kp.px_.y * downpyrcoef});
+        } else {                                                            // :438-483: prior from the 3D neighbours
+            const size_t nbmin3dcokps = 1;
+            const std::vector<Keypoint> vnearkps = frame.getSurroundingKeypoints(kp);
+            if (vnearkps.size() >= nbmin3dcokps) {
+                std::vector<Keypoint> vnear3dkps;
+                for (const auto &cokp : vnearkps)
+                    if (cokp.is3d_) vnear3dkps.push_back(cokp);
+                if (vnear3dkps.size() >= nbmin3dcokps) {
+                    size_t nb3dkp = 0;
+                    double mean_z = 0., weights = 0.;
+                    for (const auto &cokp : vnear3dkps) {
+                        auto plm = getMapPoint(cokp.lmid_);
+                        if (plm != nullptr) {
+                            nb3dkp++;
+                            const float dx = cokp.unpx_.x - kp.unpx_.x, dy = cokp.unpx_.y - kp.unpx_.y;   // Point2f difference
+                            const double coef = 1. / std::sqrt((double)dx * dx + (double)dy * dy);       // cv::norm(Point2f)
+                            weights += coef;
+                            mean_z += coef * frame.projWorldToCam(plm->getPoint()).z;
+                        }
+                    }
+                    if (nb3dkp >= nbmin3dcokps) {
+                        mean_z /= weights;
+                        const Vec3 predcampt{mean_z * (kp.bv_.x / kp.bv_.z), mean_z * (kp.bv_.y / kp.bv_.z),
+                                             mean_z * (kp.bv_.z / kp.bv_.z)};
+                        const Point2f projpt = frame.projCamToRightImageDist(predcampt);
+                        if (frame.isInRightImage(projpt)) { push(kp, projpt, true); continue; }
                     }
                 }
             }
         }
-        vkpids.push_back(kp.lmid_); vkps.push_back(kp.px_); vpriors.push_back(kp.px_);
+        push(kp, kp.px_, false);                                            // :486-488 (priorpt = kp.px_ so far)
     }
-    std::vector<int> vgoodids;
-    std::vector<Point2f> vgoodl, vgoodr;
-    if (!v3dkps.empty()) {   // :505-540, 2 levels
-        std::vector<bool> ok;
-        ov2_status s = tracker.fbKltTracking(vleftpyr, vrightpyr, st.nklt_win_size_, 1, st.nklt_err_, st.fmax_fbklt_dist_,
-                                             v3dkps, v3dpriors, ok);
+    if (!vsad.empty()) {   // FeatureTracker::getLineMinSAD for every rectified 2D keypoint in one launch
+        std::vector<float> xprior(vsad.size()), l1err(vsad.size());
+        const ov2_status s = ov2_line_min_sad(tracker.ctx_, vleftpyr.h, vrightpyr.h, nmaxpyrlvl, winsize, 1, (int)vsad.size(),
+                                              &vsadpts[0].x, xprior.data(), l1err.data());
         if (s != OV2_OK) return s;
-        for (size_t i = 0; i < v3dkps.size(); ++i) {
-            if (ok[i]) { vgoodids.push_back(v3dkpids[i]); vgoodl.push_back(v3dkps[i]); vgoodr.push_back(v3dpriors[i]); }
-            else { vkpids.push_back(v3dkpids[i]); vkps.push_back(v3dkps[i]); vpriors.push_back(v3dkps[i]); }   // :533-537
+        for (size_t k = 0; k < vsad.size(); ++k) {
+            float xp = xprior[k];
+            xp *= uppyrcoef;                                                // :431
+            if (xp >= 0 && xp <= vkps[vsad[k]].x) vpriors[vsad[k]].x = xp;  // :433-435
         }
     }
-    if (!vkps.empty()) {     // :545-580, full pyramid
-        std::vector<bool> ok;
-        ov2_status s = tracker.fbKltTracking(vleftpyr, vrightpyr, st.nklt_win_size_, st.nklt_pyr_lvl_, st.nklt_err_,
-                                             st.fmax_fbklt_dist_, vkps, vpriors, ok);
-        if (s != OV2_OK) return s;
-        for (size_t i = 0; i < vkps.size(); ++i)
-            if (ok[i]) { vgoodids.push_back(vkpids[i]); vgoodl.push_back(vkps[i]); vgoodr.push_back(vpriors[i]); }
-    }
-    // epipolar gate :585-605 (fmax_proj_pxdist = 2 px)
-    const float epi_th = 2.f;
-    double F[9] = {0};
-    if (!rectified) {   // F_rl = K_r^-T [t]x R K_l^-1 from the extrinsic
-        double R[9];
-        Trl.rotation(R);
-        const double t[3] = {Trl.v[0], Trl.v[1], Trl.v[2]};
-        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
-        double E[9];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) E[3 * i + j] = tx[3 * i] * R[j] + tx[3 * i + 1] * R[3 + j] + tx[3 * i + 2] * R[6 + j];
-        const CameraCalibration &cl = *frame.pcalib_leftcam_;
-        const double Kli[9] = {1 / cl.fx_, 0, -cl.cx_ / cl.fx_, 0, 1 / cl.fy_, -cl.cy_ / cl.fy_, 0, 0, 1};
-        const double Krit[9] = {1 / cr.fx_, 0, 0, 0, 1 / cr.fy_, 0, -cr.cx_ / cr.fx_, -cr.cy_ / cr.fy_, 1};
-        double T[9];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) T[3 * i + j] = E[3 * i] * Kli[j] + E[3 * i + 1] * Kli[3 + j] + E[3 * i + 2] * Kli[6 + j];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) F[3 * i + j] = Krit[3 * i] * T[j] + Krit[3 * i + 1] * T[3 + j] + Krit[3 * i + 2] * T[6 + j];
-    }
-    for (size_t i = 0; i < vgoodids.size(); ++i) {
-        const Point2f l = vgoodl[i], r = vgoodr[i];
-        bool good;
-        if (rectified) good = std::fabs(l.y - r.y) <= epi_th;
-        else {   // distance of the right point to the epipolar line F * x_l
-            const double a = F[0] * l.x + F[1] * l.y + F[2], b = F[3] * l.x + F[4] * l.y + F[5], c = F[6] * l.x + F[7] * l.y + F[8];
-            good = std::fabs(a * r.x + b * r.y + c) / std::sqrt(a * a + b * b) <= epi_th;
-        }
-        auto it = frame.mapkps_.find(vgoodids[i]);
-        if (!good || it == frame.mapkps_.end()) continue;
-        if (!it->second.is_stereo_) frame.nb_stereo_kps_++;   // Frame::updateKeypointStereo
-        it->second.is_stereo_ = true;
-        it->second.rpx_ = r;
-        it->second.runpx_ = r;
-    }
+    const int n = (int)vids.size();
+    if (n == 0) return OV2_OK;
+    static_assert(sizeof(Point2f) == 8, "packed floats");
+    std::vector<Point2f> vout((size_t)n);
+    std::vector<uint8_t> vstatus((size_t)n);
+    const ov2_status s = ov2_stereo_matching(tracker.ctx_, vleftpyr.h, vrightpyr.h, st.nklt_win_size_, st.nklt_pyr_lvl_,
+                                             tracker.nmax_iter_, tracker.fmax_px_precision_, st.nklt_err_, st.fmax_fbklt_dist_, n,
+                                             &vkps[0].x, &vpriors[0].x, vhas.data(), &vlunpx[0].x, st.bdo_stereo_rect_ ? 1 : 0,
+                                             frame.Frl_, &vout[0].x, vstatus.data());
+    if (s != OV2_OK) return s;
+    for (int i = 0; i < n; ++i)                                             // :597-601
+        if (vstatus[i]) frame.updateKeypointStereo(vids[i], vout[i]);
     return OV2_OK;
 }
 

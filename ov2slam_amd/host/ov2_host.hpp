@@ -44,7 +44,11 @@ struct CameraCalibration {   // pinhole part of src/camera_calibration.cpp that 
     double fx_ = 1, fy_ = 1, cx_ = 0, cy_ = 0;
     int img_w_ = 0, img_h_ = 0;
     SE3 Tc0ci_;               // extrinsic: this camera in the left-camera frame (getExtrinsic(), T_left_right)
-    Vec3 projectCamToImage(const Vec3 &pc) const { return {fx_ * pc.x / pc.z + cx_, fy_ * pc.y / pc.z + cy_, pc.z}; }
+    Vec3 projectCamToImage(const Vec3 &pc) const
+    {   // src/camera_calibration.cpp:243-252: invz first, then fx * x + cx
+        const double invz = 1. / pc.z, x = pc.x * invz, y = pc.y * invz;
+        return {fx_ * x + cx_, fy_ * y + cy_, pc.z};
+    }
 };
 
 struct Keypoint {   // include/frame.hpp:46-76
@@ -56,6 +60,7 @@ struct Keypoint {   // include/frame.hpp:46-76
     bool is_stereo_ = false;
     Point2f rpx_, runpx_;
     bool is_retracked_ = false;
+    Vec3 bv_, rbv_;           // bearing vectors (left / right), include/frame.hpp:60-66
 };
 
 class Frame {   // include/frame.hpp:78-237 (members the path touches)
@@ -68,6 +73,21 @@ public:
     std::shared_ptr<CameraCalibration> pcalib_leftcam_, pcalib_rightcam_;
     std::map<int, int> map_covkfs_;
 
+    // keypoint grid (include/frame.hpp:214-221, src/frame.cpp:40-45): cells of ncellsize_ px, ids per cell in insertion
+    // order.  initGrid() plays the part of the reference constructors; a Frame without it keeps no grid.
+    size_t ncellsize_ = 0, nbwcells_ = 0, nbhcells_ = 0, noccupcells_ = 0;
+    std::vector<std::vector<int>> vgridkps_;
+    double Frl_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // F_rl = K_r^-T [t]x R K_l^-1 (src/frame.cpp:53-62), row-major
+    void initGrid(size_t ncellsize);                  // + Frl_ when a right camera is set
+    int getKeypointCellIdx(const Point2f &pt) const;
+    std::vector<Keypoint> getKeypoints() const;
+    std::vector<Keypoint> getSurroundingKeypoints(const Keypoint &kp) const;   // src/frame.cpp:594-622
+    void computeKeypoint(const Point2f &pt, Keypoint &kp) const;              // :246-254 (no distortion: unpx = px)
+    void updateKeypointStereo(int lmid, const Point2f &pt);                    // :405-433
+    Vec3 projWorldToCam(const Vec3 &wpt) const { return Tcw_ * wpt; }
+    Point2f projWorldToRightImageDist(const Vec3 &wpt) const;                  // :835-838
+    Point2f projCamToRightImageDist(const Vec3 &pt) const;                     // :796-799
+    bool isInRightImage(const Point2f &pt) const;                              // :845-848
     SE3 getTwc() const { return Twc_; }
     SE3 getTcw() const { return Tcw_; }
     void setTwc(const SE3 &Twc) { Twc_ = Twc; Tcw_ = Twc.inverse(); }
@@ -114,13 +134,14 @@ public:
     void removeMapPoint(int lmid);
     void removeObsFromCurFrameById(int lmid);
     void updateFrameCovisibility(Frame &frame);   // src/map_manager.cpp: co-observation counts
-    // src/map_manager.cpp:367-611: left->right KLT of the keyframe's keypoints (3D ones from their reprojection into the
-    // right camera on 2 levels, the rest and the failures on the full pyramid), then the epipolar gate (rectified
-    // rows: |dy| <= 2 px; otherwise distance to the epipolar line of F_rl <= 2 px) -> Frame stereo keypoints.
-    // The SAD line search / neighbour-depth priors of :429-483 are host heuristics outside the kernel path and are
-    // not reproduced: keypoints without a 3D prior start from their left pixel.
+    // src/map_manager.cpp:367-611, statement by statement: priors (3D point reprojected into the right camera :398-413;
+    // rectified rigs: getLineMinSAD on the coarsest level :419-436 = ov2_line_min_sad; otherwise the inverse-distance
+    // weighted depth of the 3D neighbours :438-483), 3D keypoints whose map point is gone lose their observation (:414),
+    // then ov2_stereo_matching: 2-level KLT on the priors, failures re-queued with the updated prior, full pyramid for the
+    // rest, epipolar gate (row check + snap | Sampson with Frame::Frl_) -> Frame::updateKeypointStereo.  Cameras
+    // without distortion (Dcv_.empty(): undistortImagePoint / projectCamToImageDist are the pinhole maps).
     ov2_status stereoMatching(Frame &frame, const struct Pyramid &vleftpyr, const struct Pyramid &vrightpyr,
-                              const class FeatureTracker &tracker, const struct SlamParams &st, bool rectified);
+                              const class FeatureTracker &tracker, const struct SlamParams &st);
 
     // ---- flat device mirror (include/ov2slam_hip.h "ov2_map"): the hash maps above stay the host's source of truth,
     // every mutation that the local-BA set-up can see is queued here and pushed in batches (flushDevice) before the
@@ -146,6 +167,7 @@ struct SlamParams {   // the subset of include/slam_params.hpp the path reads (Y
     float fclahe_val_ = 3.f;
     bool blocalba_is_on_ = false, bforce_realtime_ = true;
     bool dop3p_ = false;
+    bool bdo_stereo_rect_ = false;   // parameters_files/*/euroc_stereo.yaml: 0
 };
 
 struct Vec2 {

@@ -74,6 +74,112 @@ int ov2h_map_add_obs(void *p, int kfid, int lmid, float ux, float uy, int is_ste
     return 0;
 }
 
+// a keypoint of keyframe kfid that is 2D or 3D (is3d); the map point is created on first use (2D ones carry no position)
+int ov2h_map_add_kp(void *p, int kfid, int lmid, float ux, float uy, int is3d, const double *xyz)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(kfid);
+    if (!f) return -1;
+    auto lm = m->map->getMapPoint(lmid);
+    if (!lm) {
+        lm = std::make_shared<MapPoint>(lmid, kfid, true);
+        if (is3d && xyz) lm->setPoint(Vec3{xyz[0], xyz[1], xyz[2]});
+        m->map->map_plms_[lmid] = lm;
+    }
+    Keypoint kp;
+    kp.lmid_ = lmid;
+    f->computeKeypoint(Point2f{ux, uy}, kp);
+    kp.is3d_ = is3d != 0;
+    f->addKeypoint(kp);
+    lm->addKfObs(kfid);
+    return 0;
+}
+
+int ov2h_frame_init_grid(void *p, int kfid, int ncellsize)
+{
+    auto f = ((HostMap *)p)->map->getKeyframe(kfid);
+    if (!f) return -1;
+    f->initGrid((size_t)ncellsize);
+    return 0;
+}
+
+// drops a map point but leaves the keypoints that reference it (the "plm == nullptr" branch of stereoMatching, :414)
+int ov2h_map_forget_landmark(void *p, int lmid) { ((HostMap *)p)->map->map_plms_.erase(lmid); return 0; }
+
+int ov2h_set_params(void *p, int klt_use_prior, int stereo_rect, int nklt_pyr_lvl, int nklt_win_size)
+{
+    HostMap *m = (HostMap *)p;
+    m->st->klt_use_prior_ = klt_use_prior != 0; m->st->bdo_stereo_rect_ = stereo_rect != 0;
+    m->st->nklt_pyr_lvl_ = nklt_pyr_lvl; m->st->nklt_win_size_ = nklt_win_size;
+    return 0;
+}
+
+// MapManager::stereoMatching(frame, vleftpyr, vrightpyr) on keyframe kfid; the two pyramids are built here the way
+// Mapper::run does (src/mapper.cpp:76-81: CLAHE + buildOpticalFlowPyramid of the right image; the left one is the frame's)
+int ov2h_stereo_matching(void *p, void *ctx, int kfid, const uint8_t *img_left, const uint8_t *img_right, int w, int h)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(kfid);
+    if (!f) return -1;
+    ov2_ctx *c = (ov2_ctx *)ctx;
+    ov2_pyr *pl = nullptr, *pr = nullptr;
+    const SlamParams &st = *m->st;
+    ov2_status s = ov2_pyramid_build(c, img_left, w, h, w, st.nklt_win_size_, st.nklt_pyr_lvl_, st.use_clahe_ ? 1 : 0, st.fclahe_val_,
+                                     w / 50, h / 50, &pl);
+    if (s != OV2_OK) return s;
+    Pyramid L(pl);
+    s = ov2_pyramid_build(c, img_right, w, h, w, st.nklt_win_size_, st.nklt_pyr_lvl_, st.use_clahe_ ? 1 : 0, st.fclahe_val_, w / 50,
+                          h / 50, &pr);
+    if (s != OV2_OK) return s;
+    Pyramid R(pr);
+    FeatureTracker tracker(c, st.nmax_iter_, st.fmax_px_precision_);
+    return m->map->stereoMatching(*f, L, R, tracker, st);
+}
+
+// VisualFrontEnd::preprocessImage (twice: previous image, current image) + kltTracking with keyframe kfid as the
+// current frame (its keypoints sit at their previous-image positions, as at src/visual_front_end.cpp:132)
+int ov2h_klt_tracking(void *p, void *ctx, int kfid, const uint8_t *img_prev, const uint8_t *img_cur, int w, int h, int *p3p_req)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(kfid);
+    if (!f) return -1;
+    ov2_ctx *c = (ov2_ctx *)ctx;
+    m->map->pcurframe_ = f;
+    auto tracker = std::make_shared<FeatureTracker>(c, m->st->nmax_iter_, m->st->fmax_px_precision_);
+    VisualFrontEnd fe(c, m->st, f, m->map, tracker);
+    ov2_status s = fe.preprocessImage(img_prev, w, h, w);
+    if (s != OV2_OK) return s;
+    if ((s = fe.preprocessImage(img_cur, w, h, w)) != OV2_OK) return s;
+    s = fe.kltTracking();
+    if (p3p_req) *p3p_req = fe.bp3preq_ ? 1 : 0;
+    return s;
+}
+
+// keypoints of keyframe kfid: lmid, px, is3d, is_stereo, rpx (arrays of capacity cap); returns the count
+int ov2h_get_keypoints(void *p, int kfid, int cap, int *lmid, float *px, uint8_t *is3d, uint8_t *is_stereo, float *rpx)
+{
+    auto f = ((HostMap *)p)->map->getKeyframe(kfid);
+    if (!f) return -1;
+    int n = 0;
+    for (const auto &kv : f->mapkps_) {
+        if (n < cap) {
+            const Keypoint &k = kv.second;
+            lmid[n] = k.lmid_; px[2 * n] = k.px_.x; px[2 * n + 1] = k.px_.y; is3d[n] = k.is3d_; is_stereo[n] = k.is_stereo_;
+            rpx[2 * n] = k.rpx_.x; rpx[2 * n + 1] = k.rpx_.y;
+        }
+        ++n;
+    }
+    return n;
+}
+
+int ov2h_get_frl(void *p, int kfid, double *F9)
+{
+    auto f = ((HostMap *)p)->map->getKeyframe(kfid);
+    if (!f) return -1;
+    for (int i = 0; i < 9; ++i) F9[i] = f->Frl_[i];
+    return 0;
+}
+
 int ov2h_map_finalize(void *p, int newkf)
 {
     HostMap *m = (HostMap *)p;

@@ -47,6 +47,15 @@ def lib():
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
         L.ov2h_count_keypoints.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        fpp = C.POINTER(C.c_float)
+        L.ov2h_map_add_kp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, dp]
+        L.ov2h_frame_init_grid.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ov2h_map_forget_landmark.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ov2h_stereo_matching.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u8, u8, C.c_int, C.c_int]
+        L.ov2h_klt_tracking.argtypes = [C.c_void_p, C.c_void_p, C.c_int, u8, u8, C.c_int, C.c_int, ip]
+        L.ov2h_get_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, fpp, u8, u8, fpp]
+        L.ov2h_get_frl.argtypes = [C.c_void_p, C.c_int, dp]
         _lib = L
     return _lib
 
@@ -212,6 +221,65 @@ class EstimatorWorker:
     def close(self):
         if getattr(self, "h", None):
             lib().ov2h_ba_worker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class FrontEndFrame:
+    """one keyframe with 2D / 3D keypoints in the C++ host mirror (Frame + MapManager + CameraCalibration pair), to drive
+    MapManager::stereoMatching and VisualFrontEnd::kltTracking through libov2host.so.  Test / bring-up only."""
+
+    def __init__(self, K, baseline, w, h, Twc=None, ncellsize=35, stereo_rect=False, klt_use_prior=True, nklt_pyr_lvl=3,
+                 nklt_win_size=9):
+        L = lib()
+        K = np.ascontiguousarray(K, np.float64)
+        t_lr7 = np.ascontiguousarray([baseline, 0, 0, 0, 0, 0, 1.0])    # right camera in the left frame (Tc0ci)
+        self.h = L.ov2h_map_create(1, 1, _dp(K), _dp(K), _dp(t_lr7), w, h, 25)
+        self.w, self.h_img, self.kfid = w, h, 0
+        T = np.ascontiguousarray([0, 0, 0, 0, 0, 0, 1.0] if Twc is None else Twc, np.float64)
+        L.ov2h_map_add_keyframe(self.h, 0, _dp(T))
+        L.ov2h_set_params(self.h, int(klt_use_prior), int(stereo_rect), nklt_pyr_lvl, nklt_win_size)
+        L.ov2h_frame_init_grid(self.h, 0, ncellsize)
+
+    def add_keypoint(self, lmid, px, xyz=None):
+        x = None if xyz is None else np.ascontiguousarray(xyz, np.float64)
+        lib().ov2h_map_add_kp(self.h, 0, int(lmid), float(px[0]), float(px[1]), int(xyz is not None), None if x is None else _dp(x))
+
+    def forget_landmark(self, lmid):
+        lib().ov2h_map_forget_landmark(self.h, int(lmid))
+
+    def stereo_matching(self, ctx, img_left, img_right):
+        u8 = C.POINTER(C.c_uint8)
+        a, b = np.ascontiguousarray(img_left, np.uint8), np.ascontiguousarray(img_right, np.uint8)
+        return lib().ov2h_stereo_matching(self.h, ctx.h, 0, a.ctypes.data_as(u8), b.ctypes.data_as(u8), self.w, self.h_img)
+
+    def klt_tracking(self, ctx, img_prev, img_cur):
+        u8 = C.POINTER(C.c_uint8)
+        a, b = np.ascontiguousarray(img_prev, np.uint8), np.ascontiguousarray(img_cur, np.uint8)
+        req = C.c_int(0)
+        st = lib().ov2h_klt_tracking(self.h, ctx.h, 0, a.ctypes.data_as(u8), b.ctypes.data_as(u8), self.w, self.h_img, C.byref(req))
+        return st, bool(req.value)
+
+    def keypoints(self, cap=65536):
+        """dict lmid -> (px (2,), is3d, is_stereo, rpx (2,))"""
+        fpp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+        lm, px, rp = np.zeros(cap, np.int32), np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        i3, ist = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = lib().ov2h_get_keypoints(self.h, 0, cap, lm.ctypes.data_as(C.POINTER(C.c_int)), px.ctypes.data_as(fpp),
+                                     i3.ctypes.data_as(u8), ist.ctypes.data_as(u8), rp.ctypes.data_as(fpp))
+        assert 0 <= n <= cap
+        return {int(lm[k]): (px[k].copy(), bool(i3[k]), bool(ist[k]), rp[k].copy()) for k in range(n)}
+
+    def frl(self):
+        F = np.zeros(9)
+        lib().ov2h_get_frl(self.h, 0, _dp(F))
+        return F.reshape(3, 3)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ov2h_map_destroy(self.h)
             self.h = None
 
     def __del__(self):

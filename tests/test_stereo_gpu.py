@@ -36,7 +36,7 @@ def test_fb_klt_left_to_right(ctx, oracle, stream, pair, n):
         assert np.array_equal(st, es.astype(bool))
         assert np.array_equal(out.view(np.uint32), eo.view(np.uint32))
     out, st = trk.fbKltTracking(gl, gr, 9, 1, 30.0, 0.5, kps, pri)
-    assert st.mean() > 0.9 and np.median(np.abs(out[st] - gt[st])) < 0.1
+    assert st.mean() > 0.9 and np.median(np.abs(out[st] - gt[st])) < 0.25
 
 
 @pytest.mark.parametrize("n", [2048, 4000])
