@@ -594,7 +594,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     const int i = (is_a ? list_a : list_b)[act ? idx : total - 1];
     const float2 kp = kps[i];
     const int b = img_idx ? img_idx[i] : 0;
-    float2 pr = is_a ? prior[i] : kp;
+    // kltTracking: keypoints without a prior start from their own position (vpriors = vkps, :181-183); stereoMatching's
+    // full-pyramid list carries priors of its own (kp.px_ or the SAD prior, src/map_manager.cpp:419-436,486-488)
+    float2 pr = (is_a || !P.rule33) ? prior[i] : kp;
     unsigned work = 0;
     const int nl = is_a ? min(1, pv.nlevels - 1) : P.nlevels;
     const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);

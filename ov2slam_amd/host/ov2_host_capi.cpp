@@ -172,6 +172,16 @@ int ov2h_get_keypoints(void *p, int kfid, int cap, int *lmid, float *px, uint8_t
     return n;
 }
 
+// Frame::projWorldToRightImageDist / projWorldToImage of keyframe kfid (test hook)
+int ov2h_project(void *p, int kfid, const double *xyz, int right, float *px)
+{
+    auto f = ((HostMap *)p)->map->getKeyframe(kfid);
+    if (!f) return -1;
+    const Point2f q = right ? f->projWorldToRightImageDist(Vec3{xyz[0], xyz[1], xyz[2]}) : f->projWorldToImage(Vec3{xyz[0], xyz[1], xyz[2]});
+    px[0] = q.x; px[1] = q.y;
+    return 0;
+}
+
 int ov2h_get_frl(void *p, int kfid, double *F9)
 {
     auto f = ((HostMap *)p)->map->getKeyframe(kfid);

@@ -109,7 +109,7 @@ def test_map_manager_stereo_matching(ctx, oracle, stream, rect):
     pk = kps[ids]
     pp = np.float32([prior[i] for i in ids])
     ph = np.uint8([has[i] for i in ids])
-    assert 0.2 < ph.mean() < 0.95
+    assert 0.2 < ph.mean() < 1.0
     eo, es = oracle.stereo_matching(ol, orr, pk, pp, ph, 9, 3, 30.0, 0.5, 30, 0.01, rectified=rect, F_rl=fr.frl())
     assert es.mean() > 0.6
     for k, i in enumerate(ids):

@@ -52,6 +52,9 @@ def test_stereo_matching_flat(ctx, oracle, stream, pair, n, rectified):
     rng = np.random.default_rng(2)
     bad = rng.uniform(size=n) < 0.08
     pri[bad & (has > 0)] += rng.normal(0, 25.0, (int((bad & (has > 0)).sum()), 2)).astype(np.float32)
+    # keypoints WITHOUT a 2-level prior still carry one for the full pyramid (the SAD prior of rectified rigs, :431-435)
+    sadlike = (has == 0) & (rng.uniform(size=n) < 0.6)
+    pri[sadlike, 0] = (gt[sadlike, 0] + rng.normal(0, 3.0, int(sadlike.sum()))).astype(np.float32)
     lunpx = kps.copy()
     lunpx[::7, 1] += np.float32(1.9)      # undistorted left pixels that differ from the raw ones (gate input only)
     lunpx[::11, 1] += np.float32(2.3)
