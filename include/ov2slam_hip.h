@@ -281,8 +281,21 @@ void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th);
  * (include/optimizer.hpp:42, src/optimizer.cpp:439-735): Levenberg-Marquardt with Jacobi scaling, Huber loss via the
  * Ceres corrector, landmark Schur complement, reduced camera system solved on device; time caps are not applied
  * (the reference's 0.2 s wall-clock truncation makes it non-deterministic).
- * p->pose / p->lm are HOST pointers, updated in place for the non-constant blocks. */
+ * p->pose / p->lm are HOST pointers, updated in place for the non-constant blocks.
+ * r->chi2 / depth_positive / outlier follow the reference's post-solve reads of the cost functors' cached fields
+ * (src/optimizer.cpp:500-592): they are the values of the LAST evaluation Ceres made -- the final state after an accepted
+ * last step, the rejected / tolerance-terminating candidate otherwise (trust_region_minimizer.cc:108-131). */
 ov2_status ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
+
+/* B independent local-BA windows in one call: p[B], r[B], one set of options (ov2_ba_solve is the B = 1 case and runs the
+ * same code).  This is how one GPU serves many SLAM instances: the reference runs one Estimator thread per instance
+ * (src/estimator.cpp:32-98), each calling Optimizer::localBA on its own keyframe window; here the windows that are pending
+ * at the same time are laid end to end, every O(residuals) / O(landmarks) kernel covers all of them in one launch, every
+ * window gets its own reduced camera system, its own Cholesky workgroup and its own device-side copy of Ceres'
+ * trust-region state machine (radius, accept / reject, tolerances), and the fixed chain of max_iters LM rounds is enqueued
+ * without a host synchronisation.  A window's result does not depend on the batch it is solved in (bitwise).
+ * All windows of a batch share one landmark parametrisation (inv_depth); calibrations / extrinsics may differ. */
+ov2_status ov2_ba_solve_batch(ov2_ctx *ctx, int B, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
 
 /* ---------------------------------------------------------------------------------------------------
  * Motion-only BA (pose refinement on fixed 3D points).

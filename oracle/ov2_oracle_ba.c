@@ -726,19 +726,26 @@ static void log_iter(ov2_ba_result *R, double cost, double change, double radius
     it->model_cost_change = model; it->step_is_valid = valid; it->step_is_successful = ok;
 }
 
+/* eval_pose / eval_lm receive the state of the LAST residual evaluation (ResidualBlock::Evaluate -> the cost functors'
+ * cached chi2err_ / isdepthpositive_, src/ceres_parametrization.cpp:136-146): x after IterationZero or an accepted step,
+ * the candidate after a rejected step or a FTOL / PTOL exit (trust_region_minimizer.cc:108-131; Ceres does not
+ * re-evaluate after Solve).  The reference flags outliers from those cached values (src/optimizer.cpp:500-592). */
 static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const uint8_t *active, int use_loss,
-                    const ov2_ba_options *o, int max_iters, ov2_ba_result *R, double *initial_cost, double *final_cost)
+                    const ov2_ba_options *o, int max_iters, ov2_ba_result *R, double *initial_cost, double *final_cost,
+                    double *eval_pose, double *eval_lm)
 {
     prog g;
     prog_build(&g, P, active, use_loss, o->huber_delta);
     const int e = g.e, nc = g.ncols, ne = g.n_e * e;
     int term = OV2_BA_TERM_MAX_ITER;
+    const size_t npose = (size_t)P->n_pose * 7, nlm = (size_t)P->n_lm * e;
+    memcpy(eval_pose, poses, sizeof(double) * npose);
+    memcpy(eval_lm, lms, sizeof(double) * nlm);
     if (g.n_act == 0 || nc == 0) {
         *initial_cost = *final_cost = 0.0;
         prog_free(&g);
         return OV2_BA_TERM_SKIPPED;
     }
-    const size_t npose = (size_t)P->n_pose * 7, nlm = (size_t)P->n_lm * e;
     double *xp = (double *)malloc(sizeof(double) * npose), *xl = (double *)malloc(sizeof(double) * (nlm ? nlm : 1));
     double *cp = (double *)malloc(sizeof(double) * npose), *cl = (double *)malloc(sizeof(double) * (nlm ? nlm : 1));
     double *scale = (double *)malloc(sizeof(double) * nc), *grad = (double *)malloc(sizeof(double) * nc);
@@ -825,6 +832,8 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
         for (int k = 0; k < nc; ++k) delta[k] = step[k] * scale[k];
         prog_plus(&g, xp, xl, delta, cp, cl);
         const double cand_cost = prog_evaluate(&g, cp, cl, 0);
+        memcpy(eval_pose, cp, sizeof(double) * npose);   /* the functors now hold the candidate's chi2 / depth sign */
+        memcpy(eval_lm, cl, sizeof(double) * nlm);
         /* ParameterToleranceReached */
         const double step_norm = sqrt(prog_xnorm2_diff(&g, xp, xl, cp, cl));
         if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { term = OV2_BA_TERM_PTOL; break; }
@@ -840,7 +849,7 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
             memcpy(xp, cp, sizeof(double) * npose);
             memcpy(xl, cl, sizeof(double) * nlm);
             x_norm = sqrt(prog_xnorm2_diff(&g, xp, xl, NULL, NULL));
-            x_cost = prog_evaluate(&g, xp, xl, 1);
+            x_cost = prog_evaluate(&g, xp, xl, 1);   /* same point as the candidate just evaluated */
             prog_colnorm_grad(&g, tmp, grad);
             if (o->jacobi_scaling) prog_scale_columns(&g, scale);
             gmax = 0.0;
@@ -924,18 +933,21 @@ int ov2o_ba_solve(const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_resul
     R->l2_initial_cost = R->l2_final_cost = 0.0; R->l2_termination = OV2_BA_TERM_SKIPPED;
     if (R->outlier) memset(R->outlier, 0, (size_t)P->n_res);
     const int use_loss = o->huber_delta > 0.0;
-    R->termination = minimize(P, P->pose, P->lm, active, use_loss, o, o->max_iters, R, &R->initial_cost, &R->final_cost);
+    const int e = P->inv_depth ? 1 : 3;
+    double *ep = (double *)malloc(sizeof(double) * ((size_t)P->n_pose * 7 + 1));
+    double *el = (double *)malloc(sizeof(double) * ((size_t)P->n_lm * e + 1));
+    R->termination = minimize(P, P->pose, P->lm, active, use_loss, o, o->max_iters, R, &R->initial_cost, &R->final_cost, ep, el);
     R->n_log_robust = R->n_log;
     int n_left, n_right;
-    R->n_outliers_pass1 = flag_outliers(P, P->pose, P->lm, active, o, R, 1, &n_left, &n_right);
+    R->n_outliers_pass1 = flag_outliers(P, ep, el, active, o, R, 1, &n_left, &n_right);
     if (o->l2_refine && use_loss && R->n_outliers_pass1 > 0) {
         /* loss dropped only if both the left and the right list are non-empty (src/optimizer.cpp:606-608) */
         const int keep_loss = !(n_left > 0 && n_right > 0);
         R->l2_termination = minimize(P, P->pose, P->lm, active, keep_loss, o, o->l2_max_iters, R, &R->l2_initial_cost,
-                                     &R->l2_final_cost);
+                                     &R->l2_final_cost, ep, el);
         R->l2_done = 1;
-        R->n_outliers_pass2 = flag_outliers(P, P->pose, P->lm, active, o, R, 2, &n_left, &n_right);
+        R->n_outliers_pass2 = flag_outliers(P, ep, el, active, o, R, 2, &n_left, &n_right);
     }
-    free(active);
+    free(active); free(ep); free(el);
     return 0;
 }

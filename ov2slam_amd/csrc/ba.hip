@@ -3,10 +3,18 @@
 // Replaces (reference, /root/reference): the ceres::Solve + chi2 flagging + L2 re-solve inside
 // Optimizer::localBA src/optimizer.cpp:439-735, with the cost functors of src/ceres_parametrization.cpp:107-709
 // and the Ceres 2.0.0 trust-region/LM/Schur semantics restated in oracle/ov2_oracle_ba.c.
-// The host (this file, bottom) keeps Ceres' control flow -- radius update, accept/reject, tolerances -- and syncs
-// once per LM iteration on a handful of scalars; every O(residuals) / O(landmarks) / O(poses^3) step is a kernel.
+// BATCHED: one call solves B independent windows (ov2_ba_solve_batch; ov2_ba_solve is B = 1).  The windows are laid end
+// to end -- residual blocks, landmarks and poses get global indices, rows stay sorted by (landmark, pose) so every
+// window owns a contiguous range of rows / landmark blocks / pose blocks -- and every O(residuals) / O(landmarks) kernel
+// is simply a larger grid.  What is per window: the reduced camera system S_w (its own dense block of the S pool, its
+// own Cholesky workgroup), the scalar reductions (cost, model change, norms) and the WHOLE trust-region state machine
+// of Ceres -- radius update, accept / reject, tolerances -- which lives in a device-side record per window (ba_win)
+// and is advanced by single-thread epilogues of the per-window reduction kernels.  The host enqueues the fixed launch
+// chain of max_iters LM rounds without a single synchronisation; a window that has terminated is skipped by every
+// kernel.  A window's arithmetic does not depend on which other windows share the batch: its reductions run over its
+// own ranges in a fixed order, so the result of window w is bitwise the same for B = 1 and B = 64.
 //
-// HBM layout (one workspace per solve, reused across calls through the ctx):
+// HBM layout (one workspace per batch, reused across calls through the ctx):
 //   rows (= residual blocks) sorted by (landmark, observing pose), SoA: type / pose / landmark / F-block ids /
 //   measurement; per row storage of the robustified, Jacobi-scaled jacobian: res[2], Je[2e], Jf[2 cells][2x6]
 //   landmark CSR row_ptr[n_e+1]; S (reduced camera system) dense column-major m x m (m = 6 * free poses), lower
@@ -37,11 +45,42 @@ namespace {
 enum { K_EVAL = OV2_K_BA_FIRST, K_COLNORM, K_SCALE, K_LMDIAG, K_SINIT, K_SCHUR, K_CHOL, K_BACKSUB, K_PLUS, K_FLAG,
        K_REDUCE, K_MISC };
 
+struct ba_wconst { double Kl[4], Kr[4], Rrl[9], trl[3]; };   // per window: calibrations + right<-left extrinsic
+
+// Device-side record of one window: its ranges in the batch-wide arrays and the state of Ceres' TrustRegionMinimizer
+// (trust_region_minimizer.cc) + LevenbergMarquardtStrategy (levenberg_marquardt_strategy.cc) for it.
+struct ba_win {
+    int row0, row1;      // sorted rows
+    int e0, e1;          // landmark blocks of the reduced program
+    int f0, f1;          // pose blocks of the reduced program
+    int vb0, vb1;        // virtual 256-row blocks (cost partials)
+    int m;               // 6 * (f1 - f0)
+    int skip;            // not part of this program (second solve of a window that needs no L2 refinement)
+    long long S_off;     // doubles into the S pool
+    // trust-region state
+    double radius, decrease_factor, x_cost, x_norm, gmax, minimum_cost, initial_cost;
+    double model_change, cand_cost;
+    int iteration, invalid_steps, reuse_diagonal, refresh_diag, last_ok;
+    int active;          // takes part in the current round
+    int valid;           // the round's step is valid: Plus + candidate evaluation run
+    int accepted;        // the round's step was accepted: copy, jacobian at the new x
+    int done, termination, use_loss, max_iters;
+    int eval_at_cand;    // the last residual evaluation of this window happened at the candidate (chi2 flags are read there)
+    int chol_fail;
+    int nbad, n_left, n_right;   // ba_flag tallies of the current pass
+    int n_log;
+    ov2_ba_iter log[OV2_BA_MAX_LOG];
+};
+
 struct ba_dev {
-    // problem constants
-    double Kl[4], Kr[4], Rrl[9], trl[3];
-    int e;               // landmark block size 1 | 3
-    int n_rows, n_e, n_f, n_pose, n_lm, m, nc;
+    int e;               // landmark block size 1 | 3 (one parametrisation per batch)
+    int B;               // windows
+    int n_rows, n_e, n_f, n_pose, n_lm, m, nc;   // batch totals (m = 6 * n_f)
+    ba_win *W;
+    const ba_wconst *wc;
+    const int *row_win, *win_of_e, *win_of_f;     // window of a sorted row / landmark block / pose block
+    const int *vb_start;                          // B + 1: first virtual block of every window
+    double *Spool;
     // rows (sorted)
     const unsigned char *type;
     const int *pose, *lm, *anch;   // global pose / landmark / anchor-pose indices (anch = -1 for XYZ)
@@ -53,13 +92,14 @@ struct ba_dev {
     double *res, *Je, *Jf;
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
-    double *S, *rhs, *iete, *ieg;
+    double *rhs, *iete, *ieg;
     double *part;        // partial sums (max(n_rows blocks, n_e, n_f + n_e))
-    double *scal;        // scalar slots
-    int *flags;          // [0] cholesky failure
 };
 
-enum { SC_COST = 0, SC_CAND_COST, SC_MODEL, SC_STEP2, SC_XNORM2, SC_GMAX_LM, SC_N };
+struct ba_lmopt {   // the solver options the device-side state machine needs
+    double min_d, max_d, max_radius, min_radius, min_rel, ptol, gtol, ftol;
+    int max_invalid, jacobi;
+};
 
 // ------------------------------------------------------------------------------------------------------
 // SE3 helpers (same formulas as the oracle / Sophus / Eigen)
@@ -145,19 +185,19 @@ struct row_eval {
 };
 
 template <bool JAC>
-__device__ inline void eval_row(const ba_dev &d, const double *__restrict__ poses, const double *__restrict__ lms,
-                                int row, row_eval &o)
+__device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const double *__restrict__ poses,
+                                const double *__restrict__ lms, int row, row_eval &o)
 {
     const int type = d.type[row], l = d.lm[row];
     const double inv_sigma = d.inv_sigma[row];
     const bool is_right = (type == OV2_BA_R_XYZ || type == OV2_BA_R_INV || type == OV2_BA_RANCH_INV);
     const bool inv = (type >= OV2_BA_L_INV);
-    const double *K = is_right ? d.Kr : d.Kl;
+    const double *K = is_right ? wc.Kr : wc.Kl;
     double wpt[3] = {0, 0, 0}, anchpt[3] = {0, 0, 0}, Rwa[9], zanch = 0.0;
     if (inv) {
         zanch = 1.0 / lms[l];
-        anchpt[0] = zanch * ((d.auv[2 * row] - d.Kl[2]) / d.Kl[0]);
-        anchpt[1] = zanch * ((d.auv[2 * row + 1] - d.Kl[3]) / d.Kl[1]);
+        anchpt[0] = zanch * ((d.auv[2 * row] - wc.Kl[2]) / wc.Kl[0]);
+        anchpt[1] = zanch * ((d.auv[2 * row + 1] - wc.Kl[3]) / wc.Kl[1]);
         anchpt[2] = zanch;
         if (type != OV2_BA_RANCH_INV) {
             double twa[3];
@@ -171,8 +211,8 @@ __device__ inline void eval_row(const ba_dev &d, const double *__restrict__ pose
     double cam[3], M[9];
     if (type == OV2_BA_RANCH_INV) {
         for (int r = 0; r < 3; ++r)
-            cam[r] = (d.Rrl[3 * r] * anchpt[0] + d.Rrl[3 * r + 1] * anchpt[1] + d.Rrl[3 * r + 2] * anchpt[2]) + d.trl[r];
-        for (int i = 0; i < 9; ++i) M[i] = d.Rrl[i];
+            cam[r] = (wc.Rrl[3 * r] * anchpt[0] + wc.Rrl[3 * r + 1] * anchpt[1] + wc.Rrl[3 * r + 2] * anchpt[2]) + wc.trl[r];
+        for (int i = 0; i < 9; ++i) M[i] = wc.Rrl[i];
     } else {
         double Rwc[9], twc[3], lcam[3];
         pose_Rt(poses + 7 * d.pose[row], Rwc, twc);
@@ -180,11 +220,11 @@ __device__ inline void eval_row(const ba_dev &d, const double *__restrict__ pose
         for (int r = 0; r < 3; ++r) lcam[r] = Rwc[r] * dd[0] + Rwc[3 + r] * dd[1] + Rwc[6 + r] * dd[2];
         if (is_right) {
             for (int r = 0; r < 3; ++r)
-                cam[r] = (d.Rrl[3 * r] * lcam[0] + d.Rrl[3 * r + 1] * lcam[1] + d.Rrl[3 * r + 2] * lcam[2]) + d.trl[r];
+                cam[r] = (wc.Rrl[3 * r] * lcam[0] + wc.Rrl[3 * r + 1] * lcam[1] + wc.Rrl[3 * r + 2] * lcam[2]) + wc.trl[r];
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 3; ++c) {
                     double s = 0;
-                    for (int k = 0; k < 3; ++k) s += d.Rrl[3 * r + k] * Rwc[3 * c + k];
+                    for (int k = 0; k < 3; ++k) s += wc.Rrl[3 * r + k] * Rwc[3 * c + k];
                     M[3 * r + c] = s;
                 }
         } else {
@@ -268,18 +308,49 @@ __device__ inline double block_sum_256(double v, double *sh)
 #define BA_WAVE_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
+// window that owns virtual block b: the last w with vb_start[w] <= b (windows without rows own no block)
+__device__ __forceinline__ int win_of_vblock(const int *__restrict__ vb_start, int B, int b)
+{
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (vb_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// which windows a launch works for
+enum { EV_ZERO = 0,   // iteration zero: every window of the program
+       EV_CAND = 1,   // candidate evaluation: windows whose round produced a valid step
+       EV_ACC = 2 };  // jacobian at the new x: windows whose step was accepted
+
+__device__ __forceinline__ bool win_runs(const ba_win &W, int mode)
+{
+    return mode == EV_ZERO ? !W.skip : (mode == EV_CAND ? (W.active && W.valid) : W.accepted != 0);
+}
+
+// workgroup b covers 256 rows of ONE window (virtual blocks: a window with r rows owns ceil(r / 256) of them), so the
+// cost partial part[b] belongs to one window and a window's partials are summed in the order a lone solve would use
 template <bool JAC, int E>
 __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
-                                                      const double *__restrict__ lms, int use_loss, double huber_a,
-                                                      int apply_scale, double *__restrict__ part)
+                                                      const double *__restrict__ lms, int mode, double huber_a, int jacobi,
+                                                      double *__restrict__ part)
 {
     BA_WAVE_PRIO();
     __shared__ double sh[256];
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int sw;
+    if (threadIdx.x == 0) sw = win_of_vblock(d.vb_start, d.B, blockIdx.x);
+    __syncthreads();
+    const int w = sw;
+    const ba_win &W = d.W[w];
+    if (!win_runs(W, mode)) return;   // workgroup-uniform
+    const int row = W.row0 + ((int)blockIdx.x - W.vb0) * 256 + (int)threadIdx.x;
+    const int use_loss = W.use_loss;
+    const int apply_scale = (mode == EV_ACC) ? jacobi : 0;   // iteration zero scales after the column norms are known
     double c = 0.0;
-    if (row < d.n_rows) {
+    if (row < W.row1) {
         row_eval ev;
-        eval_row<JAC>(d, poses, lms, row, ev);
+        eval_row<JAC>(d, d.wc[w], poses, lms, row, ev);
         double rho[3] = {ev.chi2, 1.0, 0.0};
         if (use_loss) huber(huber_a, ev.chi2, rho);
         c = 0.5 * rho[0];
@@ -338,50 +409,212 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
-// ordered sum of n doubles by ONE workgroup of 256 threads -> out[0] (sign * sum)
-__global__ __launch_bounds__(256) void ba_reduce_kernel(const double *__restrict__ in, int n, double *__restrict__ out,
-                                                        double sign)
+// ordered sum of in[0..n) by the 256 threads of a workgroup (thread t takes t, t + 256, ...; then the tree)
+__device__ __forceinline__ double ordered_sum(const double *__restrict__ in, int n, double *sh)
 {
-    __shared__ double sh[256];
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += in[i];
     const double tot = block_sum_256(v, sh);
-    if (threadIdx.x == 0) out[0] = sign * tot;
+    __syncthreads();
+    return tot;
 }
 
-__global__ void ba_copy2_kernel(double *__restrict__ d1, const double *__restrict__ s1, size_t n1, double *__restrict__ d2,
-                                const double *__restrict__ s2, size_t n2)
+// ... of the concatenation a[0..na) | b[0..nb)
+__device__ __forceinline__ double ordered_sum2(const double *__restrict__ a, int na, const double *__restrict__ b, int nb,
+                                               double *sh)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n1) d1[i] = s1[i];
-    if (i < n2) d2[i] = s2[i];
-}
-
-// up to three ordered sums in one launch (workgroup k reduces array k)
-struct ba_red3 { const double *in[3]; int n[3]; double *out[3]; double sign[3]; };
-__global__ __launch_bounds__(256) void ba_reduce3_kernel(ba_red3 r)
-{
-    BA_WAVE_PRIO();
-    __shared__ double sh[256];
-    const int k = blockIdx.x;
     double v = 0.0;
-    for (int i = threadIdx.x; i < r.n[k]; i += 256) v += r.in[k][i];
+    for (int i = threadIdx.x; i < na + nb; i += 256) v += (i < na) ? a[i] : b[i - na];
     const double tot = block_sum_256(v, sh);
-    if (threadIdx.x == 0) r.out[k][0] = r.sign[k] * tot;
+    __syncthreads();
+    return tot;
 }
 
-__global__ __launch_bounds__(256) void ba_max_kernel(const double *__restrict__ in, int n, double *__restrict__ out)
+__device__ __forceinline__ double block_max_256(double v, double *sh)
 {
-    __shared__ double sh[256];
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v = fmax(v, fabs(in[i]));
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ inline void win_log(ba_win &W, double cost, double change, double radius, double rel, double model, int valid, int ok)
+{
+    if (W.n_log >= OV2_BA_MAX_LOG) return;
+    ov2_ba_iter *it = &W.log[W.n_log++];
+    it->cost = cost; it->cost_change = change; it->radius = radius; it->relative_decrease = rel;
+    it->model_cost_change = model; it->step_is_valid = valid; it->step_is_successful = ok;
+}
+
+// HandleInvalidStep (trust_region_minimizer.cc:562-580): StepIsInvalid == StepRejected for the LM strategy
+__device__ inline void win_invalid_step(ba_win &W, const ba_lmopt &o, double model_change)
+{
+    W.valid = 0;
+    if (++W.invalid_steps >= o.max_invalid) { W.termination = OV2_BA_TERM_FAILURE; W.done = 1; W.active = 0; return; }
+    W.radius /= W.decrease_factor; W.decrease_factor *= 2.0;
+    W.last_ok = 0;
+    win_log(W, W.x_cost, 0.0, W.radius, 0.0, model_change, 0, 0);
+}
+
+// FinalizeIterationAndCheckIfMinimizerCanContinue + the head of the next iteration (trust_region_minimizer.cc:104-131)
+__device__ inline void win_begin_round(ba_win &W, const ba_lmopt &o)
+{
+    W.active = 0; W.valid = 0; W.accepted = 0;
+    if (W.skip || W.done) return;
+    if (W.iteration >= W.max_iters) { W.termination = OV2_BA_TERM_MAX_ITER; W.done = 1; return; }
+    if (W.last_ok && W.gmax <= o.gtol) { W.termination = OV2_BA_TERM_GTOL; W.done = 1; return; }
+    if (W.radius <= o.min_radius) { W.termination = OV2_BA_TERM_MIN_RADIUS; W.done = 1; return; }
+    ++W.iteration;
+    W.active = 1;
+    W.refresh_diag = W.reuse_diagonal ? 0 : 1;   // LevenbergMarquardtStrategy::ComputeStep :76-89
+    W.reuse_diagonal = 1;
+    W.chol_fail = 0;
+}
+
+// Per-window reductions + the single-thread epilogues that advance the window's trust-region state.  One workgroup
+// per window; every sum runs over the window's own range in the order a lone solve uses.
+enum { WR_JAC = 0,     // after a jacobian evaluation (iteration zero, or the new x of an accepted step): cost, gradient
+                       // max-norm -> bookkeeping of the accepted step, then the head of the next round for EVERY window
+       WR_MODEL = 1,   // after the back-substitution: model cost change -> step validity
+       WR_CAND = 2 };  // after the candidate evaluation: |step|, |x+|, candidate cost -> tolerances, accept / reject
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ba_winreduce_kernel(ba_dev d, ba_lmopt o, const double *__restrict__ xp,
+                                                           const double *__restrict__ part_cost,
+                                                           const double *__restrict__ part_step,
+                                                           const double *__restrict__ part_norm,
+                                                           const double *__restrict__ part_model, int first,
+                                                           double initial_radius)
+{
+    BA_WAVE_PRIO();
+    __shared__ double sh[256];
+    const int w = blockIdx.x;
+    ba_win &W = d.W[w];
+    const int e = d.e;
+    if (MODE == WR_JAC) {
+        const bool fin = first ? !W.skip : (W.accepted != 0);   // workgroup-uniform
+        double cost = 0.0, gmax = 0.0;
+        if (fin) {
+            cost = ordered_sum(part_cost + W.vb0, W.vb1 - W.vb0, sh);
+            // gradient_max_norm = || x - Plus(x, -g) ||_inf with g the gradient of the UNSCALED problem (grad holds the
+            // scaled one): landmark blocks are additive, pose blocks go through the SE3 Plus
+            double v = 0.0;
+            for (int i = W.e0 * e + (int)threadIdx.x; i < W.e1 * e; i += 256)
+                v = fmax(v, fabs(o.jacobi ? d.grad[i] / d.scale[i] : d.grad[i]));
+            const int ne = d.n_e * e;
+            for (int f = W.f0 + (int)threadIdx.x; f < W.f1; f += 256) {
+                double dl[6], out7[7];
+                for (int k = 0; k < 6; ++k) {
+                    const int i = ne + f * 6 + k;
+                    dl[k] = -(o.jacobi ? d.grad[i] / d.scale[i] : d.grad[i]);
+                }
+                const double *x = xp + 7 * d.pose_of_f[f];
+                se3_plus(x, dl, out7);
+                for (int k = 0; k < 7; ++k) v = fmax(v, fabs(x[k] - out7[k]));
+            }
+            gmax = block_max_256(v, sh);
+        }
+        if (threadIdx.x == 0) {
+            if (fin) {
+                if (first) {   // IterationZero
+                    W.x_cost = cost; W.gmax = gmax;
+                    W.initial_cost = cost; W.minimum_cost = cost;
+                    W.x_norm = -1.0;            // Init(): "invalid value" until the first successful step
+                    W.radius = initial_radius; W.decrease_factor = 2.0;
+                    W.reuse_diagonal = 0; W.invalid_steps = 0; W.iteration = 0; W.last_ok = 1;
+                    W.done = 0; W.termination = OV2_BA_TERM_MAX_ITER; W.eval_at_cand = 0;
+                    win_log(W, cost, 0.0, W.radius, 0.0, 0.0, 1, 1);
+                } else {       // HandleSuccessfulStep: the jacobian at the new x is in place
+                    const double rel = W.cand_cost;   // WR_CAND parked the step's relative decrease / cost change here
+                    const double cost_change = W.x_cost - cost;
+                    W.x_cost = cost; W.gmax = gmax;
+                    const double t = 2.0 * rel - 1.0;
+                    W.radius = W.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);   // StepAccepted
+                    W.radius = fmin(o.max_radius, W.radius);
+                    W.decrease_factor = 2.0;
+                    W.reuse_diagonal = 0;
+                    W.last_ok = 1;
+                    W.eval_at_cand = 0;
+                    if (cost < W.minimum_cost) W.minimum_cost = cost;
+                    win_log(W, cost, cost_change, W.radius, rel, W.model_change, 1, 1);
+                }
+            }
+            win_begin_round(W, o);
+        }
+    } else if (MODE == WR_MODEL) {
+        if (!W.active) return;
+        const double msum = ordered_sum(part_model + W.e0, W.e1 - W.e0, sh);
+        if (threadIdx.x == 0) {
+            const double model_change = -msum;
+            W.model_change = model_change;
+            const bool valid = !W.chol_fail && isfinite(model_change) && model_change > 0.0;
+            if (valid) W.valid = 1;
+            else win_invalid_step(W, o, model_change);
+        }
+    } else {
+        if (!(W.active && W.valid)) return;
+        const int ne_w = W.e1 - W.e0, nf_w = W.f1 - W.f0;
+        const double step2 = ordered_sum2(part_step + W.e0, ne_w, part_step + d.n_e + W.f0, nf_w, sh);
+        const double xnorm2 = ordered_sum2(part_norm + W.e0, ne_w, part_norm + d.n_e + W.f0, nf_w, sh);
+        const double cand_cost = ordered_sum(part_cost + W.vb0, W.vb1 - W.vb0, sh);
+        if (threadIdx.x == 0) {
+            if (!isfinite(step2)) { win_invalid_step(W, o, W.model_change); return; }
+            W.invalid_steps = 0;
+            W.eval_at_cand = 1;   // the cost functors were last evaluated at the candidate
+            const double step_norm = sqrt(step2);
+            const double cost_change = W.x_cost - cand_cost;
+            if (step_norm <= o.ptol * (W.x_norm + o.ptol)) {            // ParameterToleranceReached
+                W.termination = OV2_BA_TERM_PTOL; W.done = 1; W.active = 0;
+            } else if (fabs(cost_change) <= o.ftol * W.x_cost) {        // FunctionToleranceReached: returns WITHOUT taking the candidate
+                W.termination = OV2_BA_TERM_FTOL; W.done = 1; W.active = 0;
+                win_log(W, W.x_cost, cost_change, W.radius, 0.0, W.model_change, 1, 0);
+            } else {
+                const double rel = isfinite(cand_cost) ? cost_change / W.model_change : -1e300;
+                if (rel > o.min_rel) {                                   // IsStepSuccessful
+                    W.accepted = 1;
+                    W.x_norm = sqrt(xnorm2);
+                    W.cand_cost = rel;                                   // read back by WR_JAC
+                } else {                                                 // HandleUnsuccessfulStep
+                    W.radius = W.radius / W.decrease_factor; W.decrease_factor *= 2.0;
+                    W.last_ok = 0;
+                    win_log(W, cand_cost, cost_change, W.radius, rel, W.model_change, 1, 0);
+                }
+            }
+        }
+    }
+}
+
+// x <- candidate for the windows whose step was accepted (whole window ranges: constant / unused blocks are equal in
+// both buffers).  win_of_pose / win_of_lm come from the window offsets by bisection.
+__device__ __forceinline__ int win_of_index(const int *__restrict__ off, int B, int i)
+{
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void ba_accept_kernel(ba_dev d, const int *__restrict__ pose_off,
+                                                        const int *__restrict__ lm_off, double *__restrict__ xp,
+                                                        const double *__restrict__ cp, double *__restrict__ xl,
+                                                        const double *__restrict__ cl)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.n_pose) {
+        if (d.W[win_of_index(pose_off, d.B, i)].accepted)
+            for (int k = 0; k < 7; ++k) xp[7 * i + k] = cp[7 * i + k];
+    }
+    if (i < d.n_lm) {
+        if (d.W[win_of_index(lm_off, d.B, i)].accepted)
+            for (int k = 0; k < d.e; ++k) xl[(size_t)i * d.e + k] = cl[(size_t)i * d.e + k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -409,38 +642,44 @@ __global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
     if (fa >= 0) for (int c = 0; c < 6; ++c) { const double s = d.scale[ne + fa * 6 + c]; Jf[12 + c] *= s; Jf[18 + c] *= s; }
 }
 
-// LevenbergMarquardtStrategy::ComputeStep :76-89
-// LM diagonal of every column (refreshed from the column norms after an accepted step) and, in the same launch,
-// S = diag(D_f^2), rhs = 0, flag = 0.  The S part recomputes the few D_f it needs instead of reading what other
-// threads of this launch write.
-__global__ void ba_lmdiag_sinit_kernel(ba_dev d, int refresh_diag, double min_d, double max_d, double radius)
+// LevenbergMarquardtStrategy::ComputeStep :76-89, per window (blockIdx.y)
+// LM diagonal of the window's columns (refreshed from the column norms after an accepted step) and, in the same launch,
+// S_w = diag(D_f^2), rhs_w = 0.  The S part recomputes the few D_f it needs instead of reading what other threads of
+// this launch write.
+__global__ void ba_lmdiag_sinit_kernel(ba_dev d, double min_d, double max_d)
 {
     BA_WAVE_PRIO();
+    const ba_win &W = d.W[blockIdx.y];
+    if (!W.active) return;
+    const int e = d.e, refresh_diag = W.refresh_diag;
+    const double radius = W.radius;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)d.nc) {
-        if (refresh_diag) d.diag[i] = fmin(fmax(d.sqn[i], min_d), max_d);
-        d.lmd[i] = sqrt(d.diag[i] / radius);
+    const int nce = (W.e1 - W.e0) * e, m = W.m;
+    if (i < (size_t)(nce + m)) {
+        const size_t col = i < (size_t)nce ? (size_t)W.e0 * e + i : (size_t)d.n_e * e + (size_t)W.f0 * 6 + (i - nce);
+        if (refresh_diag) d.diag[col] = fmin(fmax(d.sqn[col], min_d), max_d);
+        d.lmd[col] = sqrt(d.diag[col] / radius);
     }
-    const size_t mm = (size_t)d.m * d.m;
+    const size_t mm = (size_t)m * m;
     if (i < mm) {
-        const int r = (int)(i % d.m), c = (int)(i / d.m);
+        const int r = (int)(i % m), c = (int)(i / m);
         double v = 0.0;
         if (r == c) {
-            const int col = d.n_e * d.e + r;
+            const size_t col = (size_t)d.n_e * e + (size_t)W.f0 * 6 + r;
             const double dg = refresh_diag ? fmin(fmax(d.sqn[col], min_d), max_d) : d.diag[col];
             const double dv = sqrt(dg / radius);   // the same D the column's own thread stores in lmd
             v = dv * dv;
         }
-        d.S[i] = v;
+        d.Spool[W.S_off + i] = v;
     }
-    if (i < (size_t)d.m) d.rhs[i] = 0.0;
-    if (i == 0) d.flags[0] = 0;
+    if (i < (size_t)m) d.rhs[(size_t)W.f0 * 6 + i] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
 // shared device helpers of the landmark kernels (SchurEliminator::Eliminate, schur_eliminator_impl.h:179-308)
 
-#define BA_MAX_RUNS 40   // distinct free observing poses per landmark handled in registers/scratch per thread
+// Packed 64-bit sort keys with runtime field widths (every sort is a hipcub SortKeys over the bit range that matters; the
+// radix sort is stable, so whatever sits in the bits below the range rides along in its original order).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -483,11 +722,11 @@ __device__ __forceinline__ void invert_ete(const double *ete, double *ie)
 }
 
 // column norms + gradient of the landmark (E) columns: 16 lanes per landmark, no atomics
-__global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d)
+__global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
 {
     BA_WAVE_PRIO();
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    const bool live = l < d.n_e;
+    const bool live = l < d.n_e && win_runs(d.W[d.win_of_e[l]], mode);
     const int e = d.e;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
@@ -508,11 +747,12 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d)
 // pose -> (row, cell) CSR built on the host.  No atomics (the per-pose sums are the most contended addresses of the
 // whole solve), fixed summation order => bitwise reproducible.
 __global__ __launch_bounds__(256) void ba_colnorm_pose_kernel(ba_dev d, const int *__restrict__ pose_ptr,
-                                                              const int *__restrict__ pose_ent)
+                                                              const int *__restrict__ pose_ent, int mode)
 {
     BA_WAVE_PRIO();
     __shared__ double sh[4][12];
     const int f = blockIdx.x, tid = threadIdx.x;
+    if (!win_runs(d.W[d.win_of_f[f]], mode)) return;
     double acc[12];
     for (int c = 0; c < 12; ++c) acc[c] = 0.0;
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
@@ -553,7 +793,7 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
         if (gi < d.m) d.step[d.n_e * d.e + gi] = -d.rhs[gi];
     }
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    const bool live = l < d.n_e;
+    const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     double acc[E];
     for (int i = 0; i < E; ++i) acc[i] = 0.0;
@@ -606,11 +846,15 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
 // queue-scratch management -- measured: 12-30 ms per minimize() instead of 3)
 #define CHOL_THREADS 512
 template <int NB>
-__global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restrict__ A, double *__restrict__ rhs, int m,
-                                                       int *__restrict__ flags)
+__global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(ba_dev d)
 {
     BA_WAVE_PRIO();
     extern __shared__ __attribute__((aligned(16))) double lds[];   // the only LDS object of this kernel
+    ba_win &W = d.W[blockIdx.x];                                   // one workgroup per window
+    if (!W.active || W.m == 0) return;
+    double *__restrict__ A = d.Spool + W.S_off;
+    double *__restrict__ rhs = d.rhs + (size_t)W.f0 * 6;
+    const int m = W.m;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int M1 = m + 1;               // augmented row count (row m = right-hand side)
     constexpr int PS = NB + 1;          // panel row stride (bank spread)
@@ -729,7 +973,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(double *__restric
         __syncthreads();
     }
     if (*failp) {
-        if (tid == 0) flags[0] = 1;
+        if (tid == 0) W.chol_fail = 1;
         return;
     }
     __threadfence_block();
@@ -786,13 +1030,18 @@ typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
                              // m = 250 the 16 launches win 6 % on an idle GPU (3.28 -> 3.08 ms) but lose 9 % beside a busy
                              // front-end (332 vs 363 LM iterations/s: every dispatch queues), so the single launch stays there
 
-__global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ A, double *__restrict__ rhs,
-                                                           double *__restrict__ Dbuf, int m, int k0, int *__restrict__ flags)
+__global__ __launch_bounds__(64) void ba_chol_panel_kernel(ba_dev d, double *__restrict__ Dpool, size_t dstride, int k0)
 {
     BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
     __shared__ double LD[NB][NB + 1];
-    if (*(volatile int *)flags) return;
+    ba_win &W = d.W[blockIdx.y];   // window = blockIdx.y; the x grid is sized for the largest window
+    const int m = W.m;
+    if (!W.active || k0 >= m) return;
+    if (*(volatile int *)&W.chol_fail) return;
+    double *__restrict__ A = d.Spool + W.S_off;
+    double *__restrict__ rhs = d.rhs + (size_t)W.f0 * 6;
+    double *__restrict__ Dbuf = Dpool + (size_t)blockIdx.y * dstride;
     const int lane = threadIdx.x;
     const int nb = min(NB, m - k0);
     double row[NB];   // lane i: row i of the diagonal block (lower part), identity outside
@@ -813,7 +1062,7 @@ __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ 
         }
     }
     if (bad) {
-        if (blockIdx.x == 0 && lane == 0) flags[0] = 1;
+        if (blockIdx.x == 0 && lane == 0) W.chol_fail = 1;
         return;
     }
     if (lane < NB) {
@@ -853,12 +1102,16 @@ __global__ __launch_bounds__(64) void ba_chol_panel_kernel(double *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void ba_chol_syrk_kernel(double *__restrict__ A, double *__restrict__ rhs, int m, int k0,
-                                                          const int *__restrict__ flags)
+__global__ __launch_bounds__(64) void ba_chol_syrk_kernel(ba_dev d, int k0)
 {
     BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
-    if (*(volatile const int *)flags) return;
+    const ba_win &W = d.W[blockIdx.y];
+    const int m = W.m;
+    if (!W.active || k0 + NB >= m) return;
+    if (*(volatile const int *)&W.chol_fail) return;
+    double *__restrict__ A = d.Spool + W.S_off;
+    double *__restrict__ rhs = d.rhs + (size_t)W.f0 * 6;
     const int t0 = k0 + NB, t = m - t0;
     const int nt = (t + 15) / 16, ntile = nt * (nt + 1) / 2;
     const int lane = threadIdx.x, b = blockIdx.x;
@@ -899,14 +1152,18 @@ __global__ __launch_bounds__(64) void ba_chol_syrk_kernel(double *__restrict__ A
 // backward substitution L^T z = y after the panel kernels: panel by panel from the bottom, (1) every wave takes panel
 // columns and forms t_c = sum_{i below the panel} L[i][c] z[i] with coalesced column reads, (2) wave 0 solves the
 // nb x nb triangle with the block's columns (from the side buffer) in registers, pivots by v_readlane.  z in LDS.
-__global__ __launch_bounds__(256) void ba_chol_backward_kernel(const double *__restrict__ A, double *__restrict__ rhs,
-                                                              const double *__restrict__ Dbuf, int m,
-                                                              const int *__restrict__ flags)
+__global__ __launch_bounds__(256) void ba_chol_backward_kernel(ba_dev d, const double *__restrict__ Dpool, size_t dstride)
 {
     BA_WAVE_PRIO();
     constexpr int NB = CHOL_NB;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (*(volatile const int *)flags) return;
+    const ba_win &W = d.W[blockIdx.x];
+    const int m = W.m;
+    if (!W.active || m == 0) return;
+    if (*(volatile const int *)&W.chol_fail) return;
+    const double *__restrict__ A = d.Spool + W.S_off;
+    double *__restrict__ rhs = d.rhs + (size_t)W.f0 * 6;
+    const double *__restrict__ Dbuf = Dpool + (size_t)blockIdx.x * dstride;
     double *zb = lds, *tpart = lds + m;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
     for (int i = tid; i < m; i += nth) zb[i] = rhs[i];
@@ -950,6 +1207,10 @@ __global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__r
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int e = d.e, ne = d.n_e * e;
+    if (i < d.n_e + d.n_f) {
+        const ba_win &W = d.W[i < d.n_e ? d.win_of_e[i] : d.win_of_f[i - d.n_e]];
+        if (!(W.active && W.valid)) return;
+    }
     if (i < d.n_e) {
         const int l = d.lm_of_e[i];
         double s2 = 0, n2 = 0;
@@ -976,29 +1237,56 @@ __global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__r
     }
 }
 
-// K_FLAG: chi2 / depth at the given state, written at the ORIGINAL residual index; rows that fail the test leave the
-// device-side active set (the L2 program is rebuilt from it without the host)
-__global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__restrict__ poses,
-                                                      const double *__restrict__ lms, const int *__restrict__ rows,
-                                                      double chi2_th, double *__restrict__ chi2,
-                                                      unsigned char *__restrict__ depth, unsigned char *__restrict__ active)
+// K_FLAG: chi2 / depth flags of every row of the program, written at the ORIGINAL residual index.  The reference reads
+// the cost functors' cached chi2err_ / isdepthpositive_ (src/optimizer.cpp:500-592; src/ceres_parametrization.cpp:136-146),
+// i.e. the values of the LAST Evaluate() call, and Ceres does not re-evaluate after Solve: after an accepted last step that
+// is the final x, after a FTOL / PTOL exit or a rejected last step it is the candidate (trust_region_minimizer.cc:108-131).
+// Rows that fail the test leave the device-side active set (the L2 program is rebuilt from it without the host); the
+// per-window tallies drive the decision for the L2 refinement (src/optimizer.cpp:603-608).
+__global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__restrict__ xp, const double *__restrict__ xl,
+                                                      const double *__restrict__ cp, const double *__restrict__ cl,
+                                                      const int *__restrict__ rows, double chi2_th, int pass,
+                                                      double *__restrict__ chi2, unsigned char *__restrict__ depth,
+                                                      unsigned char *__restrict__ active, unsigned char *__restrict__ outlier)
 {
     BA_WAVE_PRIO();
     const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= d.n_rows) return;
-    row_eval ev;
-    eval_row<false>(d, poses, lms, row, ev);
-    const int i = rows[row];
-    chi2[i] = ev.chi2;
-    depth[i] = ev.depth_pos ? 1 : 0;
-    if (ev.chi2 > chi2_th || !ev.depth_pos) active[i] = 0;
-}
-
-__global__ void ba_unscale_grad_kernel(ba_dev d, int scaled)
-{
-    // gradient of the UNSCALED problem (tolerance test only): g = g_scaled / scale
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d.nc && scaled) d.grad[i] = d.grad[i] / d.scale[i];
+    const bool in = row < d.n_rows;
+    const int w = d.row_win[in ? row : d.n_rows - 1];
+    ba_win &W = d.W[w];
+    bool bad = false, left = false, right = false;
+    if (in) {
+        const bool at_cand = W.eval_at_cand != 0;
+        row_eval ev;
+        eval_row<false>(d, d.wc[w], at_cand ? cp : xp, at_cand ? cl : xl, row, ev);
+        const int i = rows[row];
+        chi2[i] = ev.chi2;
+        depth[i] = ev.depth_pos ? 1 : 0;
+        if (ev.chi2 > chi2_th || !ev.depth_pos) {
+            active[i] = 0;
+            outlier[i] = (unsigned char)pass;
+            bad = true;
+        } else {
+            const int t = d.type[row];
+            left = (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV);
+            right = (t == OV2_BA_R_XYZ || t == OV2_BA_R_INV);
+        }
+    }
+    // tallies: one atomic per wave and counter when the wave sits inside one window (the usual case)
+    const int w0 = __builtin_amdgcn_readfirstlane(w);
+    if (__ballot(w != w0) == 0ull) {
+        const int nb = __popcll(__ballot(bad)), nl = __popcll(__ballot(left)), nr = __popcll(__ballot(right));
+        if ((threadIdx.x & 63) == 0) {
+            ba_win &W0 = d.W[w0];
+            if (nb) atomicAdd(&W0.nbad, nb);
+            if (nl) atomicAdd(&W0.n_left, nl);
+            if (nr) atomicAdd(&W0.n_right, nr);
+        }
+    } else {
+        if (bad) atomicAdd(&W.nbad, 1);
+        if (left) atomicAdd(&W.n_left, 1);
+        if (right) atomicAdd(&W.n_right, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1009,156 +1297,205 @@ __global__ void ba_unscale_grad_kernel(ba_dev d, int scaled)
 // re-solve rebuilds from the device-side `active` flags without any host work.  (The host version of this walk took
 // 1.8 + 1.35 ms of the 8.9 ms solve at 128 k rows.)
 
-struct ba_raw {
+struct ba_raw {   // the B flat problems laid end to end; indices inside a window stay window-local
     const unsigned char *type; const int *pose, *lm; const double *uv, *sigma;   // per residual block (n_res)
     const int *lm_anch; const double *lm_auv;                                     // per landmark (inv-depth only)
     const unsigned char *pose_const;                                              // per pose
     unsigned char *active;                                                        // per residual block, device-owned
-    int n_res, n_lm, n_pose, inv_depth;
+    const int *res_off, *lm_off, *pose_off;                                       // B + 1 each: where a window starts
+    int B, n_res, n_lm, n_pose, inv_depth;                                        // batch totals
 };
 
-enum { BH_ROWS = 0, BH_NE, BH_NF, BH_RUNS, BH_ERR, BH_ENT, BH_N = 8 };
+typedef unsigned long long u64;
+enum { BH_ROWS = 0, BH_NE, BH_NF, BH_ERR, BH_ENT, BH_VB, BH_MMAX, BH_STOT, BH_PAIRCAP, BH_N = 12 };
+// sort keys of inactive residual blocks carry one bit above the live key bits: they sort behind every live key
 
-__global__ __launch_bounds__(256) void bb_mark_kernel(ba_raw R, int *__restrict__ used_lm, int *__restrict__ used_pose,
-                                                      int *__restrict__ hdr)
+__global__ __launch_bounds__(256) void bb_mark_kernel(ba_raw R, const ba_win *__restrict__ W, int *__restrict__ used_lm,
+                                                      int *__restrict__ used_pose, u64 *__restrict__ hdr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R.n_res || !R.active[i]) return;
+    const int w = win_of_index(R.res_off, R.B, i);
+    if (W[w].skip) return;
+    const int nl = R.lm_off[w + 1] - R.lm_off[w], np = R.pose_off[w + 1] - R.pose_off[w];
     const int t = R.type[i], l = R.lm[i], p = R.pose[i];
     int err = 0;
-    if (l < 0 || l >= R.n_lm) err = 1;
+    if (l < 0 || l >= nl) err = 1;
     else if (t > OV2_BA_RANCH_INV) err = 2;
     else if ((t >= OV2_BA_L_INV) != (R.inv_depth != 0)) err = 3;
-    else if (t != OV2_BA_RANCH_INV && (p < 0 || p >= R.n_pose)) err = 4;
-    else if (R.inv_depth && (R.lm_anch[l] < 0 || R.lm_anch[l] >= R.n_pose)) err = 5;
-    if (err) { atomicMax(&hdr[BH_ERR], (err << 24) | (i & 0xffffff)); return; }
-    used_lm[l] = 1;
-    if (t != OV2_BA_RANCH_INV && !R.pose_const[p]) used_pose[p] = 1;
-    if ((t == OV2_BA_L_INV || t == OV2_BA_R_INV) && !R.pose_const[R.lm_anch[l]]) used_pose[R.lm_anch[l]] = 1;
-}
-
-// exclusive ranks of the set flags: idx[i] = rank or -1, list[rank] = i, *count = number set.  One workgroup.
-__global__ __launch_bounds__(1024) void bb_rank_kernel(const int *__restrict__ flags, int n, int *__restrict__ idx,
-                                                       int *__restrict__ list, int *__restrict__ count)
-{
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int running = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const bool f = i < n && flags[i] != 0;
-        const unsigned long long m = __ballot(f);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = __popcll(m);
-        __syncthreads();
-        int off = 0, tot = 0;
-        for (int k = 0; k < 16; ++k) { if (k < wv) off += wsum[k]; tot += wsum[k]; }
-        if (i < n) idx[i] = f ? running + off + rank : -1;
-        if (f) list[running + off + rank] = i;
-        running += tot;
-        __syncthreads();
+    else if (t != OV2_BA_RANCH_INV && (p < 0 || p >= np)) err = 4;
+    else if (R.inv_depth && (R.lm_anch[R.lm_off[w] + l] < 0 || R.lm_anch[R.lm_off[w] + l] >= np)) err = 5;
+    if (err) { atomicMax(&hdr[BH_ERR], ((u64)err << 56) | ((u64)(unsigned)w << 32) | (u64)(unsigned)(i - R.res_off[w])); return; }
+    const int gl = R.lm_off[w] + l, gp = R.pose_off[w] + p;
+    used_lm[gl] = 1;
+    if (t != OV2_BA_RANCH_INV && !R.pose_const[gp]) used_pose[gp] = 1;
+    if (t == OV2_BA_L_INV || t == OV2_BA_R_INV) {
+        const int ga = R.pose_off[w] + R.lm_anch[gl];
+        if (!R.pose_const[ga]) used_pose[ga] = 1;
     }
-    if (tid == 0) *count = running;
 }
 
-// sort key of an active residual block: (landmark block, observing pose block + 1 (0 = anchor-camera residual), index)
-__global__ __launch_bounds__(256) void bb_keys_kernel(ba_raw R, const int *__restrict__ eidx, const int *__restrict__ fidx,
-                                                      unsigned long long *__restrict__ keys, int *__restrict__ hdr)
+// reduced numbering from the exclusive scans of the use flags: idx[i] = rank or -1, list[rank] = i
+__global__ __launch_bounds__(256) void bb_number_kernel(const int *__restrict__ used, const int *__restrict__ scan, int n,
+                                                        int *__restrict__ idx, int *__restrict__ list)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool f = used[i] != 0;
+    idx[i] = f ? scan[i] : -1;
+    if (f) list[scan[i]] = i;
+}
+
+// sort key of an active residual block: (landmark block | observing pose block + 1 (0 = anchor-camera residual) | index);
+// only the two upper fields are sorted, blocks with the same (landmark, pose) keep their original order (the two cameras
+// of one keyframe) and the index rides along
+__global__ __launch_bounds__(256) void bb_keys_kernel(ba_raw R, const ba_win *__restrict__ W, const int *__restrict__ eidx,
+                                                      const int *__restrict__ fidx, u64 *__restrict__ keys,
+                                                      u64 *__restrict__ hdr, int nbits, int fb, int dead_bit)
 {
     __shared__ int wsum[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool a = i < R.n_res && R.active[i] != 0;
-    unsigned long long k = ~0ull;
+    bool a = i < R.n_res && R.active[i] != 0;
+    u64 k = 1ull << dead_bit;
     if (a) {
-        const int t = R.type[i];
-        const int fkey = (t == OV2_BA_RANCH_INV) ? -1 : fidx[R.pose[i]];
-        k = ((unsigned long long)(unsigned)eidx[R.lm[i]] << 40) | ((unsigned long long)(unsigned)(fkey + 1) << 24) | (unsigned)i;
+        const int w = win_of_index(R.res_off, R.B, i);
+        if (W[w].skip) a = false;
+        else {
+            const int t = R.type[i];
+            const int fkey = (t == OV2_BA_RANCH_INV) ? -1 : fidx[R.pose_off[w] + R.pose[i]];
+            k = ((u64)(unsigned)eidx[R.lm_off[w] + R.lm[i]] << (fb + nbits)) | ((u64)(unsigned)(fkey + 1) << nbits) | (u64)(unsigned)i;
+        }
     }
     if (i < R.n_res) keys[i] = k;
-    const unsigned long long m = __ballot(a);
+    const u64 m = __ballot(a);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (tot) atomicAdd(&hdr[BH_ROWS], tot);
+        if (tot) atomicAdd(&hdr[BH_ROWS], (u64)tot);
     }
 }
 
 struct ba_prog_out {   // the writable twins of the const program arrays in ba_dev
-    unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa; double *uv, *isg, *auv; int *rows;
+    unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa; double *uv, *isg, *auv; int *rows, *row_win;
 };
 
-__global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const u64 *__restrict__ keys,
                                                       const int *__restrict__ eidx, const int *__restrict__ fidx,
-                                                      const int *__restrict__ hdr, ba_prog_out O)
+                                                      const u64 *__restrict__ hdr, ba_prog_out O, int nbits)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= hdr[BH_ROWS]) return;
-    const int i = (int)(keys[r] & 0xffffffull), t = R.type[i], l = R.lm[i];
+    if (r >= (int)hdr[BH_ROWS]) return;
+    const int i = (int)(keys[r] & ((1ull << nbits) - 1ull)), t = R.type[i];
+    const int w = win_of_index(R.res_off, R.B, i);
+    const int l = R.lm_off[w] + R.lm[i];                                     // batch-wide indices from here on
+    const int pk = (t == OV2_BA_RANCH_INV) ? -1 : R.pose_off[w] + R.pose[i];
+    const int pa = R.inv_depth ? R.pose_off[w] + R.lm_anch[l] : -1;
     O.rows[r] = i;
+    O.row_win[r] = w;
     O.type[r] = (unsigned char)t;
-    O.pose[r] = (t == OV2_BA_RANCH_INV) ? 0 : R.pose[i];
+    O.pose[r] = pk < 0 ? R.pose_off[w] : pk;
     O.lm[r] = l;
-    O.anch[r] = R.inv_depth ? R.lm_anch[l] : -1;
+    O.anch[r] = pa;
     O.eb[r] = eidx[l];
-    O.fk[r] = (t == OV2_BA_RANCH_INV) ? -1 : fidx[R.pose[i]];
-    O.fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[R.lm_anch[l]] : -1;
+    O.fk[r] = pk < 0 ? -1 : fidx[pk];
+    O.fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[pa] : -1;
     O.uv[2 * r] = R.uv[2 * i]; O.uv[2 * r + 1] = R.uv[2 * i + 1];
     O.isg[r] = 1.0 / (R.sigma ? R.sigma[i] : 1.0);
     O.auv[2 * r] = R.inv_depth ? R.lm_auv[2 * l] : 0.0;
     O.auv[2 * r + 1] = R.inv_depth ? R.lm_auv[2 * l + 1] : 0.0;
 }
 
-__global__ __launch_bounds__(256) void bb_rowptr_kernel(const int *__restrict__ eb, const int *__restrict__ hdr,
+__global__ __launch_bounds__(256) void bb_rowptr_kernel(const int *__restrict__ eb, const u64 *__restrict__ hdr,
                                                         int *__restrict__ row_ptr)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x, n = hdr[BH_ROWS];
+    const int r = blockIdx.x * 256 + threadIdx.x, n = (int)hdr[BH_ROWS];
     if (r >= n) return;
     if (r == 0 || eb[r] != eb[r - 1]) row_ptr[eb[r]] = r;   // every landmark block of the reduced program has a row
-    if (r == n - 1) row_ptr[hdr[BH_NE]] = n;
+    if (r == n - 1) row_ptr[(int)hdr[BH_NE]] = n;
 }
 
-__global__ __launch_bounds__(256) void bb_runs_kernel(const int *__restrict__ row_ptr, const int *__restrict__ fk,
-                                                      int *__restrict__ hdr)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= hdr[BH_NE]) return;
-    int runs = 0, cur = -2;
-    for (int r = row_ptr[k]; r < row_ptr[k + 1]; ++r)
-        if (fk[r] >= 0 && fk[r] != cur) { cur = fk[r]; ++runs; }
-    atomicMax(&hdr[BH_RUNS], runs);
-}
-
-// pose -> (row, cell) entries as sortable keys: (pose block, 2 * row + cell); unused slots sort to the end
+// pose -> (row, cell) entries: key = (pose block << 32) | (2 * row + cell), dead slots carry the bit above the pose
+// field; sorted on the pose field only, so the entries of a pose stay in row order
 __global__ __launch_bounds__(256) void bb_posekeys_kernel(const int *__restrict__ fk, const int *__restrict__ fa,
-                                                          const int *__restrict__ hdr, int n_cap,
-                                                          unsigned long long *__restrict__ pk)
+                                                          const u64 *__restrict__ hdr, int n_cap, u64 *__restrict__ pk, int fb)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_cap) return;
-    unsigned long long k0 = ~0ull, k1 = ~0ull;
-    if (r < hdr[BH_ROWS]) {
-        if (fk[r] >= 0) k0 = ((unsigned long long)(unsigned)fk[r] << 32) | (unsigned)(2 * r);
-        if (fa[r] >= 0) k1 = ((unsigned long long)(unsigned)fa[r] << 32) | (unsigned)(2 * r + 1);
+    const u64 dead = 1ull << (32 + fb);
+    u64 k0 = dead | (u64)(unsigned)(2 * r), k1 = dead | (u64)(unsigned)(2 * r + 1);
+    if (r < (int)hdr[BH_ROWS]) {
+        if (fk[r] >= 0) k0 = ((u64)(unsigned)fk[r] << 32) | (u64)(unsigned)(2 * r);
+        if (fa[r] >= 0) k1 = ((u64)(unsigned)fa[r] << 32) | (u64)(unsigned)(2 * r + 1);
     }
     pk[2 * r] = k0; pk[2 * r + 1] = k1;
 }
 
-__global__ __launch_bounds__(256) void bb_poseptr_kernel(const unsigned long long *__restrict__ pks, int n2,
-                                                         int *__restrict__ hdr, int *__restrict__ pose_ptr,
-                                                         int *__restrict__ pose_ent)
+__global__ __launch_bounds__(256) void bb_poseptr_kernel(const u64 *__restrict__ pks, int n2, u64 *__restrict__ hdr,
+                                                         int *__restrict__ pose_ptr, int *__restrict__ pose_ent, int fb)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n2) return;
-    const unsigned long long k = pks[j];
-    if (k == ~0ull) {
-        if (j == 0) { hdr[BH_ENT] = 0; pose_ptr[hdr[BH_NF]] = 0; }
+    const u64 k = pks[j] >> 32, dead = 1ull << fb;
+    if (k == dead) {
+        if (j == 0) { hdr[BH_ENT] = 0; pose_ptr[(int)hdr[BH_NF]] = 0; }
         return;
     }
-    const int f = (int)(k >> 32);
-    pose_ent[j] = (int)(k & 0xffffffffull);
-    if (j == 0 || (int)(pks[j - 1] >> 32) != f) pose_ptr[f] = j;   // every pose block of the reduced program has an entry
-    if (j + 1 == n2 || pks[j + 1] == ~0ull) { hdr[BH_ENT] = j + 1; pose_ptr[hdr[BH_NF]] = j + 1; }
+    pose_ent[j] = (int)(pks[j] & 0xffffffffull);
+    if (j == 0 || (pks[j - 1] >> 32) != k) pose_ptr[(int)k] = j;   // every pose block of the reduced program has an entry
+    if (j + 1 == n2 || (pks[j + 1] >> 32) == dead) { hdr[BH_ENT] = (u64)(j + 1); pose_ptr[(int)hdr[BH_NF]] = j + 1; }
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int *__restrict__ a, int n, int v)
+{   // first index with a[i] >= v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// window of every landmark / pose block of the reduced program
+__global__ __launch_bounds__(256) void bb_winfill_kernel(ba_raw R, const u64 *__restrict__ hdr, const int *__restrict__ lm_of_e,
+                                                         const int *__restrict__ pose_of_f, int *__restrict__ win_of_e,
+                                                         int *__restrict__ win_of_f)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, ne = (int)hdr[BH_NE], nf = (int)hdr[BH_NF];
+    if (k < ne) win_of_e[k] = win_of_index(R.lm_off, R.B, lm_of_e[k]);
+    if (k < nf) win_of_f[k] = win_of_index(R.pose_off, R.B, pose_of_f[k]);
+}
+
+// ranges of every window in the reduced program + the prefix sums that depend on them (virtual blocks, S pool).  One
+// workgroup; B is at most a few thousand.
+__global__ __launch_bounds__(256) void bb_winranges_kernel(ba_raw R, const int *__restrict__ escan, const int *__restrict__ fscan,
+                                                           const int *__restrict__ row_win, u64 *__restrict__ hdr,
+                                                           ba_win *__restrict__ W, int *__restrict__ vb_start)
+{
+    const int n_rows = (int)hdr[BH_ROWS];
+    for (int w = threadIdx.x; w < R.B; w += 256) {
+        ba_win &X = W[w];
+        X.e0 = escan[R.lm_off[w]]; X.e1 = escan[R.lm_off[w + 1]];
+        X.f0 = fscan[R.pose_off[w]]; X.f1 = fscan[R.pose_off[w + 1]];
+        X.row0 = lower_bound_i32(row_win, n_rows, w); X.row1 = lower_bound_i32(row_win, n_rows, w + 1);
+        X.m = 6 * (X.f1 - X.f0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int vb = 0, mmax = 0;
+        long long soff = 0, pcap = 0;
+        for (int w = 0; w < R.B; ++w) {
+            ba_win &X = W[w];
+            vb_start[w] = vb;
+            X.vb0 = vb; vb += (X.row1 - X.row0 + 255) / 256; X.vb1 = vb;
+            X.S_off = soff; soff += (long long)X.m * X.m;
+            const long long nf = X.f1 - X.f0;
+            pcap += nf * (nf + 1) / 2;
+            if (X.m > mmax) mmax = X.m;
+        }
+        vb_start[R.B] = vb;
+        hdr[BH_VB] = (u64)vb; hdr[BH_MMAX] = (u64)mmax; hdr[BH_STOT] = (u64)soff; hdr[BH_PAIRCAP] = (u64)pcap;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1200,8 +1537,8 @@ __global__ __launch_bounds__(256) void bs_count_kernel(ba_dev d, int *__restrict
 __global__ __launch_bounds__(256) void bs_cells_kernel(ba_dev d, const int *__restrict__ cell_ptr,
                                                        const int *__restrict__ pair_off, int *__restrict__ cell_f,
                                                        int *__restrict__ cell_row, int *__restrict__ cell_lm,
-                                                       unsigned long long *__restrict__ pkey,
-                                                       unsigned long long *__restrict__ ckey)
+                                                       u64 *__restrict__ pkey, int *__restrict__ pent,
+                                                       u64 *__restrict__ ckey, int fb, int pb)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= d.n_e) return;
@@ -1213,20 +1550,21 @@ __global__ __launch_bounds__(256) void bs_cells_kernel(ba_dev d, const int *__re
         if (d.fa[r] >= 0) fam = d.fa[r];
     }
     if (fam >= 0) { cell_f[c0 + c] = fam; cell_row[c0 + c] = -1; cell_lm[c0 + c] = l; ++c; }
-    for (int p = 0; p < nc; ++p) ckey[c0 + p] = ((unsigned long long)(unsigned)cell_f[c0 + p] << 32) | (unsigned)(c0 + p);
+    for (int p = 0; p < nc; ++p) ckey[c0 + p] = ((u64)(unsigned)cell_f[c0 + p] << 32) | (u64)(unsigned)(c0 + p);
     int o = pair_off[l];
     for (int p = 0; p < nc; ++p)
         for (int q = p + 1; q < nc; ++q, ++o) {
             const int fp = cell_f[c0 + p], fq = cell_f[c0 + q];
             const int hi = fp >= fq ? p : q, lo = fp >= fq ? q : p;   // cell of the larger pose block first
-            // (pose hi : 11 | pose lo : 11 | cell hi : 21 | cell lo : 21) -- one 64-bit key, so the sort needs no payload
-            pkey[o] = ((unsigned long long)(unsigned)cell_f[c0 + hi] << 53) | ((unsigned long long)(unsigned)cell_f[c0 + lo] << 42) |
-                      ((unsigned long long)(unsigned)(c0 + hi) << 21) | (unsigned long long)(unsigned)(c0 + lo);
+            // key = (pose hi | pose lo | entry index), sorted on the pose pair: a pair's entries stay in landmark order;
+            // the entry's two cells are looked up through its index
+            pkey[o] = ((((u64)(unsigned)cell_f[c0 + hi] << fb) | (u64)(unsigned)cell_f[c0 + lo]) << pb) | (u64)(unsigned)o;
+            pent[2 * (size_t)o] = c0 + hi; pent[2 * (size_t)o + 1] = c0 + lo;
         }
 }
 
 // boundaries of the pose-sorted cell list -> pcell_ptr (n_f + 1) and the cell ids
-__global__ __launch_bounds__(256) void bs_posecells_kernel(const unsigned long long *__restrict__ ck, int n, int n_f,
+__global__ __launch_bounds__(256) void bs_posecells_kernel(const u64 *__restrict__ ck, int n, int n_f,
                                                            int *__restrict__ pcell_ptr, int *__restrict__ pcell_ent)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -1238,21 +1576,21 @@ __global__ __launch_bounds__(256) void bs_posecells_kernel(const unsigned long l
 }
 
 // segment heads of the sorted pair list (a new pose pair starts) ...
-__global__ __launch_bounds__(256) void bs_heads_kernel(const unsigned long long *__restrict__ pk, int n, int *__restrict__ head)
+__global__ __launch_bounds__(256) void bs_heads_kernel(const u64 *__restrict__ pk, int n, int *__restrict__ head, int pb)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j > n) return;
-    head[j] = (j < n && (j == 0 || (pk[j] >> 42) != (pk[j - 1] >> 42))) ? 1 : 0;   // entry n = 0: its rank is the pair count
+    head[j] = (j < n && (j == 0 || (pk[j] >> pb) != (pk[j - 1] >> pb))) ? 1 : 0;   // entry n = 0: its rank is the pair count
 }
 
 // ... and, from their exclusive ranks, the start of every pair's segment (+ the end of the last one)
-__global__ __launch_bounds__(256) void bs_segs_kernel(const unsigned long long *__restrict__ pk, int n,
-                                                      const int *__restrict__ head, const int *__restrict__ rank,
-                                                      int *__restrict__ seg_start, unsigned *__restrict__ pair_key)
+__global__ __launch_bounds__(256) void bs_segs_kernel(const u64 *__restrict__ pk, int n, const int *__restrict__ head,
+                                                      const int *__restrict__ rank, int *__restrict__ seg_start,
+                                                      u64 *__restrict__ pair_key, int pb)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    if (head[j]) { seg_start[rank[j]] = j; pair_key[rank[j]] = (unsigned)(pk[j] >> 42); }
+    if (head[j]) { seg_start[rank[j]] = j; pair_key[rank[j]] = pk[j] >> pb; }
     if (j == n - 1) seg_start[rank[n]] = n;
 }
 
@@ -1263,7 +1601,7 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     BA_WAVE_PRIO();
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int l = blockIdx.x * 16 + grp;
-    const bool live = l < d.n_e;
+    const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     double ete[E * E], g[E];
     for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
@@ -1398,6 +1736,8 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
                                               const int *__restrict__ pcell_ent, int f, double (*red)[27])
 {
     const int tid = threadIdx.x;
+    const ba_win &Wn = d.W[d.win_of_f[f]];
+    if (!Wn.active) return;   // workgroup-uniform
     double acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = 0.0;
@@ -1433,8 +1773,9 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
     __syncthreads();
     if (tid < 27) {
         const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const int lf = f - Wn.f0;   // block index inside the window's own S
         if (tid >= 21) d.rhs[f * 6 + tid - 21] = v;                         // ba_sinit zeroed it; this is its only writer
-        else d.S[(size_t)(f * 6 + c_tri_j[tid]) * d.m + f * 6 + c_tri_i[tid]] += v;   // on top of the LM diagonal of ba_sinit
+        else d.Spool[Wn.S_off + (size_t)(lf * 6 + c_tri_j[tid]) * Wn.m + lf * 6 + c_tri_i[tid]] += v;   // on top of the LM diagonal of ba_sinit
     }
 }
 
@@ -1442,18 +1783,22 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
 // plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries.
 template <int E>
 __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C, int n_pairs,
-                                              const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
-                                              const unsigned long long *__restrict__ pk, int pidx)
+                                              const u64 *__restrict__ pair_key, const int *__restrict__ seg_start,
+                                              const u64 *__restrict__ pk, const int *__restrict__ pent, int fb, int pb,
+                                              int pidx)
 {
     const int lane = threadIdx.x & 63;
     if (pidx >= n_pairs) return;
-    const int hi = (int)(pair_key[pidx] >> 11), lo = (int)(pair_key[pidx] & 0x7ffu);
+    const int hi = (int)(pair_key[pidx] >> fb), lo = (int)(pair_key[pidx] & ((1ull << fb) - 1ull));
+    const ba_win &Wn = d.W[d.win_of_f[hi]];   // both pose blocks of a pair belong to one window
+    if (!Wn.active) return;
     double acc[36];   // element (i of hi, j of lo) at i + 6 j
 #pragma unroll
     for (int t = 0; t < 36; ++t) acc[t] = 0.0;
     const int s0 = seg_start[pidx], s1 = seg_start[pidx + 1];
     for (int q = s0 + lane; q < s1; q += 64) {
-        const int ch = (int)((pk[q] >> 21) & 0x1fffffull), cl = (int)(pk[q] & 0x1fffffull);
+        const size_t ent = (size_t)(pk[q] & ((1ull << pb) - 1ull));
+        const int ch = pent[2 * ent], cl = pent[2 * ent + 1];
         const double *Wh = C.W + (size_t)ch * 6 * E, *Wl = C.W + (size_t)cl * 6 * E;
         const double *ie = d.iete + (size_t)C.cell_lm[ch] * E * E;
         double T[6 * E];
@@ -1484,7 +1829,8 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
     for (int t = 0; t < 36; ++t) {
         const double v = wave_total(acc[t]);
         const int i = t % 6, j = t / 6;
-        if (lane == 0 && (hi != lo || i >= j)) d.S[(size_t)(lo * 6 + j) * d.m + hi * 6 + i] += v;
+        if (lane == 0 && (hi != lo || i >= j))
+            d.Spool[Wn.S_off + (size_t)((lo - Wn.f0) * 6 + j) * Wn.m + (hi - Wn.f0) * 6 + i] += v;
     }
 }
 
@@ -1494,13 +1840,13 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
 template <int E>
 __global__ __launch_bounds__(256) void bs_gather_kernel(ba_dev d, ba_cells C, const int *__restrict__ pcell_ptr,
                                                         const int *__restrict__ pcell_ent, const int *__restrict__ n_pairs,
-                                                        const unsigned *__restrict__ pair_key, const int *__restrict__ seg_start,
-                                                        const unsigned long long *__restrict__ pk)
+                                                        const u64 *__restrict__ pair_key, const int *__restrict__ seg_start,
+                                                        const u64 *__restrict__ pk, const int *__restrict__ pent, int fb, int pb)
 {
     BA_WAVE_PRIO();
     __shared__ double red[4][27];
     if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, pcell_ent, blockIdx.x, red);
-    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pk, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6));
+    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pk, pent, fb, pb, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1568,167 +1914,235 @@ ov2_status hcarve(ov2_ctx *c, size_t &off, T **host, const T **dev, size_t n)
 
 struct ba_solver {
     ov2_ctx *c;
-    const ov2_ba_problem *P;
+    int B;
+    const ov2_ba_problem *P;     // B problems
     const ov2_ba_options *o;
     size_t arena_off = 0;
     ba_dev d;
-    ba_raw raw;                  // the flat problem on the device (uploaded once per solve) + the active flags
-    size_t raw_end = 0;          // arena offset behind it: programs are (re)built from here
-    const int *rows = nullptr;   // device: sorted row -> original residual index
+    ba_raw raw;                  // the flat problems on the device (uploaded once per batch) + the active flags
+    size_t persist_end = 0;      // arena offset behind everything that lives for the whole batch: programs are (re)built from here
+    std::vector<int> res_off, lm_off, pose_off;   // host prefix sums (B + 1)
+    ba_win *W = nullptr;         // device window records
+    ba_wconst *wc = nullptr;
+    std::vector<ba_win> hW;      // host mirror of the window records (pageable; staged through the pinned block)
+    const int *rows = nullptr;   // device: sorted row -> batch-wide residual index
     // atomic-free Schur complement: cells, pose -> cells, pose pairs -> (cell, cell) entries (see the bs_* kernels)
     ba_cells cells;
     const int *pcell_ptr = nullptr, *pcell_ent = nullptr;
-    const int *n_pairs = nullptr, *seg_start = nullptr, *seg_len = nullptr;
-    const unsigned *pair_key = nullptr;
-    const unsigned long long *pair_val = nullptr;
-    int pair_cap = 0;
-    double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states
-    double *chold = nullptr;      // diagonal blocks of the Cholesky factor (multi-workgroup path)
+    const int *n_pairs = nullptr, *seg_start = nullptr;
+    const u64 *pair_key = nullptr, *pair_val = nullptr;   // pair_val: the sorted (pose pair | entry) keys
+    const int *pair_ent = nullptr;                        // entry -> its two cells
+    int fb = 1, pb = 1;                                   // bit widths of a pose block id / of a pair entry index in the packed keys
+    long long pair_cap = 0;
+    double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states (batch-wide)
+    double *chold = nullptr;      // diagonal blocks of the Cholesky factors (multi-workgroup path), one slab per window
+    size_t chold_stride = 0;
     double *chi2_dev = nullptr;
-    unsigned char *depth_dev = nullptr;
-    int eval_blocks = 0;
+    unsigned char *depth_dev = nullptr, *outlier_dev = nullptr;
+    int vblocks = 0, mmax = 0, cover_max = 0;
     const int *pose_ptr = nullptr, *pose_ent = nullptr;   // pose -> (row*2 + cell) CSR
-    std::vector<double> h_pose, h_lm;   // "parameters_": best state so far
-    std::vector<int> h_pose_of_f;
-
+    int n_res = 0, n_lm = 0, n_pose = 0, e = 1;           // batch totals
+    bool any_sigma = false;
 };
 
 #define BA_LAUNCH(S, id, ...) OV2_LAUNCH((S).c, id, __VA_ARGS__)
 
-// Uploads the flat problem (once per solve) into the head of the arena: one pinned staging copy + one H2D.
-ov2_status upload_raw(ba_solver &S)
+// Lays the B flat problems end to end in the PINNED mirror of the arena head and sends them with one copy (measured in
+// round 1: the same data in pageable vectors, ~15 copies of 0.5-2 MB, took 10-30 ms to arrive; the pinned single copy
+// ~0.3 ms for one window).  Indices stay window-local; the kernels add the window offsets.
+ov2_status upload_batch(ba_solver &S)
 {
     ov2_ctx *c = S.c;
-    const ov2_ba_problem *P = S.P;
-    const size_t n = (size_t)P->n_res, L = (size_t)P->n_lm, NP = (size_t)P->n_pose;
-    if (n >= (1u << 24)) return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "more than 2^24 residual blocks");
+    const int B = S.B;
+    const size_t n = (size_t)S.n_res, L = (size_t)S.n_lm, NP = (size_t)S.n_pose, e = (size_t)S.e;
     ov2_status s;
     S.arena_off = 0;
-    unsigned char *h_type, *h_pc; int *h_pose, *h_lm, *h_anch; double *h_uv, *h_sig, *h_auv;
+    unsigned char *h_type, *h_pc; int *h_pose, *h_lm, *h_anch, *h_ro, *h_lo, *h_po; double *h_uv, *h_sig, *h_auv, *h_xp, *h_xl;
+    ba_win *h_W; ba_wconst *h_wc;
     ba_raw &R = S.raw;
     memset(&R, 0, sizeof(R));
-    R.n_res = P->n_res; R.n_lm = P->n_lm; R.n_pose = P->n_pose; R.inv_depth = P->inv_depth ? 1 : 0;
-#define HC(field, hostp, count) if ((s = hcarve(c, S.arena_off, &hostp, &R.field, (size_t)(count))) != OV2_OK) return s
-    HC(type, h_type, n); HC(pose, h_pose, n); HC(lm, h_lm, n); HC(uv, h_uv, 2 * n); HC(sigma, h_sig, n);
-    HC(lm_anch, h_anch, L); HC(lm_auv, h_auv, 2 * L); HC(pose_const, h_pc, NP);
+    R.B = B; R.n_res = S.n_res; R.n_lm = S.n_lm; R.n_pose = S.n_pose; R.inv_depth = S.e == 1 ? 1 : 0;
+    const double *d_xp, *d_xl; const ba_win *d_W; const ba_wconst *d_wc;
+#define HC(devp, hostp, count) if ((s = hcarve(c, S.arena_off, &hostp, &devp, (size_t)(count))) != OV2_OK) return s
+    HC(R.type, h_type, n); HC(R.pose, h_pose, n); HC(R.lm, h_lm, n); HC(R.uv, h_uv, 2 * n);
+    if (S.any_sigma) { HC(R.sigma, h_sig, n); } else { R.sigma = nullptr; h_sig = nullptr; }
+    HC(R.lm_anch, h_anch, L); HC(R.lm_auv, h_auv, 2 * L); HC(R.pose_const, h_pc, NP);
+    HC(R.res_off, h_ro, B + 1); HC(R.lm_off, h_lo, B + 1); HC(R.pose_off, h_po, B + 1);
+    HC(d_xp, h_xp, 7 * NP); HC(d_xl, h_xl, e * L); HC(d_W, h_W, B); HC(d_wc, h_wc, B);
 #undef HC
-    memcpy(h_type, P->res_type, n);
-    memcpy(h_pose, P->res_pose, n * sizeof(int));
-    memcpy(h_lm, P->res_lm, n * sizeof(int));
-    memcpy(h_uv, P->res_uv, 2 * n * sizeof(double));
-    if (P->res_sigma) memcpy(h_sig, P->res_sigma, n * sizeof(double));
-    else R.sigma = nullptr;
-    if (P->inv_depth && L) {
-        memcpy(h_anch, P->lm_anchor_pose, L * sizeof(int));
-        memcpy(h_auv, P->lm_anchor_uv, 2 * L * sizeof(double));
+    for (int w = 0; w < B; ++w) {
+        const ov2_ba_problem &P = S.P[w];
+        const size_t r0 = (size_t)S.res_off[w], l0 = (size_t)S.lm_off[w], p0 = (size_t)S.pose_off[w];
+        const size_t nr = (size_t)P.n_res, nl = (size_t)P.n_lm, np = (size_t)P.n_pose;
+        if (nr) {
+            memcpy(h_type + r0, P.res_type, nr);
+            memcpy(h_pose + r0, P.res_pose, nr * sizeof(int));
+            memcpy(h_lm + r0, P.res_lm, nr * sizeof(int));
+            memcpy(h_uv + 2 * r0, P.res_uv, 2 * nr * sizeof(double));
+            if (h_sig) {
+                if (P.res_sigma) memcpy(h_sig + r0, P.res_sigma, nr * sizeof(double));
+                else for (size_t k = 0; k < nr; ++k) h_sig[r0 + k] = 1.0;
+            }
+        }
+        if (nl) {
+            if (P.inv_depth) {
+                memcpy(h_anch + l0, P.lm_anchor_pose, nl * sizeof(int));
+                memcpy(h_auv + 2 * l0, P.lm_anchor_uv, 2 * nl * sizeof(double));
+            }
+            memcpy(h_xl + e * l0, P.lm, e * nl * sizeof(double));
+        }
+        if (np) {
+            memcpy(h_pc + p0, P.pose_const, np);
+            memcpy(h_xp + 7 * p0, P.pose, 7 * np * sizeof(double));
+        }
+        ba_wconst &K = h_wc[w];
+        for (int i = 0; i < 4; ++i) { K.Kl[i] = P.calib_l[i]; K.Kr[i] = P.calib_r[i]; }
+        pose_Rt(P.T_rl, K.Rrl, K.trl);
     }
-    memcpy(h_pc, P->pose_const, NP);
+    memcpy(h_ro, S.res_off.data(), sizeof(int) * (B + 1));
+    memcpy(h_lo, S.lm_off.data(), sizeof(int) * (B + 1));
+    memcpy(h_po, S.pose_off.data(), sizeof(int) * (B + 1));
+    memcpy(h_W, S.hW.data(), sizeof(ba_win) * B);
     OV2_HIP(c, hipMemcpyAsync(c->ba_arena, c->ba_host, S.arena_off, hipMemcpyHostToDevice, c->stream));
+    S.xp = const_cast<double *>(d_xp); S.xl = const_cast<double *>(d_xl);
+    S.W = const_cast<ba_win *>(d_W); S.wc = const_cast<ba_wconst *>(d_wc);
+    // device-only arrays that live for the whole batch
     unsigned char *act = nullptr;
     if ((s = dalloc(c, S.arena_off, &act, n)) != OV2_OK) return s;
     R.active = act;
     OV2_HIP(c, hipMemsetAsync(act, 1, std::max<size_t>(n, 1), c->stream));
-    S.raw_end = S.arena_off;
+    if ((s = dalloc(c, S.arena_off, &S.cp, 7 * NP)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.cl, e * L)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.chi2_dev, n)) != OV2_OK) return s;       // indexed by batch-wide residual
+    if ((s = dalloc(c, S.arena_off, &S.depth_dev, n)) != OV2_OK) return s;
+    if ((s = dalloc(c, S.arena_off, &S.outlier_dev, n)) != OV2_OK) return s;
+    OV2_HIP(c, hipMemsetAsync(S.outlier_dev, 0, std::max<size_t>(n, 1), c->stream));
+    if (NP) OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, 7 * NP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (L) OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, e * L * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    S.persist_end = S.arena_off;
     return OV2_OK;
 }
 
-// Builds the reduced program of the currently active residual blocks on the device (see the bb_* kernels) and carves
-// the solver's work arrays behind it.  One small D2H + synchronisation tells the host the six sizes it needs.
+int bits_for(size_t v)
+{
+    int b = 1;
+    while (b < 63 && (1ull << b) <= v) ++b;
+    return b;
+}
+
+// Builds the reduced program of the currently active residual blocks of the windows that are not skipped (see the bb_*
+// kernels) and carves the solver's work arrays behind it.  Two small D2H + synchronisations tell the host the sizes.
 ov2_status build_program(ba_solver &S)
 {
     ov2_ctx *c = S.c;
-    const ov2_ba_problem *P = S.P;
     ba_dev &d = S.d;
     memset(&d, 0, sizeof(d));
-    const int e = P->inv_depth ? 1 : 3;
-    d.e = e;
-    for (int i = 0; i < 4; ++i) { d.Kl[i] = P->calib_l[i]; d.Kr[i] = P->calib_r[i]; }
-    pose_Rt(P->T_rl, d.Rrl, d.trl);
-    d.n_pose = P->n_pose; d.n_lm = P->n_lm;
+    const int e = S.e, B = S.B;
+    d.e = e; d.B = B;
+    d.n_pose = S.n_pose; d.n_lm = S.n_lm;
+    d.W = S.W; d.wc = S.wc;
     hipStream_t st = c->stream;
     const ba_raw &R = S.raw;
-    const int n = P->n_res, L = P->n_lm, NP = P->n_pose;
-    S.arena_off = S.raw_end;
+    const int n = S.n_res, L = S.n_lm, NP = S.n_pose;
+    S.arena_off = S.persist_end;
     ov2_status s;
-    // scratch of the build: flags, numbering, keys, header
-    int *used_lm, *used_pose, *eidx, *fidx, *lm_of_e, *pose_of_f, *hdr, *rows, *row_ptr, *pose_ptr, *pose_ent;
-    unsigned long long *keys, *keys2, *pk, *pk2;
+    int *used_lm, *used_pose, *escan, *fscan, *eidx, *fidx, *lm_of_e, *pose_of_f, *rows, *row_ptr, *pose_ptr, *pose_ent;
+    int *win_of_e, *win_of_f, *vb_start;
+    u64 *hdr, *keys, *keys2, *pk, *pk2;
     ba_prog_out O;
 #define AL(ptr, count) if ((s = dalloc(c, S.arena_off, &ptr, (size_t)(count))) != OV2_OK) return s
-    AL(hdr, BH_N); AL(used_lm, L); AL(used_pose, NP); AL(eidx, L); AL(fidx, NP); AL(lm_of_e, L); AL(pose_of_f, NP);
+    AL(hdr, BH_N); AL(used_lm, L + 1); AL(used_pose, NP + 1); AL(escan, L + 1); AL(fscan, NP + 1); AL(eidx, L); AL(fidx, NP);
+    AL(lm_of_e, L); AL(pose_of_f, NP); AL(win_of_e, L); AL(win_of_f, NP); AL(vb_start, B + 1);
     AL(keys, n); AL(keys2, n); AL(pk, 2 * (size_t)n); AL(pk2, 2 * (size_t)n);
     AL(O.type, n); AL(O.pose, n); AL(O.lm, n); AL(O.anch, n); AL(O.eb, n); AL(O.fk, n); AL(O.fa, n);
-    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.auv, 2 * (size_t)n); AL(O.rows, n);
+    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.auv, 2 * (size_t)n); AL(O.rows, n); AL(O.row_win, n);
     AL(row_ptr, L + 1); AL(pose_ptr, NP + 1); AL(pose_ent, 2 * (size_t)n);
     rows = O.rows;
-    size_t tmp1 = 0, tmp2 = 0;
+    // row keys: [landmark block : bits(L)] [pose block + 1 : fb] [residual index : nbits], one dead bit above
+    const int nbits = bits_for((size_t)n), fb = bits_for((size_t)NP + 1);
+    const int dead_bit = bits_for((size_t)L) + fb + nbits;
+    S.fb = fb;
+    if (dead_bit > 62)
+        return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large for the packed sort keys (%d residual blocks, %d landmarks, %d "
+                           "poses): split it", n, L, NP);
+    size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
     OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp1, keys, keys2, std::max(n, 1), 0, 64, st));
     OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp2, pk, pk2, std::max(2 * n, 1), 0, 64, st));
-    size_t tmp_bytes = std::max(tmp1, tmp2);
+    OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp3, used_lm, escan, std::max(L, NP) + 1, st));
+    size_t tmp_bytes = std::max(std::max(tmp1, tmp2), tmp3);
     unsigned char *tmp;
     AL(tmp, tmp_bytes + 256);
-    OV2_HIP(c, hipMemsetAsync(hdr, 0, sizeof(int) * BH_N, st));
-    OV2_HIP(c, hipMemsetAsync(used_lm, 0, sizeof(int) * std::max(L, 1), st));
-    OV2_HIP(c, hipMemsetAsync(used_pose, 0, sizeof(int) * std::max(NP, 1), st));
+    OV2_HIP(c, hipMemsetAsync(hdr, 0, sizeof(u64) * BH_N, st));
+    OV2_HIP(c, hipMemsetAsync(used_lm, 0, sizeof(int) * (L + 1), st));
+    OV2_HIP(c, hipMemsetAsync(used_pose, 0, sizeof(int) * (NP + 1), st));
+    if (n > 0) BA_LAUNCH(S, K_MISC, bb_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, R, S.W, used_lm, used_pose, hdr);
+    OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, used_lm, escan, L + 1, st));     // also for an empty batch:
+    OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, used_pose, fscan, NP + 1, st));  // the window ranges read them
     if (n > 0) {
         const dim3 gn((n + 255) / 256);
-        BA_LAUNCH(S, K_MISC, bb_mark_kernel, gn, dim3(256), 0, st, R, used_lm, used_pose, hdr);
-        BA_LAUNCH(S, K_MISC, bb_rank_kernel, dim3(1), dim3(1024), 0, st, used_lm, L, eidx, lm_of_e, hdr + BH_NE);
-        BA_LAUNCH(S, K_MISC, bb_rank_kernel, dim3(1), dim3(1024), 0, st, used_pose, NP, fidx, pose_of_f, hdr + BH_NF);
-        BA_LAUNCH(S, K_MISC, bb_keys_kernel, gn, dim3(256), 0, st, R, eidx, fidx, keys, hdr);
-        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys2, n, 0, 64, st));
-        BA_LAUNCH(S, K_MISC, bb_fill_kernel, gn, dim3(256), 0, st, R, keys2, eidx, fidx, hdr, O);
+        if (L) BA_LAUNCH(S, K_MISC, bb_number_kernel, dim3((L + 255) / 256), dim3(256), 0, st, used_lm, escan, L, eidx, lm_of_e);
+        if (NP) BA_LAUNCH(S, K_MISC, bb_number_kernel, dim3((NP + 255) / 256), dim3(256), 0, st, used_pose, fscan, NP, fidx, pose_of_f);
+        // hdr[BH_NE] / hdr[BH_NF] = the last scan entries
+        OV2_HIP(c, hipMemcpyAsync(hdr + BH_NE, escan + L, sizeof(int), hipMemcpyDeviceToDevice, st));
+        OV2_HIP(c, hipMemcpyAsync(hdr + BH_NF, fscan + NP, sizeof(int), hipMemcpyDeviceToDevice, st));
+        BA_LAUNCH(S, K_MISC, bb_keys_kernel, gn, dim3(256), 0, st, R, S.W, eidx, fidx, keys, hdr, nbits, fb, dead_bit);
+        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys2, n, nbits, dead_bit + 1, st));
+        BA_LAUNCH(S, K_MISC, bb_fill_kernel, gn, dim3(256), 0, st, R, keys2, eidx, fidx, hdr, O, nbits);
         BA_LAUNCH(S, K_MISC, bb_rowptr_kernel, gn, dim3(256), 0, st, O.eb, hdr, row_ptr);
-        BA_LAUNCH(S, K_MISC, bb_runs_kernel, dim3((L + 255) / 256), dim3(256), 0, st, row_ptr, O.fk, hdr);
-        BA_LAUNCH(S, K_MISC, bb_posekeys_kernel, gn, dim3(256), 0, st, O.fk, O.fa, hdr, n, pk);
-        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, pk, pk2, 2 * n, 0, 64, st));
-        BA_LAUNCH(S, K_MISC, bb_poseptr_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, pk2, 2 * n, hdr, pose_ptr, pose_ent);
+        BA_LAUNCH(S, K_MISC, bb_posekeys_kernel, gn, dim3(256), 0, st, O.fk, O.fa, hdr, n, pk, fb);
+        OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, pk, pk2, 2 * n, 32, 32 + fb + 1, st));
+        BA_LAUNCH(S, K_MISC, bb_poseptr_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, pk2, 2 * n, hdr, pose_ptr, pose_ent, fb);
+        BA_LAUNCH(S, K_MISC, bb_winfill_kernel, dim3((std::max(L, NP) + 255) / 256), dim3(256), 0, st, R, hdr, lm_of_e, pose_of_f,
+                  win_of_e, win_of_f);
     }
-    // the six integers + the pose blocks in use come back through the pinned mirror
-    int *h_hdr = (int *)c->ba_host;                     // the raw staging area is free again (its H2D was enqueued
-    int *h_pof = h_hdr + BH_N;                          // before these copies on the same stream)
-    OV2_HIP(c, hipMemcpyAsync(h_hdr, hdr, sizeof(int) * BH_N, hipMemcpyDeviceToHost, st));
-    if (NP > 0) OV2_HIP(c, hipMemcpyAsync(h_pof, pose_of_f, sizeof(int) * NP, hipMemcpyDeviceToHost, st));
+    BA_LAUNCH(S, K_MISC, bb_winranges_kernel, dim3(1), dim3(256), 0, st, R, escan, fscan, O.row_win, hdr, S.W, vb_start);
+    // sizes + the window ranges come back through the pinned mirror (its upload was enqueued before these copies)
+    u64 *h_hdr = (u64 *)c->ba_host;
+    ba_win *h_W = (ba_win *)(h_hdr + 32);
+    OV2_HIP(c, hipMemcpyAsync(h_hdr, hdr, sizeof(u64) * BH_N, hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipMemcpyAsync(h_W, S.W, sizeof(ba_win) * B, hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipStreamSynchronize(st));
     if (h_hdr[BH_ERR]) {
         static const char *what[] = {"", "landmark out of range", "unknown type", "type does not match inv_depth",
                                      "pose out of range", "anchor pose out of range"};
-        const int code = h_hdr[BH_ERR] >> 24;
-        return ov2_set_err(c, OV2_ERR_INVALID, "residual %d: %s", h_hdr[BH_ERR] & 0xffffff, what[code > 5 ? 0 : code]);
+        const int code = (int)(h_hdr[BH_ERR] >> 56);
+        return ov2_set_err(c, OV2_ERR_INVALID, "window %d, residual %d: %s", (int)((h_hdr[BH_ERR] >> 32) & 0xffffff),
+                           (int)(h_hdr[BH_ERR] & 0xffffffffu), what[code > 5 ? 0 : code]);
     }
-    d.n_rows = h_hdr[BH_ROWS]; d.n_e = h_hdr[BH_NE]; d.n_f = h_hdr[BH_NF];
-    S.h_pose_of_f.assign(h_pof, h_pof + d.n_f);
+    memcpy(S.hW.data(), h_W, sizeof(ba_win) * B);
+    d.n_rows = (int)h_hdr[BH_ROWS]; d.n_e = (int)h_hdr[BH_NE]; d.n_f = (int)h_hdr[BH_NF];
     d.m = 6 * d.n_f; d.nc = d.n_e * e + d.m;
-    if (h_hdr[BH_RUNS] > BA_MAX_RUNS)
-        return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "a landmark is observed by %d free keyframes (max %d)", h_hdr[BH_RUNS], BA_MAX_RUNS);
+    S.vblocks = (int)h_hdr[BH_VB]; S.mmax = (int)h_hdr[BH_MMAX];
+    const size_t s_tot = (size_t)h_hdr[BH_STOT];
+    const long long pair_cap_bound = (long long)h_hdr[BH_PAIRCAP];
+    S.cover_max = 1;
+    for (int w = 0; w < B; ++w) {
+        const ba_win &X = S.hW[w];
+        const long long cov = std::max<long long>((long long)(X.e1 - X.e0) * e + X.m, (long long)X.m * X.m);
+        if (cov > S.cover_max) S.cover_max = (int)std::min<long long>(cov, 0x7fffffff);
+    }
     d.type = O.type; d.pose = O.pose; d.lm = O.lm; d.anch = O.anch; d.eb = O.eb; d.fk = O.fk; d.fa = O.fa;
     d.uv = O.uv; d.inv_sigma = O.isg; d.auv = O.auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
+    d.row_win = O.row_win; d.win_of_e = win_of_e; d.win_of_f = win_of_f; d.vb_start = vb_start;
     S.rows = rows; S.pose_ptr = pose_ptr; S.pose_ent = pose_ent;
     const int nr = d.n_rows;
 #undef AL
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
     AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(Jf, 24 * (size_t)nr);
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
-    AL(S, (size_t)d.m * d.m); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
-    S.eval_blocks = (nr + 255) / 256;
-    AL(part, std::max<size_t>({(size_t)S.eval_blocks, (size_t)d.n_e + d.n_f, 1}) * 3 + 16);
-    AL(scal, SC_N + 2); AL(flags, 4);
+    AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
+    AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);   // |step|^2, |x+|^2, model change per block | cost partials per virtual block
 #undef AL
-    if ((s = dalloc(c, S.arena_off, &S.chold, (size_t)(d.m / CHOL_NB + 1) * CHOL_NB * CHOL_NB)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.chi2_dev, (size_t)n)) != OV2_OK) return s;     // indexed by ORIGINAL residual
-    if ((s = dalloc(c, S.arena_off, &S.depth_dev, (size_t)n)) != OV2_OK) return s;
-    const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * e;
-    if ((s = dalloc(c, S.arena_off, &S.xp, np)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.cp, np)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.xl, nl)) != OV2_OK) return s;
-    if ((s = dalloc(c, S.arena_off, &S.cl, nl)) != OV2_OK) return s;
+    S.chold_stride = (size_t)(S.mmax / CHOL_NB + 1) * CHOL_NB * CHOL_NB;
+    if ((s = dalloc(c, S.arena_off, &S.chold, S.chold_stride * B)) != OV2_OK) return s;
+    S.pair_cap = 0;
     if (d.n_rows == 0 || d.n_e == 0) return OV2_OK;
     // ---- structure of the atomic-free Schur complement (bs_* kernels)
     {
-        int *ncell, *npair, *cell_ptr, *pair_off, *h2;
+        int *ncell, *npair, *cell_ptr, *pair_off;
 #define AL2(ptr, count) if ((s = dalloc(c, S.arena_off, &ptr, (size_t)(count))) != OV2_OK) return s
 #define AL3(ptr, count) if ((s = dalloc2(c, off2, &ptr, (size_t)(count))) != OV2_OK) return s
-        AL2(ncell, d.n_e + 1); AL2(npair, d.n_e + 1); AL2(cell_ptr, d.n_e + 1); AL2(pair_off, d.n_e + 1); AL2(h2, 4);
+        AL2(ncell, d.n_e + 1); AL2(npair, d.n_e + 1); AL2(cell_ptr, d.n_e + 1); AL2(pair_off, d.n_e + 1);
         size_t tb = 0;
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ncell, cell_ptr, d.n_e + 1, st));
         unsigned char *tscan;
@@ -1741,21 +2155,25 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipMemcpyAsync(h_tot + 1, pair_off + d.n_e, sizeof(int), hipMemcpyDeviceToHost, st));
         OV2_HIP(c, hipStreamSynchronize(st));
         const int C_tot = h_tot[0], P_tot = h_tot[1];
-        if (d.n_f > 2047 || C_tot >= (1 << 21))
-            return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "window too large for the packed pair keys (%d free poses, %d cells)", d.n_f, C_tot);
-        int *cell_f, *cell_row, *cell_lm, *pcell_ptr, *pcell_ent, *seg_start, *head, *rank;
-        unsigned *ukey;
-        unsigned long long *pkey = nullptr, *pkey2 = nullptr, *ckey = nullptr, *ckey2 = nullptr;
+        if (C_tot < 0 || P_tot < 0)
+            return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large: more than 2^31 Schur cells or cell pairs");
+        int *cell_f, *cell_row, *cell_lm, *pcell_ptr, *pcell_ent, *seg_start, *head, *rank, *pent;
+        u64 *ukey, *pkey = nullptr, *pkey2 = nullptr, *ckey = nullptr, *ckey2 = nullptr;
         ba_cells &Cc = S.cells;
-        const int pair_cap = (int)std::min<long long>((long long)P_tot, (long long)d.n_f * (d.n_f + 1) / 2);
+        const long long pair_cap = std::min<long long>((long long)P_tot, pair_cap_bound);
+        const int fb = bits_for((size_t)d.n_f), pb = bits_for((size_t)P_tot);   // pair keys: [pose hi : fb] [pose lo : fb] [entry : pb]
+        S.fb = fb; S.pb = pb;
+        if (2 * fb + pb > 64)
+            return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large for the packed pair keys (%d free poses, %d cell pairs): split it",
+                               d.n_f, P_tot);
         size_t t1 = 0, t2 = 0, t4 = 0;
         OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, t1, pkey, pkey2, std::max(P_tot, 1), 0, 64, st));
         OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, t2, ckey, ckey2, std::max(C_tot, 1), 0, 64, st));
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
         size_t tbytes = std::max(std::max(t1, t2), t4);
         {   // the structure lives in its own block, sized now that the counts are known and kept across solves
-            const size_t need2 = (size_t)C_tot * (7 * 4 + 2 * 8 + (size_t)(6 * e + 63) * 8) + (size_t)P_tot * (2 * 8 + 2 * 4) +
-                                 (size_t)pair_cap * 8 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
+            const size_t need2 = (size_t)C_tot * (5 * 4 + 2 * 8 + (size_t)(6 * e + 63) * 8) + (size_t)P_tot * (2 * 8 + 4 * 4) +
+                                 (size_t)pair_cap * 12 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
             if (need2 > c->ba_arena2_cap) {
                 OV2_HIP(c, hipStreamSynchronize(st));
                 if (c->ba_arena2) OV2_HIP(c, hipFree(c->ba_arena2));
@@ -1770,7 +2188,7 @@ ov2_status build_program(ba_solver &S)
         AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot);
         AL3(Cc.W, (size_t)C_tot * 6 * e); AL3(Cc.FF, (size_t)C_tot * 21); AL3(Cc.FFa, (size_t)C_tot * 36); AL3(Cc.rhsc, (size_t)C_tot * 6);
         AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
-        AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
+        AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(pent, 2 * (size_t)P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
         AL3(ukey, pair_cap + 1); AL3(seg_start, pair_cap + 2);
         unsigned char *tsort;
         AL3(tsort, tbytes + 256);
@@ -1778,383 +2196,187 @@ ov2_status build_program(ba_solver &S)
 #undef AL2
         Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm;
         BA_LAUNCH(S, K_MISC, bs_cells_kernel, dim3((d.n_e + 255) / 256), dim3(256), 0, st, d, cell_ptr, pair_off, cell_f, cell_row,
-                  cell_lm, pkey, ckey);
+                  cell_lm, pkey, pent, ckey, fb, pb);
         if (C_tot > 0) {
-            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, ckey, ckey2, C_tot, 0, 64, st));
+            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, ckey, ckey2, C_tot, 32, 32 + fb, st));
             BA_LAUNCH(S, K_MISC, bs_posecells_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, ckey2, C_tot, d.n_f, pcell_ptr, pcell_ent);
         }
         if (P_tot > 0) {
-            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, pkey, pkey2, P_tot, 0, 64, st));
-            BA_LAUNCH(S, K_MISC, bs_heads_kernel, dim3((P_tot + 256) / 256), dim3(256), 0, st, pkey2, P_tot, head);
+            OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, pkey, pkey2, P_tot, pb, pb + 2 * fb, st));
+            BA_LAUNCH(S, K_MISC, bs_heads_kernel, dim3((P_tot + 256) / 256), dim3(256), 0, st, pkey2, P_tot, head, pb);
             OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tsort, tbytes, head, rank, P_tot + 1, st));
-            BA_LAUNCH(S, K_MISC, bs_segs_kernel, dim3((P_tot + 255) / 256), dim3(256), 0, st, pkey2, P_tot, head, rank, seg_start, ukey);
+            BA_LAUNCH(S, K_MISC, bs_segs_kernel, dim3((P_tot + 255) / 256), dim3(256), 0, st, pkey2, P_tot, head, rank, seg_start, ukey, pb);
         }
-        int *n_pairs = rank + P_tot;     // exclusive rank behind the last entry = number of pose pairs
-        int *seg_len = nullptr;
-        unsigned long long *pval2 = pkey2;
-        S.pcell_ptr = pcell_ptr; S.pcell_ent = pcell_ent; S.n_pairs = n_pairs; S.seg_start = seg_start; S.seg_len = seg_len;
-        S.pair_key = ukey; S.pair_val = pval2; S.pair_cap = P_tot > 0 ? pair_cap : 0;
+        S.pcell_ptr = pcell_ptr; S.pcell_ent = pcell_ent; S.n_pairs = rank + P_tot;   // exclusive rank behind the last entry = number of pose pairs
+        S.seg_start = seg_start; S.pair_key = ukey; S.pair_val = pkey2; S.pair_ent = pent; S.pair_cap = P_tot > 0 ? pair_cap : 0;
     }
     return OV2_OK;
 }
 
-ov2_status get_scalars(ba_solver &S, double *h, int n)
+ba_lmopt make_lmopt(const ov2_ba_options *o)
 {
-    OV2_HIP(S.c, hipMemcpyAsync(h, S.d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, S.c->stream));
-    OV2_HIP(S.c, hipStreamSynchronize(S.c->stream));
-    return OV2_OK;
+    ba_lmopt L;
+    L.min_d = o->min_lm_diagonal; L.max_d = o->max_lm_diagonal; L.max_radius = o->max_radius; L.min_radius = o->min_radius;
+    L.min_rel = o->min_relative_decrease; L.ptol = o->parameter_tolerance; L.gtol = o->gradient_tolerance;
+    L.ftol = o->function_tolerance; L.max_invalid = o->max_consecutive_invalid_steps; L.jacobi = o->jacobi_scaling ? 1 : 0;
+    return L;
 }
 
-// EvaluateGradientAndJacobian at the current x (xp/xl): cost -> scal[SC_COST]; jacobian rows; sqn/grad
-ov2_status eval_jacobian(ba_solver &S, int use_loss, bool first)
+__global__ void ba_fill_kernel(double *__restrict__ p, size_t n, double v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// a window of the program that has nothing to minimise ends before iteration zero, as TrustRegionMinimizer does not run
+__global__ void ba_skip_empty_kernel(ba_dev d)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= d.B) return;
+    ba_win &W = d.W[w];
+    if (W.skip) return;
+    W.done = 0; W.active = 0; W.valid = 0; W.accepted = 0; W.eval_at_cand = 0; W.chol_fail = 0;
+    W.nbad = W.n_left = W.n_right = 0;
+    if (W.row1 == W.row0 || (W.e1 - W.e0) * d.e + W.m == 0) {
+        W.skip = 2;   // in the program, but empty
+        W.done = 1; W.termination = OV2_BA_TERM_SKIPPED;
+        W.initial_cost = W.minimum_cost = W.x_cost = 0.0;
+    }
+}
+
+// Enqueues TrustRegionMinimizer::Minimize for every window of the program: iteration zero + max_rounds LM rounds, a fixed
+// chain of launches with no host synchronisation (every kernel skips the windows that are done).
+ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
 {
     ov2_ctx *c = S.c;
+    const ov2_ba_options *o = S.o;
     ba_dev &d = S.d;
     hipStream_t st = c->stream;
-    if (d.e == 1)
-        BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
-                  S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
-    else
-        BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, use_loss,
-                  S.o->huber_delta, first ? 0 : (S.o->jacobi_scaling ? 1 : 0), d.part);
-    BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_COST, 1.0);
-    auto colnorm = [&]() {
-        BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d);
-        if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_colnorm_pose_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent);
-    };
-    colnorm();
-    if (first) {
-        if (S.o->jacobi_scaling) {
-            BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
-            BA_LAUNCH(S, K_SCALE, ba_scale_rows_kernel, dim3(S.eval_blocks), dim3(256), 0, st, d);
-            // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute
-            // norms on it; its gradient is the scaled one, unscale it for the tolerance test
-            colnorm();
-            BA_LAUNCH(S, K_MISC, ba_unscale_grad_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, 1);
-            BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+    const int e = d.e, B = S.B;
+    const ba_lmopt lo = make_lmopt(o);
+    BA_LAUNCH(S, K_MISC, ba_skip_empty_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d);
+    if (d.n_rows == 0 || d.nc == 0) return OV2_OK;
+    // candidate buffers start as copies of x: blocks outside this program are never written by Plus, and x <- candidate
+    // copies whole windows (after a first solve the buffers still hold its last, possibly rejected, candidate)
+    if (S.n_pose) OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, 7 * (size_t)S.n_pose * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (S.n_lm) OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, (size_t)e * S.n_lm * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const dim3 g_rows(S.vblocks), g_lm((d.n_e + 15) / 16), g_win(B);
+    auto eval = [&](bool jac, const double *xp, const double *xl, int mode) {
+        double *pc = d.part + 3 * (size_t)(d.n_e + d.n_f);
+        if (jac) {
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
         } else {
-            std::vector<double> ones(d.nc, 1.0);
-            OV2_HIP(c, hipMemcpyAsync(d.scale, ones.data(), sizeof(double) * d.nc, hipMemcpyHostToDevice, st));
-            OV2_HIP(c, hipStreamSynchronize(st));
-            BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
         }
+    };
+    auto colnorm = [&](int mode) {
+        BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, g_lm, dim3(256), 0, st, d, mode);
+        if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_colnorm_pose_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent, mode);
+    };
+    const int nb = d.n_e + d.n_f;
+    double *part_step = d.part, *part_norm = d.part + nb, *part_model = d.part + 2 * (size_t)nb;
+    double *part_cost = d.part + 3 * (size_t)nb;
+    // ---- IterationZero: EvaluateGradientAndJacobian at x
+    eval(true, S.xp, S.xl, EV_ZERO);
+    colnorm(EV_ZERO);
+    if (lo.jacobi) {
+        BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
+        BA_LAUNCH(S, K_SCALE, ba_scale_rows_kernel, dim3((d.n_rows + 255) / 256), dim3(256), 0, st, d);
+        // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute the norms on
+        // it; its gradient is the scaled one, the tolerance test unscales it on the fly
+        colnorm(EV_ZERO);
     } else {
-        // grad currently = scaled gradient; the tolerance test wants the unscaled one over the landmark block
-        BA_LAUNCH(S, K_MISC, ba_unscale_grad_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d, S.o->jacobi_scaling);
-        BA_LAUNCH(S, K_MISC, ba_max_kernel, dim3(1), dim3(256), 0, st, d.grad, d.n_e * d.e, d.scal + SC_GMAX_LM);
+        BA_LAUNCH(S, K_SCALE, ba_fill_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d.scale, (size_t)d.nc, 1.0);
+    }
+    BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm, part_model,
+              1, o->initial_radius);
+    static const int chol_multi_min = getenv("OV2_CHOL_MULTI_MIN") ? atoi(getenv("OV2_CHOL_MULTI_MIN")) : CHOL_MULTI_MIN;
+    for (int round = 0; round < max_rounds; ++round) {
+        // ---- ComputeTrustRegionStep
+        BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_sinit_kernel, dim3((unsigned)((S.cover_max + 255) / 256), B), dim3(256), 0, st, d, lo.min_d, lo.max_d);
+        {
+            const long long gblocks = (long long)d.n_f + (S.pair_cap + 3) / 4;
+            if (e == 1) {
+                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, g_lm, dim3(256), 0, st, d, S.cells);
+                if (gblocks > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val, S.pair_ent, S.fb, S.pb);
+            } else {
+                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, g_lm, dim3(256), 0, st, d, S.cells);
+                if (gblocks > 0)
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val, S.pair_ent, S.fb, S.pb);
+            }
+        }
+        if (S.mmax > 0) {
+            const int m = S.mmax;
+            if (m >= chol_multi_min) {
+                // right-looking, two launches per panel (trailing update on the matrix cores), then the backward pass;
+                // window = blockIdx.y, grids sized for the largest window
+                for (int k0 = 0; k0 < m; k0 += CHOL_NB) {
+                    const int nbk = std::min(CHOL_NB, m - k0), below = m - (k0 + nbk) + 1;
+                    BA_LAUNCH(S, K_CHOL, ba_chol_panel_kernel, dim3((below + 63) / 64, B), dim3(64), 0, st, d, S.chold, S.chold_stride, k0);
+                    if (k0 + nbk < m) {
+                        const int t = m - (k0 + nbk), nt = (t + 15) / 16;
+                        BA_LAUNCH(S, K_CHOL, ba_chol_syrk_kernel, dim3(nt * (nt + 1) / 2 + (t + 63) / 64, B), dim3(64), 0, st, d, k0);
+                    }
+                }
+                BA_LAUNCH(S, K_CHOL, ba_chol_backward_kernel, dim3(B), dim3(256), (size_t)(m + CHOL_NB + 2) * 8, st, d, S.chold, S.chold_stride);
+            } else {
+                // one workgroup per window; panel width by LDS budget: (m+1) x (NB+1) + NB x 64 doubles <= 158 KiB
+                const size_t lds32 = ((size_t)(m + 1) * 33 + 32 * 64 + 4) * 8, lds16 = ((size_t)(m + 1) * 17 + 16 * 64 + 4) * 8,
+                             lds8 = ((size_t)(m + 1) * 9 + 8 * 64 + 4) * 8;
+                if (lds32 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, g_win, dim3(CHOL_THREADS), lds32, st, d);
+                else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, g_win, dim3(CHOL_THREADS), lds16, st, d);
+                else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, g_win, dim3(CHOL_THREADS), lds8, st, d);
+                else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", m);
+            }
+        }
+        {
+            const int bgrid = std::max((d.n_e + 15) / 16, (d.m + 255) / 256);
+            if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3(bgrid), dim3(256), 0, st, d, part_model);
+            else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3(bgrid), dim3(256), 0, st, d, part_model);
+        }
+        BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_MODEL>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
+                  part_model, 0, 0.0);
+        // ---- ComputeCandidatePointAndEvaluateCost (windows with a valid step)
+        BA_LAUNCH(S, K_PLUS, ba_plus_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, d, S.xp, S.xl, S.cp, S.cl, d.step, lo.jacobi,
+                  part_step, part_norm);
+        eval(false, S.cp, S.cl, EV_CAND);
+        BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_CAND>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
+                  part_model, 0, 0.0);
+        // ---- HandleSuccessfulStep (windows whose step was accepted): x <- candidate, jacobian at the new x
+        BA_LAUNCH(S, K_MISC, ba_accept_kernel, dim3((std::max(S.n_pose, S.n_lm) + 255) / 256), dim3(256), 0, st, d, S.raw.pose_off,
+                  S.raw.lm_off, S.xp, S.cp, S.xl, S.cl);
+        eval(true, S.xp, S.xl, EV_ACC);
+        colnorm(EV_ACC);
+        BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
+                  part_model, 0, 0.0);
     }
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
 }
 
-void host_se3_plus(const double *x, const double *dlt, double *out);  // defined below (mirror of the device code)
-
-void log_iter(ov2_ba_result *R, double cost, double change, double radius, double rel, double model, int valid, int ok)
+// chi2 / depth flags of the rows of the program that was just minimised (src/optimizer.cpp:500-592, 637-735)
+ov2_status enqueue_flags(ba_solver &S, int pass)
 {
-    if (!R || R->n_log >= OV2_BA_MAX_LOG) return;
-    ov2_ba_iter *it = &R->log[R->n_log++];
-    it->cost = cost; it->cost_change = change; it->radius = radius; it->relative_decrease = rel;
-    it->model_cost_change = model; it->step_is_valid = valid; it->step_is_successful = ok;
-}
-
-// TrustRegionMinimizer::Minimize on the device program; h_pose/h_lm hold "parameters_" (best state) on return
-ov2_status minimize(ba_solver &S, const std::vector<uint8_t> &active, int use_loss, int max_iters, ov2_ba_result *R,
-                    double *initial_cost, double *final_cost, int *termination)
-{
-    ov2_ctx *c = S.c;
-    const ov2_ba_options *o = S.o;
-    ov2_status s = OV2_OK;
-    (void)active;   // the program over the active rows was built by the caller (build_program)
     ba_dev &d = S.d;
-    hipStream_t st = c->stream;
-    *termination = OV2_BA_TERM_MAX_ITER;
-    if (d.n_rows == 0 || d.nc == 0) {
-        *initial_cost = *final_cost = 0.0;
-        *termination = OV2_BA_TERM_SKIPPED;
-        return OV2_OK;
-    }
-    const int e = d.e;
-    const size_t np = (size_t)S.P->n_pose * 7, nl = (size_t)S.P->n_lm * e;
-    OV2_HIP(c, hipMemcpyAsync(S.xp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-    OV2_HIP(c, hipMemcpyAsync(S.xl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
-    OV2_HIP(c, hipMemcpyAsync(S.cp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-    OV2_HIP(c, hipMemcpyAsync(S.cl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
-
-    double sc[SC_N];
-    const bool trc0 = getenv("OV2_BA_TRACE") != nullptr;
-    const auto tz0 = std::chrono::steady_clock::now();
-    // IterationZero
-    if ((s = eval_jacobian(S, use_loss, true)) != OV2_OK) return s;
-    const auto tz1 = std::chrono::steady_clock::now();
-    if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
-    const auto tz2 = std::chrono::steady_clock::now();
-    if (trc0)
-        fprintf(stderr, "   [minimize] iteration zero: enqueue %.3f ms, sync %.3f ms\n",
-                std::chrono::duration<double, std::milli>(tz1 - tz0).count(),
-                std::chrono::duration<double, std::milli>(tz2 - tz1).count());
-    double x_cost = sc[SC_COST];
-    // gradient max norm: landmarks from the device, poses via Plus on the host (n_f is small)
-    auto grad_max = [&](double lm_part, double *out) -> ov2_status {
-        std::vector<double> g(d.m), xp(np);
-        double gm = lm_part;
-        if (d.m > 0) {
-            OV2_HIP(c, hipMemcpyAsync(g.data(), d.grad + d.n_e * e, sizeof(double) * d.m, hipMemcpyDeviceToHost, st));
-            OV2_HIP(c, hipMemcpyAsync(xp.data(), S.xp, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-            OV2_HIP(c, hipStreamSynchronize(st));
-            const std::vector<int> &pf = S.h_pose_of_f;
-            for (int f = 0; f < d.n_f; ++f) {
-                double dl[6], out7[7];
-                for (int k = 0; k < 6; ++k) dl[k] = -g[f * 6 + k];
-                host_se3_plus(&xp[7 * pf[f]], dl, out7);
-                for (int k = 0; k < 7; ++k) gm = std::max(gm, std::fabs(xp[7 * pf[f] + k] - out7[k]));
-            }
-        }
-        *out = gm;
-        return OV2_OK;
-    };
-    double gmax = 0.0;
-    if ((s = grad_max(sc[SC_GMAX_LM], &gmax)) != OV2_OK) return s;
-    *initial_cost = x_cost;
-    double minimum_cost = x_cost;
-    double x_norm = -1.0, radius = o->initial_radius, decrease_factor = 2.0;
-    int reuse_diagonal = 0, invalid_steps = 0, iteration = 0, last_ok = 1;
-    log_iter(R, x_cost, 0.0, radius, 0.0, 0.0, 1, 1);
-
-    for (;;) {
-        if (iteration >= max_iters) { *termination = OV2_BA_TERM_MAX_ITER; break; }
-        if (last_ok && gmax <= o->gradient_tolerance) { *termination = OV2_BA_TERM_GTOL; break; }
-        if (radius <= o->min_radius) { *termination = OV2_BA_TERM_MIN_RADIUS; break; }
-        ++iteration;
-        const bool trc = getenv("OV2_BA_TRACE") != nullptr;
-        auto tnow = [] { return std::chrono::steady_clock::now(); };
-        auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-            return std::chrono::duration<double, std::milli>(b - a).count();
-        };
-        const auto ta = tnow();
-        // ---- ComputeTrustRegionStep + candidate evaluation, all enqueued, one sync
-        {
-            const size_t cover = std::max<size_t>((size_t)d.nc, (size_t)d.m * d.m);
-            BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_sinit_kernel, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, d,
-                      reuse_diagonal ? 0 : 1, o->min_lm_diagonal, o->max_lm_diagonal, radius);
-            reuse_diagonal = 1;
-        }
-        {
-            const int gblocks = d.n_f + (S.pair_cap + 3) / 4;
-            if (e == 1) {
-                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
-                if (gblocks > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3(gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
-                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val);
-            } else {
-                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, dim3((d.n_e + 15) / 16), dim3(256), 0, st, d, S.cells);
-                if (gblocks > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3(gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
-                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val);
-            }
-        }
-        const auto tb = tnow();
-        if (d.m > 0) {
-            static const int chol_multi_min = getenv("OV2_CHOL_MULTI_MIN") ? atoi(getenv("OV2_CHOL_MULTI_MIN")) : CHOL_MULTI_MIN;
-            if (d.m >= chol_multi_min) {
-                // right-looking, two launches per panel (trailing update on the matrix cores), then the backward pass
-                for (int k0 = 0; k0 < d.m; k0 += CHOL_NB) {
-                    const int nb = std::min(CHOL_NB, d.m - k0), below = d.m - (k0 + nb) + 1;
-                    BA_LAUNCH(S, K_CHOL, ba_chol_panel_kernel, dim3((below + 63) / 64), dim3(64), 0, st, d.S, d.rhs, S.chold, d.m, k0, d.flags);
-                    if (k0 + nb < d.m) {
-                        const int t = d.m - (k0 + nb), nt = (t + 15) / 16;
-                        BA_LAUNCH(S, K_CHOL, ba_chol_syrk_kernel, dim3(nt * (nt + 1) / 2 + (t + 63) / 64), dim3(64), 0, st, d.S, d.rhs,
-                                  d.m, k0, d.flags);
-                    }
-                }
-                BA_LAUNCH(S, K_CHOL, ba_chol_backward_kernel, dim3(1), dim3(256), (size_t)(d.m + CHOL_NB + 2) * 8, st, d.S, d.rhs,
-                          S.chold, d.m, d.flags);
-            } else {
-            // panel width by LDS budget: (m+1) x (NB+1) + NB x 32 doubles <= 150 KiB
-            const size_t lds32 = ((size_t)(d.m + 1) * 33 + 32 * 64 + 4) * 8, lds16 = ((size_t)(d.m + 1) * 17 + 16 * 64 + 4) * 8,
-                         lds8 = ((size_t)(d.m + 1) * 9 + 8 * 64 + 4) * 8;
-            if (lds32 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<32>, dim3(1), dim3(CHOL_THREADS), lds32, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, dim3(1), dim3(CHOL_THREADS), lds16, st, d.S, d.rhs, d.m, d.flags);
-            else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, dim3(1), dim3(CHOL_THREADS), lds8, st, d.S, d.rhs, d.m, d.flags);
-            else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", d.m);
-            }
-        }
-        const auto tc = tnow();
-        {
-            double *pm = d.part + 2 * (size_t)(d.n_e + d.n_f);   // model-change partials, behind the two arrays ba_plus fills
-            const int bgrid = std::max((d.n_e + 15) / 16, (d.m + 255) / 256);
-            if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3(bgrid), dim3(256), 0, st, d, pm);
-            else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3(bgrid), dim3(256), 0, st, d, pm);
-        }
-        const int nb = d.n_e + d.n_f;
-        double *part_step = d.part, *part_norm = d.part + nb, *part_model = d.part + 2 * (size_t)nb;
-        BA_LAUNCH(S, K_PLUS, ba_plus_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, d, S.xp, S.xl, S.cp, S.cl, d.step,
-                  o->jacobi_scaling ? 1 : 0, part_step, part_norm);
-        {
-            ba_red3 r3;
-            r3.in[0] = part_model; r3.n[0] = d.n_e; r3.out[0] = d.scal + SC_MODEL; r3.sign[0] = -1.0;
-            r3.in[1] = part_step; r3.n[1] = nb; r3.out[1] = d.scal + SC_STEP2; r3.sign[1] = 1.0;
-            r3.in[2] = part_norm; r3.n[2] = nb; r3.out[2] = d.scal + SC_XNORM2; r3.sign[2] = 1.0;
-            BA_LAUNCH(S, K_REDUCE, ba_reduce3_kernel, dim3(3), dim3(256), 0, st, r3);
-        }
-        if (e == 1)
-            BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
-                      o->huber_delta, 0, d.part);
-        else
-            BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), dim3(S.eval_blocks), dim3(256), 0, st, d, S.cp, S.cl, use_loss,
-                      o->huber_delta, 0, d.part);
-        BA_LAUNCH(S, K_REDUCE, ba_reduce_kernel, dim3(1), dim3(256), 0, st, d.part, S.eval_blocks, d.scal + SC_CAND_COST, 1.0);
-        int h_flags[1];
-        OV2_HIP(c, hipMemcpyAsync(h_flags, d.flags, sizeof(int), hipMemcpyDeviceToHost, st));
-        const auto tq0 = std::chrono::steady_clock::now();
-        if (trc) fprintf(stderr, "   [minimize] it %d enqueue: lmdiag+sinit+schur %.3f | chol+zstep %.3f | rest %.3f ms\n", iteration,
-                         tms(ta, tb), tms(tb, tc), tms(tc, tq0));
-        if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
-        if (getenv("OV2_BA_TRACE"))
-            fprintf(stderr, "   [minimize] it %d: step+candidate sync %.3f ms\n", iteration,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
-        const double model_change = sc[SC_MODEL], cand_cost = sc[SC_CAND_COST];
-        const bool finite = !h_flags[0] && std::isfinite(model_change) && std::isfinite(sc[SC_STEP2]);
-        const bool valid = finite && model_change > 0.0;
-        if (!valid) {   // HandleInvalidStep
-            if (++invalid_steps >= o->max_consecutive_invalid_steps) { *termination = OV2_BA_TERM_FAILURE; break; }
-            radius /= decrease_factor; decrease_factor *= 2.0;
-            last_ok = 0;
-            log_iter(R, x_cost, 0.0, radius, 0.0, model_change, 0, 0);
-            continue;
-        }
-        invalid_steps = 0;
-        const double step_norm = std::sqrt(sc[SC_STEP2]);
-        if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { *termination = OV2_BA_TERM_PTOL; break; }
-        const double cost_change = x_cost - cand_cost;
-        if (std::fabs(cost_change) <= o->function_tolerance * x_cost) {
-            *termination = OV2_BA_TERM_FTOL;
-            log_iter(R, x_cost, cost_change, radius, 0.0, model_change, 1, 0);
-            break;
-        }
-        const double rel = std::isfinite(cand_cost) ? (x_cost - cand_cost) / model_change : -1e300;
-        if (rel > o->min_relative_decrease) {   // HandleSuccessfulStep
-            std::swap(S.xp, S.cp);
-            std::swap(S.xl, S.cl);
-            // keep the constant / unused blocks of the new candidate buffer in sync for the next Plus
-            BA_LAUNCH(S, K_MISC, ba_copy2_kernel, dim3((unsigned)((std::max(np, nl) + 255) / 256)), dim3(256), 0, st, S.cp, S.xp, np,
-                      S.cl, S.xl, nl);
-            x_norm = std::sqrt(sc[SC_XNORM2]);
-            const auto tq1 = std::chrono::steady_clock::now();
-            if ((s = eval_jacobian(S, use_loss, false)) != OV2_OK) return s;
-            if ((s = get_scalars(S, sc, SC_N)) != OV2_OK) return s;
-            if (getenv("OV2_BA_TRACE"))
-                fprintf(stderr, "   [minimize] it %d: jacobian enqueue+sync %.3f ms\n", iteration,
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
-            x_cost = sc[SC_COST];
-            if ((s = grad_max(sc[SC_GMAX_LM], &gmax)) != OV2_OK) return s;
-            radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
-            radius = std::min(o->max_radius, radius);
-            decrease_factor = 2.0;
-            reuse_diagonal = 0;
-            last_ok = 1;
-            if (x_cost < minimum_cost) {
-                minimum_cost = x_cost;
-                OV2_HIP(c, hipMemcpyAsync(S.h_pose.data(), S.xp, np * sizeof(double), hipMemcpyDeviceToHost, st));
-                OV2_HIP(c, hipMemcpyAsync(S.h_lm.data(), S.xl, nl * sizeof(double), hipMemcpyDeviceToHost, st));
-                OV2_HIP(c, hipStreamSynchronize(st));
-            }
-            log_iter(R, x_cost, cost_change, radius, rel, model_change, 1, 1);
-        } else {                                // StepRejected
-            radius = radius / decrease_factor; decrease_factor *= 2.0;
-            last_ok = 0;
-            log_iter(R, cand_cost, cost_change, radius, rel, model_change, 1, 0);
-        }
-    }
-    *final_cost = minimum_cost;
+    if (d.n_rows == 0) return OV2_OK;
+    BA_LAUNCH(S, K_FLAG, ba_flag_kernel, dim3((d.n_rows + 255) / 256), dim3(256), 0, S.c->stream, d, S.xp, S.xl, S.cp, S.cl, S.rows,
+              S.o->chi2_th, pass, S.chi2_dev, S.depth_dev, S.raw.active, S.outlier_dev);
+    OV2_HIP(S.c, hipGetLastError());
     return OV2_OK;
 }
 
-void host_se3_plus(const double *x, const double *d, double *out)
-{
-    const double *u = d, *w = d + 3;
-    const double eps = 1e-10;
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    double theta, imag, real;
-    if (th2 < eps * eps) {
-        theta = 0.0;
-        const double th4 = th2 * th2;
-        imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
-        real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
-    } else {
-        theta = std::sqrt(th2);
-        imag = std::sin(0.5 * theta) / theta;
-        real = std::cos(0.5 * theta);
-    }
-    const double a[4] = {imag * w[0], imag * w[1], imag * w[2], real};
-    double Ra[9], V[9];
-    quat_to_R(a, Ra);
-    if (theta < eps) {
-        for (int i = 0; i < 9; ++i) V[i] = Ra[i];
-    } else {
-        const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-        double O2[9];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double s = 0;
-                for (int k = 0; k < 3; ++k) s += O[3 * i + k] * O[3 * k + j];
-                O2[3 * i + j] = s;
-            }
-        const double t2 = theta * theta;
-        const double c1 = (1.0 - std::cos(theta)) / t2, c2 = (theta - std::sin(theta)) / (t2 * theta);
-        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
-    }
-    double b[4] = {x[3], x[4], x[5], x[6]};
-    const double nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3]);
-    for (int i = 0; i < 4; ++i) b[i] /= nb;
-    double q[4];
-    q[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-    q[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    q[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    q[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-    const double nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int r = 0; r < 3; ++r)
-        out[r] = (V[3 * r] * u[0] + V[3 * r + 1] * u[1] + V[3 * r + 2] * u[2]) +
-                 (Ra[3 * r] * x[0] + Ra[3 * r + 1] * x[1] + Ra[3 * r + 2] * x[2]);
-    for (int i = 0; i < 4; ++i) out[3 + i] = q[i] / nq;
-}
-
-// chi2 / depth flags at the final state (src/optimizer.cpp:500-592, 637-735)
-ov2_status flag_outliers(ba_solver &S, std::vector<uint8_t> &active, ov2_ba_result *R, int pass, int *nbad, int *n_left,
-                         int *n_right)
+ov2_status fetch_windows(ba_solver &S)
 {
     ov2_ctx *c = S.c;
-    const ov2_ba_problem *P = S.P;
-    *nbad = *n_left = *n_right = 0;
-    // the program of the preceding minimize() covers exactly the currently active rows: reuse it
-    ba_dev &d = S.d;
-    if (d.n_rows == 0) return OV2_OK;
-    hipStream_t st = c->stream;
-    const size_t np = (size_t)P->n_pose * 7, nl = (size_t)P->n_lm * d.e;
-    OV2_HIP(c, hipMemcpyAsync(S.xp, S.h_pose.data(), np * sizeof(double), hipMemcpyHostToDevice, st));
-    OV2_HIP(c, hipMemcpyAsync(S.xl, S.h_lm.data(), nl * sizeof(double), hipMemcpyHostToDevice, st));
-    BA_LAUNCH(S, K_FLAG, ba_flag_kernel, dim3(S.eval_blocks), dim3(256), 0, st, d, S.xp, S.xl, S.rows, S.o->chi2_th, S.chi2_dev,
-              S.depth_dev, S.raw.active);
-    // results come back at the original residual index, through the pinned mirror (free after the program build)
-    const int n = P->n_res;
-    double *chi2 = (double *)c->ba_host;
-    unsigned char *depth = (unsigned char *)(chi2 + n);
-    OV2_HIP(c, hipMemcpyAsync(chi2, S.chi2_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-    OV2_HIP(c, hipMemcpyAsync(depth, S.depth_dev, n, hipMemcpyDeviceToHost, st));
-    OV2_HIP(c, hipStreamSynchronize(st));
-    for (int i = 0; i < n; ++i) {
-        if (!active[i]) continue;                       // not part of the program that was just solved
-        if (R->chi2) R->chi2[i] = chi2[i];
-        if (R->depth_positive) R->depth_positive[i] = depth[i];
-        if (chi2[i] > S.o->chi2_th || !depth[i]) {      // the kernel took the same decision for the device-side flags
-            active[i] = 0;
-            if (R->outlier) R->outlier[i] = (uint8_t)pass;
-            ++*nbad;
-        } else {
-            const int t = P->res_type[i];
-            if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) ++*n_left;
-            else if (t == OV2_BA_R_XYZ || t == OV2_BA_R_INV) ++*n_right;
-        }
-    }
+    ba_win *h_W = (ba_win *)c->ba_host;
+    OV2_HIP(c, hipMemcpyAsync(h_W, S.W, sizeof(ba_win) * S.B, hipMemcpyDeviceToHost, c->stream));
+    OV2_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(S.hW.data(), h_W, sizeof(ba_win) * S.B);
     return OV2_OK;
 }
 
@@ -2179,32 +2401,58 @@ extern "C" void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th)
 
 extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R)
 {
+    return ov2_ba_solve_batch(c, 1, P, o, R);
+}
+
+extern "C" ov2_status ov2_ba_solve_batch(ov2_ctx *c, int B, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R)
+{
     if (!c) return OV2_ERR_INVALID;
-    if (!P || !o || !R) return ov2_set_err(c, OV2_ERR_INVALID, "null problem/options/result");
-    if (P->n_pose < 0 || P->n_lm < 0 || P->n_res < 0 || (P->n_pose && (!P->pose || !P->pose_const)) ||
-        (P->n_lm && !P->lm) || (P->n_res && (!P->res_type || !P->res_pose || !P->res_lm || !P->res_uv)) ||
-        (P->inv_depth && P->n_lm && (!P->lm_anchor_pose || !P->lm_anchor_uv)))
-        return ov2_set_err(c, OV2_ERR_INVALID, "inconsistent ov2_ba_problem");
-    OV2_HIP(c, hipSetDevice(c->device));
-    R->n_log = 0; R->n_log_robust = 0; R->l2_done = 0; R->n_outliers_pass1 = R->n_outliers_pass2 = 0;
-    R->initial_cost = R->final_cost = R->l2_initial_cost = R->l2_final_cost = 0.0;
-    R->termination = R->l2_termination = OV2_BA_TERM_SKIPPED;
-    if (R->outlier) memset(R->outlier, 0, (size_t)P->n_res);
-    const int e = P->inv_depth ? 1 : 3;
+    if (B == 0) return OV2_OK;
+    if (B < 0 || !P || !o || !R) return ov2_set_err(c, OV2_ERR_INVALID, "null problem/options/result");
     ba_solver S;
-    S.c = c; S.P = P; S.o = o;
-    S.h_pose.assign(P->pose, P->pose + (size_t)P->n_pose * 7);
-    S.h_lm.assign(P->lm, P->lm + (size_t)P->n_lm * e);
-    std::vector<uint8_t> active(P->n_res, 1);
+    S.c = c; S.B = B; S.P = P; S.o = o;
+    S.e = P[0].inv_depth ? 1 : 3;
+    S.res_off.assign(B + 1, 0); S.lm_off.assign(B + 1, 0); S.pose_off.assign(B + 1, 0);
+    long long tn = 0, tl = 0, tp = 0;
+    size_t s_bound = 0, chold_bound = 0;
+    for (int w = 0; w < B; ++w) {
+        const ov2_ba_problem &Q = P[w];
+        if (Q.n_pose < 0 || Q.n_lm < 0 || Q.n_res < 0 || (Q.n_pose && (!Q.pose || !Q.pose_const)) || (Q.n_lm && !Q.lm) ||
+            (Q.n_res && (!Q.res_type || !Q.res_pose || !Q.res_lm || !Q.res_uv)) ||
+            (Q.inv_depth && Q.n_lm && (!Q.lm_anchor_pose || !Q.lm_anchor_uv)))
+            return ov2_set_err(c, OV2_ERR_INVALID, "inconsistent ov2_ba_problem (window %d)", w);
+        if ((Q.inv_depth ? 1 : 3) != S.e)
+            return ov2_set_err(c, OV2_ERR_INVALID, "the windows of a batch must share one landmark parametrisation (window %d)", w);
+        S.res_off[w] = (int)tn; S.lm_off[w] = (int)tl; S.pose_off[w] = (int)tp;
+        tn += Q.n_res; tl += Q.n_lm; tp += Q.n_pose;
+        if (Q.res_sigma) S.any_sigma = true;
+        const size_t m6 = 6 * (size_t)Q.n_pose;
+        s_bound += m6 * m6;
+        chold_bound += (m6 / CHOL_NB + 1) * CHOL_NB * CHOL_NB;
+    }
+    if (tn >= (1ll << 31) - 1024 || tl >= (1ll << 31) - 1024 || tp >= (1ll << 31) - 1024)
+        return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large: split it (more than 2^31 residual blocks / landmarks / poses)");
+    S.res_off[B] = (int)tn; S.lm_off[B] = (int)tl; S.pose_off[B] = (int)tp;
+    S.n_res = (int)tn; S.n_lm = (int)tl; S.n_pose = (int)tp;
+    OV2_HIP(c, hipSetDevice(c->device));
     const int use_loss = o->huber_delta > 0.0;
-    // arena: upper bound of everything build_program carves for the full problem
+    S.hW.assign(B, ba_win());
+    for (int w = 0; w < B; ++w) {
+        ba_win &X = S.hW[w];
+        memset(&X, 0, sizeof(X));
+        X.use_loss = use_loss; X.max_iters = o->max_iters;
+        ov2_ba_result &Rw = R[w];
+        Rw.n_log = 0; Rw.n_log_robust = 0; Rw.l2_done = 0; Rw.n_outliers_pass1 = Rw.n_outliers_pass2 = 0;
+        Rw.initial_cost = Rw.final_cost = Rw.l2_initial_cost = Rw.l2_final_cost = 0.0;
+        Rw.termination = Rw.l2_termination = OV2_BA_TERM_SKIPPED;
+        if (Rw.outlier) memset(Rw.outlier, 0, (size_t)P[w].n_res);
+    }
+    // arena: upper bound of everything upload_batch + build_program carve for the full batch
     {
-        const size_t n = (size_t)P->n_res, L = (size_t)P->n_lm, m6 = 6 * (size_t)P->n_pose;
-        const size_t cells = (size_t)std::min(BA_MAX_RUNS, P->n_pose) + 1;
-        // per residual block: raw copy 34 B + active 1 + sort keys 48 + program records 77 + radix-sort scratch (~2 x keys)
-        // 64 + jacobian rows 256 + chi2/depth 9 -> 520 with slack
-        const size_t need = n * 520 + L * (640 + cells * (6 * 3 * 8 + 4)) + m6 * m6 * 8 + (L * 3 + m6) * 64 +
-                            (size_t)P->n_pose * 7 * 16 + L * 3 * 16 + 64 * 256 + (m6 / 32 + 1) * 8192 + (1u << 20);
+        const size_t n = (size_t)tn, L = (size_t)tl, NP = (size_t)tp;
+        // per residual block: raw copy 33 B + flags 3 + chi2 8 + sort keys / values 80 + program records 85 + radix-sort
+        // scratch (~ keys + values) + jacobian rows 256 -> 600 with slack
+        const size_t need = n * 600 + L * 720 + NP * 1280 + s_bound * 8 + chold_bound * 8 + (size_t)B * (sizeof(ba_win) + 1024) + (4u << 20);
         if (need > c->ba_arena_cap) {
             OV2_HIP(c, hipStreamSynchronize(c->stream));
             if (c->ba_arena) OV2_HIP(c, hipFree(c->ba_arena));
@@ -2214,8 +2462,9 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
             if (he != hipSuccess) return ov2_set_err(c, OV2_ERR_NOMEM, "BA arena hipMalloc(%zu): %s", want, hipGetErrorString(he));
             c->ba_arena_cap = want;
         }
-        // pinned mirror of the uploaded head of the arena: per row 69 B of records + 8 B of pose-CSR entries
-        const size_t hneed = n * 128 + (L + (size_t)P->n_pose) * 64 + (1u << 20);
+        // pinned mirror of the uploaded head (raw problems + initial states + window records) and of what comes back
+        // (window records, states, chi2 / depth / outlier flags)
+        const size_t hneed = n * 64 + L * 96 + NP * 192 + (size_t)B * (2 * sizeof(ba_win) + sizeof(ba_wconst) + 256) + (1u << 20);
         if (hneed > c->ba_host_cap) {
             OV2_HIP(c, hipStreamSynchronize(c->stream));
             if (c->ba_host) OV2_HIP(c, hipHostFree(c->ba_host));
@@ -2233,36 +2482,92 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    ov2_status s = upload_raw(S);
+    ov2_status s = upload_batch(S);
     if (s != OV2_OK) return s;
+    const auto t0b = now();
     if ((s = build_program(S)) != OV2_OK) return s;
     const auto t1 = now();
-    s = minimize(S, active, use_loss, o->max_iters, R, &R->initial_cost, &R->final_cost, &R->termination);
-    if (s != OV2_OK) return s;
+    // ---- robust solve + flags, no synchronisation in between
+    if ((s = enqueue_minimize(S, o->max_iters)) != OV2_OK) return s;
+    if ((s = enqueue_flags(S, 1)) != OV2_OK) return s;
+    const auto t1b = now();
+    if ((s = fetch_windows(S)) != OV2_OK) return s;
     const auto t2 = now();
-    R->n_log_robust = R->n_log;
-    int nbad, nl, nr;
-    if ((s = flag_outliers(S, active, R, 1, &nbad, &nl, &nr)) != OV2_OK) return s;
-    R->n_outliers_pass1 = nbad;
-    const auto t3 = now();
-    auto t4 = t3, t5 = t3, t6 = t3;
-    if (o->l2_refine && use_loss && nbad > 0) {
-        const int keep_loss = !(nl > 0 && nr > 0);   // src/optimizer.cpp:606-608
-        if ((s = build_program(S)) != OV2_OK) return s;    // from the device-side active flags; re-carves the arena
+    int n_l2 = 0;
+    std::vector<uint8_t> did_l2((size_t)B, 0);
+    for (int w = 0; w < B; ++w) {
+        ba_win &X = S.hW[w];
+        ov2_ba_result &Rw = R[w];
+        Rw.initial_cost = X.initial_cost; Rw.final_cost = X.minimum_cost; Rw.termination = X.termination;
+        Rw.n_log_robust = X.n_log;
+        Rw.n_outliers_pass1 = X.nbad;
+        const bool l2 = o->l2_refine && use_loss && X.nbad > 0;
+        X.skip = l2 ? 0 : 1;
+        if (l2) {
+            ++n_l2;
+            did_l2[w] = 1;
+            X.use_loss = !(X.n_left > 0 && X.n_right > 0);   // src/optimizer.cpp:606-608
+            X.max_iters = o->l2_max_iters;
+            X.nbad = X.n_left = X.n_right = 0;
+        }
+    }
+    auto t3 = t2, t4 = t2, t5 = t2;
+    if (n_l2 > 0) {
+        // ---- second solve of the windows that lost residual blocks: program rebuilt from the device-side active flags
+        ba_win *h_W = (ba_win *)c->ba_host;
+        memcpy(h_W, S.hW.data(), sizeof(ba_win) * B);
+        OV2_HIP(c, hipMemcpyAsync(S.W, h_W, sizeof(ba_win) * B, hipMemcpyHostToDevice, c->stream));
+        if ((s = build_program(S)) != OV2_OK) return s;
+        t3 = now();
+        if ((s = enqueue_minimize(S, o->l2_max_iters)) != OV2_OK) return s;
+        if ((s = enqueue_flags(S, 2)) != OV2_OK) return s;
         t4 = now();
-        s = minimize(S, active, keep_loss, o->l2_max_iters, R, &R->l2_initial_cost, &R->l2_final_cost, &R->l2_termination);
-        if (s != OV2_OK) return s;
+    }
+    // ---- results: window records, states, per-residual outputs
+    {
+        const size_t n = (size_t)tn, L = (size_t)tl, NP = (size_t)tp, e = (size_t)S.e;
+        char *hb = (char *)c->ba_host;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { char *p = hb + off; off += (bytes + 255) / 256 * 256; return p; };
+        ba_win *h_W = (ba_win *)carve(sizeof(ba_win) * B);
+        double *h_xp = (double *)carve(7 * NP * 8), *h_xl = (double *)carve(e * L * 8);
+        bool want_chi2 = false, want_depth = false, want_out = false;
+        for (int w = 0; w < B; ++w) { want_chi2 |= R[w].chi2 != nullptr; want_depth |= R[w].depth_positive != nullptr; want_out |= R[w].outlier != nullptr; }
+        double *h_chi2 = want_chi2 ? (double *)carve(n * 8) : nullptr;
+        unsigned char *h_depth = want_depth ? (unsigned char *)carve(n) : nullptr, *h_out = want_out ? (unsigned char *)carve(n) : nullptr;
+        if (off > c->ba_host_cap) return ov2_set_err(c, OV2_ERR_NOMEM, "BA pinned mirror too small for the results");
+        if (n_l2 > 0) OV2_HIP(c, hipMemcpyAsync(h_W, S.W, sizeof(ba_win) * B, hipMemcpyDeviceToHost, c->stream));
+        if (NP) OV2_HIP(c, hipMemcpyAsync(h_xp, S.xp, 7 * NP * 8, hipMemcpyDeviceToHost, c->stream));
+        if (L) OV2_HIP(c, hipMemcpyAsync(h_xl, S.xl, e * L * 8, hipMemcpyDeviceToHost, c->stream));
+        if (h_chi2 && n) OV2_HIP(c, hipMemcpyAsync(h_chi2, S.chi2_dev, n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (h_depth && n) OV2_HIP(c, hipMemcpyAsync(h_depth, S.depth_dev, n, hipMemcpyDeviceToHost, c->stream));
+        if (h_out && n) OV2_HIP(c, hipMemcpyAsync(h_out, S.outlier_dev, n, hipMemcpyDeviceToHost, c->stream));
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
         t5 = now();
-        R->l2_done = 1;
-        if ((s = flag_outliers(S, active, R, 2, &nbad, &nl, &nr)) != OV2_OK) return s;
-        R->n_outliers_pass2 = nbad;
-        t6 = now();
+        for (int w = 0; w < B; ++w) {
+            const ov2_ba_problem &Q = P[w];
+            ov2_ba_result &Rw = R[w];
+            const bool l2 = did_l2[w] != 0;
+            const ba_win &X = n_l2 > 0 ? h_W[w] : S.hW[w];
+            if (l2) {
+                Rw.l2_done = 1;
+                Rw.l2_initial_cost = X.initial_cost; Rw.l2_final_cost = X.minimum_cost; Rw.l2_termination = X.termination;
+                Rw.n_outliers_pass2 = X.nbad;
+            }
+            Rw.n_log = std::min<int>(X.n_log, OV2_BA_MAX_LOG);
+            memcpy(Rw.log, X.log, sizeof(ov2_ba_iter) * (size_t)Rw.n_log);
+            const size_t r0 = (size_t)S.res_off[w], l0 = (size_t)S.lm_off[w], p0 = (size_t)S.pose_off[w];
+            // write back the non-constant blocks ("parameters_"; constant ones come back unchanged)
+            if (Q.n_pose) memcpy(Q.pose, h_xp + 7 * p0, sizeof(double) * 7 * (size_t)Q.n_pose);
+            if (Q.n_lm) memcpy(Q.lm, h_xl + e * l0, sizeof(double) * e * (size_t)Q.n_lm);
+            if (Rw.chi2 && Q.n_res) memcpy(Rw.chi2, h_chi2 + r0, sizeof(double) * (size_t)Q.n_res);
+            if (Rw.depth_positive && Q.n_res) memcpy(Rw.depth_positive, h_depth + r0, (size_t)Q.n_res);
+            if (Rw.outlier && Q.n_res) memcpy(Rw.outlier, h_out + r0, (size_t)Q.n_res);
+        }
     }
     if (trace)
-        fprintf(stderr, "[ov2_ba_solve] build %.2f | minimize %.2f (%d log) | flag %.2f | rebuild %.2f | minimize %.2f (%d log) | flag %.2f ms\n",
-                ms(t0, t1), ms(t1, t2), R->n_log_robust, ms(t2, t3), ms(t3, t4), ms(t4, t5), R->n_log - R->n_log_robust, ms(t5, t6));
-    // write back the non-constant blocks ("parameters_")
-    memcpy(P->pose, S.h_pose.data(), sizeof(double) * (size_t)P->n_pose * 7);
-    memcpy(P->lm, S.h_lm.data(), sizeof(double) * (size_t)P->n_lm * e);
+        fprintf(stderr, "[ov2_ba_solve_batch] B %d | upload %.2f | build %.2f | enqueue robust %.2f | sync %.2f | rebuild %.2f (%d windows) | "
+                        "enqueue L2 %.2f | results %.2f ms\n", B, ms(t0, t0b), ms(t0b, t1), ms(t1, t1b), ms(t1b, t2), ms(t2, t3), n_l2,
+                ms(t3, t4), ms(t4, t5));
     return OV2_OK;
 }

@@ -5,7 +5,7 @@ Plumbing only; no arithmetic happens here."""
 import ctypes as C
 
 from . import _lib
-from .ba_types import BaOptionsC, BaResult
+from .ba_types import BaOptionsC, BaProblemC, BaResult, BaResultC
 from .frontend import _check
 
 
@@ -33,4 +33,26 @@ class Optimizer:
         res = BaResult(problem.n_res)
         pc = problem.as_c()
         _check(self.ctx.h, self.ctx.lib.ov2_ba_solve(self.ctx.h, C.byref(pc), C.byref(o), C.byref(res.c)))
+        return res
+
+    def localBA_batch(self, problems, buse_robust_cost=True, options=None, want_flags=True):
+        """B independent windows in one call (ov2_ba_solve_batch): every BaProblem is solved in place; returns the list of
+        BaResult.  The reference runs one Estimator thread per SLAM instance; this is that, for the windows pending at the
+        same time on one GPU.  want_flags=False skips the per-residual outputs (chi2 / depth / outlier arrays)."""
+        o = options if options is not None else self.options
+        if not buse_robust_cost:
+            o = BaOptionsC.from_buffer_copy(o)
+            o.huber_delta = 0.0
+        B = len(problems)
+        res = [BaResult(p.n_res) for p in problems]
+        pcs = (BaProblemC * B)(*[p.as_c() for p in problems])
+        rcs = (BaResultC * B)()
+        for k, r in enumerate(res):
+            if want_flags:
+                rcs[k].chi2, rcs[k].depth_positive, rcs[k].outlier = r.c.chi2, r.c.depth_positive, r.c.outlier
+        _check(self.ctx.h, self.ctx.lib.ov2_ba_solve_batch(self.ctx.h, B, pcs, C.byref(o), rcs))
+        for k, r in enumerate(res):
+            keep = (r.c.chi2, r.c.depth_positive, r.c.outlier)
+            C.memmove(C.byref(r.c), C.byref(rcs[k]), C.sizeof(BaResultC))
+            r.c.chi2, r.c.depth_positive, r.c.outlier = keep
         return res

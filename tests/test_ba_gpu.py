@@ -107,3 +107,61 @@ def test_local_ba_config4_window(ctx, oracle, inv_depth):
     Rg = local_ba.Optimizer(ctx).localBA(P)
     Rc = oracle.ba_solve(Pc)
     _compare(P, Rg, Pc, Rc, flags_exact=False)
+
+
+def test_local_ba_batch_matches_oracle_and_single(ctx, oracle):
+    """ov2_ba_solve_batch on ragged windows (different sizes, one structure-only, one empty, one that needs no L2
+    refinement): every window matches the oracle like a lone solve does, and is BITWISE what the same window gives when it
+    is solved alone (a window's arithmetic does not depend on the batch it shares)."""
+    Ps = [synth_ba.make_window(6, 80, inv_depth=True, seed=23),
+          synth_ba.make_window(20, 2000, inv_depth=True, seed=37),
+          synth_ba.make_window(12, 600, inv_depth=True, seed=3, outlier_frac=0.0, px_noise=0.05),   # no outliers: no L2 pass
+          synth_ba.make_window(9, 300, inv_depth=True, seed=41, stereo=False),
+          synth_ba.make_window(31, 3000, inv_depth=True, seed=43, max_obs=9)]
+    allc = synth_ba.make_window(6, 100, inv_depth=True, seed=9)
+    allc.pose_const[:] = 1                                      # structure-only window
+    Ps.append(allc)
+    E = synth_ba.make_window(4, 20, inv_depth=True, seed=1)     # empty window
+    E.res_type, E.res_pose, E.res_lm, E.res_uv = E.res_type[:0], E.res_pose[:0], E.res_lm[:0], E.res_uv[:0]
+    Ps.insert(2, E)
+    singles = [p.copy() for p in Ps]
+    oracles = [p.copy() for p in Ps]
+    opt = local_ba.Optimizer(ctx)
+    Rb = opt.localBA_batch(Ps)
+    assert Rb[2].summary()["termination"] == "skipped" and Rb[2].c.n_log == 0
+    for k, (P, R) in enumerate(zip(Ps, Rb)):
+        Rs = opt.localBA(singles[k])
+        assert np.array_equal(P.pose.view(np.uint64), singles[k].pose.view(np.uint64)), k
+        assert np.array_equal(P.lm.view(np.uint64), singles[k].lm.view(np.uint64)), k
+        assert R.c.n_log == Rs.c.n_log and R.c.final_cost == Rs.c.final_cost and R.c.l2_final_cost == Rs.c.l2_final_cost
+        assert np.array_equal(R.outlier, Rs.outlier) and np.array_equal(R.chi2.view(np.uint64), Rs.chi2.view(np.uint64))
+        if k == 2:
+            continue
+        Rc = oracle.ba_solve(oracles[k])
+        _compare(P, R, oracles[k], Rc)
+    assert not Rb[3].summary()["l2_done"] or Rb[3].c.n_outliers_pass1 > 0
+
+
+def test_local_ba_batch_xyz_and_mixed_calibration(ctx, oracle):
+    """XYZ parametrisation, per-window calibrations; mixing parametrisations in one batch is refused"""
+    Ps = [synth_ba.make_window(8, 300, inv_depth=False, seed=51), synth_ba.make_window(15, 900, inv_depth=False, seed=52)]
+    Ps[1].calib_l = Ps[1].calib_l * np.array([1.02, 0.99, 1.0, 1.0])
+    Ps[1].calib_r = Ps[1].calib_r * np.array([0.98, 1.01, 1.0, 1.0])
+    Pc = [p.copy() for p in Ps]
+    Rb = local_ba.Optimizer(ctx).localBA_batch(Ps)
+    for k in range(2):
+        _compare(Ps[k], Rb[k], Pc[k], oracle.ba_solve(Pc[k]))
+    with pytest.raises(Exception):
+        local_ba.Optimizer(ctx).localBA_batch([synth_ba.make_window(6, 80, inv_depth=True, seed=1),
+                                               synth_ba.make_window(6, 80, inv_depth=False, seed=1)])
+
+
+def test_local_ba_long_tracks(ctx, oracle):
+    """a landmark seen by every keyframe of a 100-keyframe window (round 1 refused more than 40 observing keyframes)"""
+    P = synth_ba.make_window(100, 3000, inv_depth=True, seed=77, max_obs=100)
+    nobs = np.bincount(P.res_lm[P.res_type != 4], minlength=len(P.lm))
+    assert nobs.max() > 80
+    Pc = P.copy()
+    Rg = local_ba.Optimizer(ctx).localBA(P)
+    Rc = oracle.ba_solve(Pc)
+    _compare(P, Rg, Pc, Rc, flags_exact=False)
