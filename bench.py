@@ -13,7 +13,8 @@ Workload (BASELINE.json north_star; synthetic because no EuRoC data exists here 
   processed in lock-step (one "step" = one new stereo frame of every sequence):
     per frame     : CLAHE + 4-level pyramid + Scharr of the left image  (VisualFrontEnd::preprocessImage)
                     two-stage forward-backward KLT prev->cur            (VisualFrontEnd::kltTracking)
-    every KF-th   : right image CLAHE + pyramid, stereo KLT left->right (Mapper::run / MapManager::stereoMatching)
+    every KF-th   : right image CLAHE + pyramid, stereo KLT left->right + epipolar gate (Mapper::run /
+                    MapManager::stereoMatching: ov2_stereo_matching_dev)
                     [localBA on the keyframe window when the BA path is built: Optimizer::localBA]
   inputs (images, keypoints, priors) are resident in HBM before the timed region; nothing crosses PCIe inside it.
 Sequences are independent, so N GPUs = N x seqs sequences, no data-path collective ("scaling": "weak");
@@ -55,6 +56,7 @@ def parse():
     ap.add_argument("--ba-workers", type=int, default=1,
                     help="Estimator threads per GPU (the reference runs one per SLAM instance; each owns a share of the "
                          "sequences and its own high-priority HIP context)")
+    ap.add_argument("--ba-batch", type=int, default=64, help="most windows one ov2_ba_solve_batch call of a worker takes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnp", action="store_true",
                     help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
@@ -205,14 +207,14 @@ class Workload:
         if is_kf and self.mctx is not None:                                          # 1.KF_stereoMatching on the mapper's context
             kfpyr = cur.retain()                                                      # Keyframe keeps the pyramid (src/ov2slam.cpp:175-180)
             rp = fe.preprocess_images(self.mctx, self.right[c], True, 3.0, WIN, NLVL)
-            self.mtrk.kltTracking_dev(kfpyr, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
-                                      self.m_out_xy, self.m_out_st, self.n, self.img_idx, self.m_p3p, None)
+            self.mtrk.stereoMatching_dev(kfpyr, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
+                                         self.m_out_xy, self.m_out_st, self.n, self.img_idx, None, True, None)
             rp.release()
             kfpyr.release_from(self.mctx)
         elif is_kf:                                                                  # 1.KF_stereoMatching
             rp = fe.preprocess_images(ctx, self.right[c], True, 3.0, WIN, NLVL)
-            self.trk.kltTracking_dev(cur, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
-                                     self.out_xy, self.out_st, self.n, self.img_idx, self.p3p, None)
+            self.trk.stereoMatching_dev(cur, rp, WIN, NLVL, 30.0, 0.5, self.kps[c], self.st_pri[c], self.st_has[c],
+                                        self.out_xy, self.out_st, self.n, self.img_idx, None, True, None)
             rp.release()
             if self.detect:                                                           # 1.FE_createKeyframe (detector)
                 fe.detect_grid_batch_dev(ctx, cur, self.det_cell, 1, self.d_det_thresh, self.det_ncur, self.d_det_cur,
@@ -228,18 +230,21 @@ class BaWorker:
     newest).  The loop is a NATIVE thread of libov2host.so (ov2slam_amd/host/ov2_host_capi.cpp): a Python thread here
     fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
-    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1):
+    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64):
         from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
         workers = max(1, min(workers, seqs))
         share = [seqs // workers + (1 if k < seqs % workers else 0) for k in range(workers)]
-        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k]) for k in range(workers)]
+        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k], max_batch=max_batch) for k in range(workers)]
         for w in self.ws:
             w.submit_all()                        # warm-up (allocations, code objects); not counted
         self.solves = self.iters = self.dropped = self.submitted = 0
         self.busy_s = 0.0
-        self.mode = ("Estimator-like native worker threads, each on its own high-priority HIP stream, concurrent with the "
-                     "front-end (reference: src/estimator.cpp:32-98); robust solve (<=5 it) + L2 (<=10 it)")
+        self.batches = 0
+        self.mode = (f"{workers} native worker thread(s), each on its own high-priority HIP stream, concurrent with the front-end; a "
+                     f"worker solves the windows of all its sequences that have a keyframe pending in ONE ov2_ba_solve_batch "
+                     f"call (<= {max_batch} windows; reference: one Estimator thread per SLAM instance, src/estimator.cpp:32-98); "
+                     "robust solve (<=5 it) + L2 (<=10 it); a newer keyframe of a sequence replaces its pending one")
 
     def submit_all(self):
         for w in self.ws:
@@ -250,7 +255,7 @@ class BaWorker:
             w.set_counting(on)
 
     def refresh(self):
-        tot = dict(solves=0, iters=0, dropped=0, submitted=0, busy_s=0.0)
+        tot = dict(solves=0, iters=0, dropped=0, submitted=0, busy_s=0.0, batches=0)
         for w in self.ws:
             st = w.stats()
             if st["last_status"] != 0:
@@ -259,6 +264,7 @@ class BaWorker:
                 tot[k] += st[k]
         self.solves, self.iters, self.dropped = tot["solves"], tot["iters"], tot["dropped"]
         self.submitted, self.busy_s = tot["submitted"], tot["busy_s"] / len(self.ws)
+        self.batches = tot["batches"]
         return tot
 
     def stop(self):
@@ -292,7 +298,7 @@ def cpu_baseline(workload, kf_every, budget_s, threads=1):
         if s % kf_every == 0:
             rp = O.Pyramid(O.clahe(right[cur_i], 3.0, 15, 9), WIN, NLVL)
             pri, has = spri[s % L]
-            O.klt_tracking_frame(cur, rp, base, pri, has, WIN, NLVL, 30.0, 0.5, 30, 0.01)
+            O.stereo_matching(cur, rp, base, pri, has, WIN, NLVL, 30.0, 0.5, 30, 0.01, rectified=True)
         prev = cur
         frames += 1
         s += 1
@@ -333,7 +339,7 @@ def main():
         wl.enable_pnp(seed=777 + rank)
     ba = None
     if not a.no_ba:
-        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers)
+        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers, max_batch=a.ba_batch)
     def run_step():
         """one bench step = a.chunk frame-batches; returns the number of keyframe batches it held"""
         k = 0
@@ -404,7 +410,8 @@ def main():
                            "replaced_fraction": (ba_drop_all / ba_sub_all) if ba_sub_all else 0.0,
                            "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
                                       "parametrisation": "anchored inverse depth (buse_inv_depth: 1)"},
-                           "workers_per_gpu": len(ba.ws),
+                           "workers_per_gpu": len(ba.ws), "batches": ba.batches,
+                           "windows_per_batch": (ba.solves / ba.batches) if ba.batches else 0.0,
                            "mode": ba.mode,
                            "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
         out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"

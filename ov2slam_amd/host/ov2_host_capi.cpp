@@ -329,67 +329,83 @@ int ov2h_count_keypoints(void *p, int kfid, int *nbkps, int *nb3d, int *nbstereo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Estimator thread (reference src/estimator.cpp:32-98 run(): wait for a keyframe -> applyLocalBA -> next), native so
-// that it runs beside a Python front-end loop without sharing the interpreter lock.  One worker serves `nseq`
-// sequences: a keyframe that arrives while its sequence still has one pending replaces it (the reference keeps only
-// the newest, src/estimator.cpp:185-210).  Every job solves a fresh copy of the window it was created with.
+// Estimator threads of `nseq` SLAM instances (reference src/estimator.cpp:32-98 run(): wait for a keyframe ->
+// applyLocalBA -> next), served by ONE native thread with its own HIP context: it takes every sequence that has a
+// keyframe pending and solves their windows in one ov2_ba_solve_batch call (at most max_batch windows per call).  A
+// keyframe that arrives while its sequence still has one pending replaces it (the reference keeps only the newest,
+// src/estimator.cpp:185-210).  Every job solves a fresh copy of the window it was created with.  Native so that it runs
+// beside a Python front-end loop without sharing the interpreter lock.
 struct BaWorkerNative {
     ov2_ctx *ctx = nullptr;
-    std::vector<double> pose0, lm0, lm_auv, res_uv, res_sigma, pose, lm;
+    std::vector<double> pose0, lm0, lm_auv, res_uv, res_sigma;
     std::vector<uint8_t> pose_const, res_type;
     std::vector<int32_t> lm_anchor, res_pose, res_lm;
     ov2_ba_problem P{};
     ov2_ba_options opt{};
+    int max_batch = 64;
     std::vector<uint8_t> pending;
     std::mutex mu;
     std::condition_variable cv;
     std::thread th;
     bool stop = false, counting = false;
-    long long solves = 0, iters = 0, dropped = 0, submitted = 0;
+    long long solves = 0, iters = 0, dropped = 0, submitted = 0, batches = 0;
     double busy_s = 0.0;
     int last_status = 0;
 
     void loop()
     {
         size_t rr = 0;
+        std::vector<int> jobs;
+        std::vector<std::vector<double>> poses, lms;   // per job: the window's own state (solved in place)
+        std::vector<ov2_ba_problem> Ps;
+        std::vector<ov2_ba_result> Rs;
         for (;;) {
-            int job = -1;
+            jobs.clear();
             bool counted = false;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     if (stop) return;
-                    for (size_t k = 0; k < pending.size(); ++k) {
+                    for (size_t k = 0; k < pending.size() && (int)jobs.size() < max_batch; ++k) {
                         const size_t b = (rr + k) % pending.size();
-                        if (pending[b]) { pending[b] = 0; job = (int)b; rr = b + 1; break; }
+                        if (pending[b]) { pending[b] = 0; jobs.push_back((int)b); }
                     }
-                    if (job >= 0) break;
+                    if (!jobs.empty()) { rr = ((size_t)jobs.back() + 1) % pending.size(); break; }
                     cv.wait_for(lk, std::chrono::milliseconds(2));
                 }
-                counted = counting;   // a job counts only if it started inside the counted region
+                counted = counting;   // a batch counts only if it started inside the counted region
             }
-            pose = pose0; lm = lm0;
-            P.pose = pose.data(); P.lm = lm.data();
-            ov2_ba_result R;
-            std::memset(&R, 0, sizeof(R));
+            const size_t nb = jobs.size();
+            if (poses.size() < nb) { poses.resize(nb); lms.resize(nb); }
+            Ps.assign(nb, P);
+            Rs.resize(nb);
+            for (size_t k = 0; k < nb; ++k) {
+                poses[k] = pose0; lms[k] = lm0;
+                Ps[k].pose = poses[k].data(); Ps[k].lm = lms[k].data();
+                std::memset(&Rs[k], 0, sizeof(ov2_ba_result));
+            }
             const auto t0 = std::chrono::steady_clock::now();
-            const ov2_status s = ov2_ba_solve(ctx, &P, &opt, &R);
+            const ov2_status s = ov2_ba_solve_batch(ctx, (int)nb, Ps.data(), &opt, Rs.data());
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);
             last_status = s;
-            if (counted && counting && s == OV2_OK) {
-                ++solves;
-                const int it = R.n_log - 1 - (R.l2_done ? 1 : 0);   // the log holds one iteration-0 record per solve
-                iters += it > 0 ? it : 0;
+            if (counted && counting && s == OV2_OK) {   // ... and finished inside it
+                ++batches;
+                for (size_t k = 0; k < nb; ++k) {
+                    ++solves;
+                    const int it = Rs[k].n_log - 1 - (Rs[k].l2_done ? 1 : 0);   // the log holds one iteration-0 record per solve
+                    iters += it > 0 ? it : 0;
+                }
                 busy_s += dt;
             }
         }
     }
 };
 
-void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq)
+void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq, int max_batch)
 {
     BaWorkerNative *w = new BaWorkerNative();
+    w->max_batch = max_batch > 0 ? max_batch : 1;
     if (ov2_ctx_create_ex(device, 1, &w->ctx) != OV2_OK) { delete w; return nullptr; }   // high-priority stream
     const int e = P->inv_depth ? 1 : 3;
     w->pose0.assign(P->pose, P->pose + 7 * (size_t)P->n_pose);
@@ -438,13 +454,13 @@ void ov2h_ba_worker_set_counting(void *p, int on)
     w->counting = on != 0;
 }
 
-// out[6] = solves, LM iterations, jobs replaced by a newer keyframe, jobs submitted, busy seconds, last status
+// out[7] = solves, LM iterations, jobs replaced by a newer keyframe, jobs submitted, busy seconds, last status, batches
 void ov2h_ba_worker_stats(void *p, double *out)
 {
     BaWorkerNative *w = (BaWorkerNative *)p;
     std::lock_guard<std::mutex> lk(w->mu);
     out[0] = (double)w->solves; out[1] = (double)w->iters; out[2] = (double)w->dropped; out[3] = (double)w->submitted;
-    out[4] = w->busy_s; out[5] = (double)w->last_status;
+    out[4] = w->busy_s; out[5] = (double)w->last_status; out[6] = (double)w->batches;
 }
 
 void ov2h_ba_worker_destroy(void *p)

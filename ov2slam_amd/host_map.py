@@ -33,7 +33,7 @@ def lib():
         L.ov2h_map_bad_lmids.argtypes = [C.c_void_p, ip, C.c_int]
         L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
-        L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int]
+        L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int]
         L.ov2h_ba_worker_create.restype = C.c_void_p
         L.ov2h_ba_worker_submit_all.argtypes = [C.c_void_p]
         L.ov2h_ba_worker_submit_all.restype = None
@@ -196,13 +196,14 @@ class HostMap:
 
 class EstimatorWorker:
     """the reference's Estimator thread (src/estimator.cpp:32-98) as a NATIVE thread of libov2host.so with its own
-    high-priority HIP context: waits for keyframes, runs localBA on the newest pending one of any sequence.  Python only
-    submits keyframes and reads the counters, so the worker never competes for the interpreter lock."""
+    high-priority HIP context: waits for keyframes and solves the windows of ALL sequences that have one pending in one
+    ov2_ba_solve_batch call (at most max_batch).  Python only submits keyframes and reads the counters, so the worker never
+    competes for the interpreter lock."""
 
-    def __init__(self, device, problem, nseq, robust_mono_th=5.9915):
+    def __init__(self, device, problem, nseq, robust_mono_th=5.9915, max_batch=64):
         self.problem = problem              # keeps the arrays alive during the deep copy
         pc = problem.as_c()
-        self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq)
+        self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq, max_batch)
         if not self.h:
             raise RuntimeError("ov2h_ba_worker_create failed (no GPU?)")
 
@@ -213,10 +214,10 @@ class EstimatorWorker:
         lib().ov2h_ba_worker_set_counting(self.h, int(bool(on)))
 
     def stats(self):
-        out = np.zeros(6)
+        out = np.zeros(7)
         lib().ov2h_ba_worker_stats(self.h, _dp(out))
         return dict(solves=int(out[0]), iters=int(out[1]), dropped=int(out[2]), submitted=int(out[3]), busy_s=float(out[4]),
-                    last_status=int(out[5]))
+                    last_status=int(out[5]), batches=int(out[6]))
 
     def close(self):
         if getattr(self, "h", None):
