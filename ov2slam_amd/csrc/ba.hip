@@ -80,6 +80,7 @@ struct ba_dev {
     const ba_wconst *wc;
     const int *row_win, *win_of_e, *win_of_f;     // window of a sorted row / landmark block / pose block
     const int *vb_start;                          // B + 1: first virtual block of every window
+    int *n_active;                                // per LM round: windows that enter it (the host stops enqueuing at zero)
     double *Spool;
     // rows (sorted)
     const unsigned char *type;
@@ -93,6 +94,7 @@ struct ba_dev {
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
     double *rhs, *iete, *ieg;
+    double *FFp;         // per pose block: lower triangle (21) of F'F over all its rows, refreshed with the jacobian
     double *part;        // partial sums (max(n_rows blocks, n_e, n_f + n_e))
 };
 
@@ -322,11 +324,12 @@ __device__ __forceinline__ int win_of_vblock(const int *__restrict__ vb_start, i
 // which windows a launch works for
 enum { EV_ZERO = 0,   // iteration zero: every window of the program
        EV_CAND = 1,   // candidate evaluation: windows whose round produced a valid step
-       EV_ACC = 2 };  // jacobian at the new x: windows whose step was accepted
+       EV_ACC = 2,    // jacobian at the new x: windows whose step was accepted
+       EV_ZERO_SCALED = 3 };  // iteration zero, second pass: the same jacobian with the Jacobi scaling applied
 
 __device__ __forceinline__ bool win_runs(const ba_win &W, int mode)
 {
-    return mode == EV_ZERO ? !W.skip : (mode == EV_CAND ? (W.active && W.valid) : W.accepted != 0);
+    return (mode == EV_ZERO || mode == EV_ZERO_SCALED) ? !W.skip : (mode == EV_CAND ? (W.active && W.valid) : W.accepted != 0);
 }
 
 // workgroup b covers 256 rows of ONE window (virtual blocks: a window with r rows owns ceil(r / 256) of them), so the
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
     if (!win_runs(W, mode)) return;   // workgroup-uniform
     const int row = W.row0 + ((int)blockIdx.x - W.vb0) * 256 + (int)threadIdx.x;
     const int use_loss = W.use_loss;
-    const int apply_scale = (mode == EV_ACC) ? jacobi : 0;   // iteration zero scales after the column norms are known
+    const int apply_scale = (mode == EV_ACC || mode == EV_ZERO_SCALED) ? jacobi : 0;   // iteration zero: the scale comes from its first pass
     double c = 0.0;
     if (row < W.row1) {
         row_eval ev;
@@ -396,13 +399,17 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
                 d.Je[(size_t)row * 2 * e + cc] = ev.Jl[cc] * s;
                 d.Je[(size_t)row * 2 * e + e + cc] = ev.Jl[e + cc] * s;
             }
-            double *Jf = d.Jf + (size_t)row * 24;
+            double out[24];
+#pragma unroll
             for (int cc = 0; cc < 6; ++cc) {
                 const double sk = (apply_scale && fk >= 0) ? d.scale[ne + fk * 6 + cc] : 1.0;
                 const double sa = (apply_scale && fa >= 0) ? d.scale[ne + fa * 6 + cc] : 1.0;
-                Jf[cc] = ev.Jk[cc] * sk; Jf[6 + cc] = ev.Jk[6 + cc] * sk;
-                Jf[12 + cc] = ev.Ja[cc] * sa; Jf[18 + cc] = ev.Ja[6 + cc] * sa;
+                out[cc] = ev.Jk[cc] * sk; out[6 + cc] = ev.Jk[6 + cc] * sk;
+                out[12 + cc] = ev.Ja[cc] * sa; out[18 + cc] = ev.Ja[6 + cc] * sa;
             }
+            double2 *Jf2 = reinterpret_cast<double2 *>(d.Jf + (size_t)row * 24);   // 192-byte rows: twelve 16-byte stores
+#pragma unroll
+            for (int cc = 0; cc < 12; ++cc) Jf2[cc] = make_double2(out[2 * cc], out[2 * cc + 1]);
         }
     }
     const double tot = block_sum_256(c, sh);
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(256) void ba_winreduce_kernel(ba_dev d, ba_lmopt o,
                                                            const double *__restrict__ part_step,
                                                            const double *__restrict__ part_norm,
                                                            const double *__restrict__ part_model, int first,
-                                                           double initial_radius)
+                                                           double initial_radius, int next_round)
 {
     BA_WAVE_PRIO();
     __shared__ double sh[256];
@@ -545,6 +552,7 @@ __global__ __launch_bounds__(256) void ba_winreduce_kernel(ba_dev d, ba_lmopt o,
                 }
             }
             win_begin_round(W, o);
+            if (W.active) atomicAdd(&d.n_active[next_round], 1);
         }
     } else if (MODE == WR_MODEL) {
         if (!W.active) return;
@@ -743,45 +751,55 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
         for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
 }
 
-// column norms + gradient of the pose (F) columns: one workgroup per free pose gathers its cells through the
-// pose -> (row, cell) CSR built on the host.  No atomics (the per-pose sums are the most contended addresses of the
-// whole solve), fixed summation order => bitwise reproducible.
-__global__ __launch_bounds__(256) void ba_colnorm_pose_kernel(ba_dev d, const int *__restrict__ pose_ptr,
-                                                              const int *__restrict__ pose_ent, int mode)
+// lower-triangle element order of a symmetric 6x6 block
+__constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+__constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__constant__ signed char c_tri_diag[6] = {0, 6, 11, 15, 18, 20};
+
+// Normal-equation pieces of the pose (F) columns that only change with the jacobian: one workgroup per free pose
+// gathers its (row, cell) entries through the pose -> entries CSR and forms F'F (lower triangle, 21 values: its diagonal
+// is the column norms) and F'b (the gradient).  No atomics (the per-pose sums were the most contended addresses of the
+// whole solve), fixed summation order => bitwise reproducible.  The Schur complement reuses F'F and F'b in every LM
+// round until the next accepted step instead of re-deriving them from the rows.
+__global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int *__restrict__ pose_ptr,
+                                                             const int *__restrict__ pose_ent, int mode)
 {
     BA_WAVE_PRIO();
-    __shared__ double sh[4][12];
+    __shared__ double sh[4][27];
     const int f = blockIdx.x, tid = threadIdx.x;
     if (!win_runs(d.W[d.win_of_f[f]], mode)) return;
-    double acc[12];
-    for (int c = 0; c < 12; ++c) acc[c] = 0.0;
+    double acc[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) acc[c] = 0.0;
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
         const int ent = pose_ent[k], r = ent >> 1;
-        const double *Jf = d.Jf + (size_t)r * 24 + (ent & 1) * 12;
+        const double *Jp = d.Jf + (size_t)r * 24 + (ent & 1) * 12;
+        double J[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) J[c] = Jp[c];
         const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
-        for (int c = 0; c < 6; ++c) {
-            acc[c] += Jf[c] * Jf[c] + Jf[6 + c] * Jf[6 + c];
-            acc[6 + c] += Jf[c] * b0 + Jf[6 + c] * b1;
-        }
+#pragma unroll
+        for (int t = 0; t < 21; ++t) acc[t] += J[c_tri_i[t]] * J[c_tri_j[t]] + J[6 + c_tri_i[t]] * J[6 + c_tri_j[t]];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[21 + c] += J[c] * b0 + J[6 + c] * b1;
     }
-    for (int c = 0; c < 12; ++c) {
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
         const double v = row_sum(acc[c]);
         const double w = (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
         if ((tid & 63) == 0) sh[tid >> 6][c] = w;
     }
     __syncthreads();
-    if (tid < 12) {
+    if (tid < 27) {
         const double t = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
         const int ne = d.n_e * d.e;
-        if (tid < 6) d.sqn[ne + f * 6 + tid] = t;
-        else d.grad[ne + f * 6 + tid - 6] = t;
+        if (tid < 21) {
+            d.FFp[(size_t)f * 21 + tid] = t;
+            for (int c = 0; c < 6; ++c)
+                if (c_tri_diag[c] == tid) d.sqn[ne + f * 6 + c] = t;
+        } else d.grad[ne + f * 6 + tid - 21] = t;
     }
 }
-
-// lower-triangle element order of a symmetric 6x6 block
-__constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-__constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-
 
 // back-substitution + model cost change, 16 lanes per landmark
 template <int E>
@@ -1513,7 +1531,10 @@ struct ba_cells {
     const int *cell_f;        // pose block of the cell
     const int *cell_row;      // first row of its run, -1 = anchor cell (always the last cell of its landmark)
     const int *cell_lm;       // landmark block of the cell
-    double *W, *FF, *FFa, *rhsc;   // per cell: 6E, 21, 36, 6 doubles
+    const int *cell_rank;     // position of the cell in the pose-major order (cells of a pose are contiguous there)
+    // per cell, stored at its pose-major position: W = F'E (6E), W (E'E + D)^-1 (6E), W (E'E + D)^-1 E'b (6) and, for the
+    // observing cells of a landmark that has an anchor cell, F'Fa (36)
+    double *Wm, *Wie, *Wg, *FFa;
 };
 
 __global__ __launch_bounds__(256) void bs_count_kernel(ba_dev d, int *__restrict__ ncell, int *__restrict__ npair)
@@ -1594,7 +1615,37 @@ __global__ __launch_bounds__(256) void bs_segs_kernel(const u64 *__restrict__ pk
     if (j == n - 1) seg_start[rank[n]] = n;
 }
 
-// (1) per landmark, 16 lanes: (E'E + D)^-1, (E'E)^-1 E'b, and per cell W / F'F / F'Fa / rhs contribution
+// position of a cell in the pose-major order (inverse of the pose-sorted cell list)
+__global__ __launch_bounds__(256) void bs_rank_kernel(const int *__restrict__ pcell_ent, int n, int *__restrict__ cell_rank)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) cell_rank[pcell_ent[j]] = j;
+}
+
+// pair entries: cell ids -> pose-major positions, bit 31 = "this cell is the landmark's anchor cell"
+__global__ __launch_bounds__(256) void bs_pent_kernel(int *__restrict__ pent, size_t n2, const int *__restrict__ cell_rank,
+                                                      const int *__restrict__ cell_row)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n2) return;
+    const int c = pent[k];
+    pent[k] = cell_rank[c] | (cell_row[c] < 0 ? (int)0x80000000u : 0);
+}
+
+// the entries in the order of the sorted pair list (what the gather reads, coalesced): sorted position -> (hi, lo) cells
+__global__ __launch_bounds__(256) void bs_pent_sorted_kernel(const u64 *__restrict__ pk, int n, int pb, const int *__restrict__ pent,
+                                                             int2 *__restrict__ out)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const size_t ent = (size_t)(pk[q] & ((1ull << pb) - 1ull));
+    out[q] = make_int2(pent[2 * ent], pent[2 * ent + 1]);
+}
+
+// (1) per landmark, 16 lanes: (E'E + D)^-1, (E'E + D)^-1 E'b, and per pose cell W = F'E, W (E'E + D)^-1, W (E'E + D)^-1 E'b
+// (+ F'Fa for the cells that observe an anchored landmark), written at the cell's pose-major position so that the
+// gathers of (2) read contiguous memory.  F'F and F'b are not formed here: they only change with the jacobian
+// (ba_pose_normal_kernel).
 template <int E>
 __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
 {
@@ -1636,54 +1687,65 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const int c0 = C.cell_ptr[l], nc = C.cell_ptr[l + 1] - c0;
     const bool has_anchor = nc > 0 && C.cell_row[c0 + nc - 1] < 0;
     const int nobs = has_anchor ? nc - 1 : nc;
-    // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once and keeps all of the
-    // cell's quantities in registers: W = F'E (6E), F'F (lower 21), F'Fa (36), F'(b - E (E'E)^-1 E'b) (6).  (A first
-    // version shared one cell among the 16 lanes, cell after cell: four serial passes over the rows per cell.)
+    // F'Fa only changes with the jacobian: recomputed in the first round after an evaluation (the round that also
+    // refreshes the LM diagonal), reused by the rounds that follow a rejected step
+    const bool do_ffa = has_anchor && d.W[d.win_of_e[l]].refresh_diag != 0;
+    // writes W, W ie, W ieg of one cell at its pose-major position
+    auto store_cell = [&](int cell, const double *Wk) {
+        const size_t q = (size_t)C.cell_rank[cell];
+        double T[6 * E], wg[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double sg = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < E; ++cc) {
+                double w = 0.0;
+#pragma unroll
+                for (int k = 0; k < E; ++k) w += Wk[i * E + k] * ie[k * E + cc];
+                T[i * E + cc] = w;
+            }
+#pragma unroll
+            for (int k = 0; k < E; ++k) sg += Wk[i * E + k] * ieg[k];
+            wg[i] = sg;
+        }
+#pragma unroll
+        for (int i = 0; i < 6 * E; ++i) { C.Wm[q * 6 * E + i] = Wk[i]; C.Wie[q * 6 * E + i] = T[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) C.Wg[q * 6 + i] = wg[i];
+    };
+    // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once
     for (int c = sub; c < nobs; c += 16) {
         const int fk = C.cell_f[c0 + c];
-        double Wk[6 * E], rh[6], ff[21], ffa[36];
+        double Wk[6 * E], ffa[36];
 #pragma unroll
         for (int i = 0; i < 6 * E; ++i) Wk[i] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) rh[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 21; ++i) ff[i] = 0.0;
-#pragma unroll
         for (int i = 0; i < 36; ++i) ffa[i] = 0.0;
         for (int r2 = C.cell_row[c0 + c]; r2 < r1 && d.fk[r2] == fk; ++r2) {
-            double J2[24], Je2[2 * E];
+            double J2[12], Je2[2 * E];
 #pragma unroll
-            for (int i = 0; i < 24; ++i) J2[i] = d.Jf[(size_t)r2 * 24 + i];
+            for (int i = 0; i < 12; ++i) J2[i] = d.Jf[(size_t)r2 * 24 + i];
 #pragma unroll
             for (int i = 0; i < 2 * E; ++i) Je2[i] = d.Je[(size_t)r2 * 2 * E + i];
-            double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
 #pragma unroll
-            for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                rh[i] += J2[i] * t0 + J2[6 + i] * t1;
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int k = 0; k < E; ++k) Wk[i * E + k] += J2[i] * Je2[k] + J2[6 + i] * Je2[E + k];
-            }
+            if (do_ffa && d.fa[r2] >= 0) {
+                double Ja[12];
 #pragma unroll
-            for (int t = 0; t < 21; ++t) ff[t] += J2[c_tri_i[t]] * J2[c_tri_j[t]] + J2[6 + c_tri_i[t]] * J2[6 + c_tri_j[t]];
-            if (d.fa[r2] >= 0) {
+                for (int i = 0; i < 12; ++i) Ja[i] = d.Jf[(size_t)r2 * 24 + 12 + i];
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) ffa[i * 6 + j] += J2[i] * J2[12 + j] + J2[6 + i] * J2[18 + j];
+                    for (int j = 0; j < 6; ++j) ffa[i * 6 + j] += J2[i] * Ja[j] + J2[6 + i] * Ja[6 + j];
             }
         }
-        const size_t cc = (size_t)(c0 + c);
+        store_cell(c0 + c, Wk);
+        if (do_ffa) {
+            const size_t q = (size_t)C.cell_rank[c0 + c];
 #pragma unroll
-        for (int i = 0; i < 6 * E; ++i) C.W[cc * 6 * E + i] = Wk[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) C.rhsc[cc * 6 + i] = rh[i];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) C.FF[cc * 21 + i] = ff[i];
-        if (has_anchor) {
-#pragma unroll
-            for (int i = 0; i < 36; ++i) C.FFa[cc * 36 + i] = ffa[i];
+            for (int i = 0; i < 36; ++i) C.FFa[q * 36 + i] = ffa[i];
         }
     }
     if (has_anchor) {   // W of the anchor cell: summed over all rows by the group
@@ -1698,27 +1760,7 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
             }
         }
         for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
-        if (sub == 0) for (int i = 0; i < 6 * E; ++i) C.W[(size_t)(c0 + nc - 1) * 6 * E + i] = Wa[i];
-    }
-    if (has_anchor) {   // anchor cell: sums over every row of the landmark that carries the anchor block
-        for (int t = sub; t < 27; t += 16) {
-            const int i = (t < 6) ? t : c_tri_i[t - 6], j = (t < 6) ? 0 : c_tri_j[t - 6];
-            double v = 0.0;
-            for (int r2 = r0; r2 < r1; ++r2) {
-                if (d.fa[r2] < 0) continue;
-                const double *J2 = d.Jf + (size_t)r2 * 24;
-                if (t < 6) {
-                    const double *Je2 = d.Je + (size_t)r2 * 2 * E;
-                    double t0 = d.res[2 * r2], t1 = d.res[2 * r2 + 1];
-                    for (int k = 0; k < E; ++k) { t0 -= Je2[k] * ieg[k]; t1 -= Je2[E + k] * ieg[k]; }
-                    v += J2[12 + i] * t0 + J2[18 + i] * t1;
-                } else {
-                    v += J2[12 + i] * J2[12 + j] + J2[18 + i] * J2[18 + j];
-                }
-            }
-            if (t < 6) C.rhsc[(size_t)(c0 + nc - 1) * 6 + i] = v;
-            else C.FF[(size_t)(c0 + nc - 1) * 21 + (t - 6)] = v;
-        }
+        if (sub == 0) store_cell(c0 + nc - 1, Wa);
     }
 }
 
@@ -1728,12 +1770,12 @@ __device__ __forceinline__ double wave_total(double v)
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-// (2a) one workgroup per pose block: diagonal block of S (lower triangle) and its rhs segment, summed over the pose's
-// cells.  Threads stride over the cells (a pose has thousands: a serial walk was latency-bound at ~1 us per cell),
-// every thread keeps the 27 partial sums, fixed-order wave + LDS reduction at the end.
+// (2a) one workgroup per pose block: diagonal block of S (lower triangle) = D_f^2 + F'F - sum_cells W (E'E + D)^-1 W' and
+// its rhs segment = F'b - sum_cells W (E'E + D)^-1 E'b.  The pose's cells are one contiguous run of the pose-major arrays;
+// threads stride over them, every thread keeps the 27 partial sums, fixed-order wave + LDS reduction at the end.
 template <int E>
-__device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C, const int *__restrict__ pcell_ptr,
-                                              const int *__restrict__ pcell_ent, int f, double (*red)[27])
+__device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C, const int *__restrict__ pcell_ptr, int f,
+                                              double (*red)[27])
 {
     const int tid = threadIdx.x;
     const ba_win &Wn = d.W[d.win_of_f[f]];
@@ -1742,28 +1784,20 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = 0.0;
     for (int q = pcell_ptr[f] + tid; q < pcell_ptr[f + 1]; q += 256) {
-        const int c = pcell_ent[q];
-        const double *W = C.W + (size_t)c * 6 * E, *ie = d.iete + (size_t)C.cell_lm[c] * E * E;
-        double T[6 * E];   // T = W (E'E)^-1
+        const double *W = C.Wm + (size_t)q * 6 * E, *T = C.Wie + (size_t)q * 6 * E;
+        double w[6 * E], t6[6 * E];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int cc = 0; cc < E; ++cc) {
-                double w = 0.0;
-#pragma unroll
-                for (int k = 0; k < E; ++k) w += W[i * E + k] * ie[k * E + cc];
-                T[i * E + cc] = w;
-            }
+        for (int i = 0; i < 6 * E; ++i) { w[i] = W[i]; t6[i] = T[i]; }
 #pragma unroll
         for (int t = 0; t < 21; ++t) {
             const int i = c_tri_i[t], j = c_tri_j[t];
-            double w = 0.0;
+            double p = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * W[j * E + cc];
-            acc[t] += C.FF[(size_t)c * 21 + t] - w;
+            for (int cc = 0; cc < E; ++cc) p += t6[i * E + cc] * w[j * E + cc];
+            acc[t] -= p;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += C.rhsc[(size_t)c * 6 + i];
+        for (int i = 0; i < 6; ++i) acc[21 + i] -= C.Wg[(size_t)q * 6 + i];
     }
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
@@ -1774,18 +1808,19 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
     if (tid < 27) {
         const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         const int lf = f - Wn.f0;   // block index inside the window's own S
-        if (tid >= 21) d.rhs[f * 6 + tid - 21] = v;                         // ba_sinit zeroed it; this is its only writer
-        else d.Spool[Wn.S_off + (size_t)(lf * 6 + c_tri_j[tid]) * Wn.m + lf * 6 + c_tri_i[tid]] += v;   // on top of the LM diagonal of ba_sinit
+        if (tid >= 21) d.rhs[f * 6 + tid - 21] = d.grad[d.n_e * d.e + f * 6 + tid - 21] + v;   // its only writer
+        else d.Spool[Wn.S_off + (size_t)(lf * 6 + c_tri_j[tid]) * Wn.m + lf * 6 + c_tri_i[tid]] += d.FFp[(size_t)f * 21 + tid] + v;   // on top of the LM diagonal of ba_sinit
     }
 }
 
-// (2b) one wave per pose pair (hi > lo): S[hi, lo] = sum over the landmarks seen by both of  -W_hi (E'E)^-1 W_lo^T,
-// plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries.
+// (2b) one wave per pose pair (hi > lo): S[hi, lo] = sum over the landmarks seen by both of  -W_hi (E'E + D)^-1 W_lo^T,
+// plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries; an entry
+// names the two cells by their pose-major positions, which grow with the landmark inside both poses' runs, so
+// consecutive entries read nearly consecutive records.
 template <int E>
 __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C, int n_pairs,
                                               const u64 *__restrict__ pair_key, const int *__restrict__ seg_start,
-                                              const u64 *__restrict__ pk, const int *__restrict__ pent, int fb, int pb,
-                                              int pidx)
+                                              const int2 *__restrict__ pent, int fb, int pidx, int dbg = 0)
 {
     const int lane = threadIdx.x & 63;
     if (pidx >= n_pairs) return;
@@ -1796,41 +1831,72 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
 #pragma unroll
     for (int t = 0; t < 36; ++t) acc[t] = 0.0;
     const int s0 = seg_start[pidx], s1 = seg_start[pidx + 1];
-    for (int q = s0 + lane; q < s1; q += 64) {
-        const size_t ent = (size_t)(pk[q] & ((1ull << pb) - 1ull));
-        const int ch = pent[2 * ent], cl = pent[2 * ent + 1];
-        const double *Wh = C.W + (size_t)ch * 6 * E, *Wl = C.W + (size_t)cl * 6 * E;
-        const double *ie = d.iete + (size_t)C.cell_lm[ch] * E * E;
-        double T[6 * E];
+    double mine_ffa = 0.0;   // element `lane` of the block (i = lane % 6 of hi, j = lane / 6 of lo), anchor terms only
+    for (int q0 = s0; q0 < s1; q0 += 64) {
+        const int q = q0 + lane;
+        const bool in = q < s1;
+        const int2 pe = in ? pent[q] : make_int2(0, 0);
+        const int eh = pe.x, el = pe.y;
+        if (in) {
+            const size_t qh = (size_t)(eh & 0x7fffffff), ql = (size_t)(el & 0x7fffffff);
+            double T[6 * E], Wl[6 * E];
+            {   // 16-byte loads: the records are 48 E bytes, 16-byte aligned
+                const double2 *th = reinterpret_cast<const double2 *>(C.Wie + qh * 6 * E), *wl = reinterpret_cast<const double2 *>(C.Wm + ql * 6 * E);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int cc = 0; cc < E; ++cc) {
-                double w = 0.0;
-#pragma unroll
-                for (int k = 0; k < E; ++k) w += Wh[i * E + k] * ie[k * E + cc];
-                T[i * E + cc] = w;
+                for (int i = 0; i < 3 * E; ++i) { const double2 a = th[i], b = wl[i]; T[2 * i] = a.x; T[2 * i + 1] = a.y; Wl[2 * i] = b.x; Wl[2 * i + 1] = b.y; }
             }
-        const bool lo_anchor = C.cell_row[cl] < 0, hi_anchor = C.cell_row[ch] < 0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                double w = 0.0;
+                for (int i = 0; i < 6; ++i) {
+                    double w = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * Wl[j * E + cc];
-                double v = -w;
-                if (lo_anchor) v += C.FFa[(size_t)ch * 36 + i * 6 + j];        // hi cell observes, lo cell is the anchor
-                else if (hi_anchor) v += C.FFa[(size_t)cl * 36 + j * 6 + i];   // lo cell observes, hi cell is the anchor
-                acc[i + 6 * j] += v;
+                    for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * Wl[j * E + cc];
+                    acc[i + 6 * j] -= w;
+                }
+        }
+        // entries in which one of the two cells is the landmark's anchor cell add F'Fa (36 doubles of the observing cell's
+        // record): walked one entry at a time, lane t < 36 fetching element t -- one coalesced 288-byte read per entry
+        // instead of 36 scattered loads per lane (which made this kernel 3x slower)
+        unsigned long long am = (dbg & 4) ? 0ull : __ballot(in && (eh < 0 || el < 0));
+        const int li = lane % 6, lj = lane / 6;
+        while (am) {   // four entries per trip: their loads are in flight together, the adds keep the entry order
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = 0.0;
+                if (am) {
+                    const int b = __builtin_ctzll(am);
+                    am &= am - 1;
+                    const int ehb = __builtin_amdgcn_readlane(eh, b), elb = __builtin_amdgcn_readlane(el, b);
+                    // lo cell is the anchor: hi observes, F'Fa stored (i of hi, j of anchor) row-major; else transposed
+                    if (lane < 36)
+                        v[u] = (elb < 0) ? C.FFa[(size_t)(ehb & 0x7fffffff) * 36 + li * 6 + lj] : C.FFa[(size_t)(elb & 0x7fffffff) * 36 + lj * 6 + li];
+                }
             }
+            mine_ffa += v[0]; mine_ffa += v[1]; mine_ffa += v[2]; mine_ffa += v[3];
+        }
     }
+    // the 36 totals are wave-uniform: lane t keeps total t, then 36 lanes write the block with one store.  An
+    // off-diagonal block has this wave as its only writer and was zeroed by ba_sinit: plain stores (a serial
+    // read-modify-write of 36 elements by one lane made these short waves latency-bound)
+    double mine = 0.0;
+    if (dbg & 8) {
+#pragma unroll
+        for (int t = 0; t < 36; ++t) mine += acc[t];
+    } else {
 #pragma unroll
     for (int t = 0; t < 36; ++t) {
         const double v = wave_total(acc[t]);
-        const int i = t % 6, j = t / 6;
-        if (lane == 0 && (hi != lo || i >= j))
-            d.Spool[Wn.S_off + (size_t)((lo - Wn.f0) * 6 + j) * Wn.m + (hi - Wn.f0) * 6 + i] += v;
+        if (lane == t) mine = v;
+    }
+    }
+    mine += mine_ffa;
+    if (lane < 36) {
+        const int i = lane % 6, j = lane / 6;
+        double *dst = d.Spool + Wn.S_off + (size_t)((lo - Wn.f0) * 6 + j) * Wn.m + (hi - Wn.f0) * 6 + i;
+        if (hi != lo) *dst = mine;
+        else if (i >= j) *dst += mine;
     }
 }
 
@@ -1839,14 +1905,15 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
 // the BA stream queues behind resident waves.
 template <int E>
 __global__ __launch_bounds__(256) void bs_gather_kernel(ba_dev d, ba_cells C, const int *__restrict__ pcell_ptr,
-                                                        const int *__restrict__ pcell_ent, const int *__restrict__ n_pairs,
-                                                        const u64 *__restrict__ pair_key, const int *__restrict__ seg_start,
-                                                        const u64 *__restrict__ pk, const int *__restrict__ pent, int fb, int pb)
+                                                        const int *__restrict__ n_pairs, const u64 *__restrict__ pair_key,
+                                                        const int *__restrict__ seg_start, const int2 *__restrict__ pent, int fb,
+                                                        int dbg_only)
 {
     BA_WAVE_PRIO();
     __shared__ double red[4][27];
-    if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, pcell_ent, blockIdx.x, red);
-    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pk, pent, fb, pb, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6));
+    if ((dbg_only & 3) && (((dbg_only & 3) == 1) != ((int)blockIdx.x < d.n_f))) return;   // timing experiments: 1 = diagonal part only, 2 = pairs only
+    if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, blockIdx.x, red);
+    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pent, fb, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6), dbg_only);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1931,7 +1998,7 @@ struct ba_solver {
     const int *pcell_ptr = nullptr, *pcell_ent = nullptr;
     const int *n_pairs = nullptr, *seg_start = nullptr;
     const u64 *pair_key = nullptr, *pair_val = nullptr;   // pair_val: the sorted (pose pair | entry) keys
-    const int *pair_ent = nullptr;                        // entry -> its two cells
+    const int2 *pair_ent = nullptr;                       // sorted entry -> its two cells (pose-major positions, bit 31 = anchor cell)
     int fb = 1, pb = 1;                                   // bit widths of a pose block id / of a pair entry index in the packed keys
     long long pair_cap = 0;
     double *xp = nullptr, *xl = nullptr, *cp = nullptr, *cl = nullptr;  // device states (batch-wide)
@@ -2130,8 +2197,9 @@ ov2_status build_program(ba_solver &S)
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
     AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(Jf, 24 * (size_t)nr);
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
-    AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e);
-    AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);   // |step|^2, |x+|^2, model change per block | cost partials per virtual block
+    AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e); AL(FFp, (size_t)d.n_f * 21);
+    AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);
+    AL(n_active, 64);   // |step|^2, |x+|^2, model change per block | cost partials per virtual block
 #undef AL
     S.chold_stride = (size_t)(S.mmax / CHOL_NB + 1) * CHOL_NB * CHOL_NB;
     if ((s = dalloc(c, S.arena_off, &S.chold, S.chold_stride * B)) != OV2_OK) return s;
@@ -2157,7 +2225,8 @@ ov2_status build_program(ba_solver &S)
         const int C_tot = h_tot[0], P_tot = h_tot[1];
         if (C_tot < 0 || P_tot < 0)
             return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large: more than 2^31 Schur cells or cell pairs");
-        int *cell_f, *cell_row, *cell_lm, *pcell_ptr, *pcell_ent, *seg_start, *head, *rank, *pent;
+        int *cell_f, *cell_row, *cell_lm, *cell_rank, *pcell_ptr, *pcell_ent, *seg_start, *head, *rank, *pent;
+        int2 *pent_sorted;
         u64 *ukey, *pkey = nullptr, *pkey2 = nullptr, *ckey = nullptr, *ckey2 = nullptr;
         ba_cells &Cc = S.cells;
         const long long pair_cap = std::min<long long>((long long)P_tot, pair_cap_bound);
@@ -2172,7 +2241,7 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
         size_t tbytes = std::max(std::max(t1, t2), t4);
         {   // the structure lives in its own block, sized now that the counts are known and kept across solves
-            const size_t need2 = (size_t)C_tot * (5 * 4 + 2 * 8 + (size_t)(6 * e + 63) * 8) + (size_t)P_tot * (2 * 8 + 4 * 4) +
+            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + (size_t)(12 * e + 42) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
                                  (size_t)pair_cap * 12 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
             if (need2 > c->ba_arena2_cap) {
                 OV2_HIP(c, hipStreamSynchronize(st));
@@ -2185,30 +2254,34 @@ ov2_status build_program(ba_solver &S)
             }
         }
         size_t off2 = 0;
-        AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot);
-        AL3(Cc.W, (size_t)C_tot * 6 * e); AL3(Cc.FF, (size_t)C_tot * 21); AL3(Cc.FFa, (size_t)C_tot * 36); AL3(Cc.rhsc, (size_t)C_tot * 6);
+        AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot); AL3(cell_rank, C_tot);
+        AL3(Cc.Wm, (size_t)C_tot * 6 * e); AL3(Cc.Wie, (size_t)C_tot * 6 * e); AL3(Cc.Wg, (size_t)C_tot * 6); AL3(Cc.FFa, (size_t)C_tot * 36);
         AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
-        AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(pent, 2 * (size_t)P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
+        AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(pent, 2 * (size_t)P_tot); AL3(pent_sorted, P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
         AL3(ukey, pair_cap + 1); AL3(seg_start, pair_cap + 2);
         unsigned char *tsort;
         AL3(tsort, tbytes + 256);
 #undef AL3
 #undef AL2
-        Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm;
+        Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm; Cc.cell_rank = cell_rank;
         BA_LAUNCH(S, K_MISC, bs_cells_kernel, dim3((d.n_e + 255) / 256), dim3(256), 0, st, d, cell_ptr, pair_off, cell_f, cell_row,
                   cell_lm, pkey, pent, ckey, fb, pb);
         if (C_tot > 0) {
             OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, ckey, ckey2, C_tot, 32, 32 + fb, st));
             BA_LAUNCH(S, K_MISC, bs_posecells_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, ckey2, C_tot, d.n_f, pcell_ptr, pcell_ent);
+            BA_LAUNCH(S, K_MISC, bs_rank_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, pcell_ent, C_tot, cell_rank);
         }
         if (P_tot > 0) {
+            BA_LAUNCH(S, K_MISC, bs_pent_kernel, dim3((unsigned)((2 * (size_t)P_tot + 255) / 256)), dim3(256), 0, st, pent, 2 * (size_t)P_tot,
+                      cell_rank, cell_row);
             OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, pkey, pkey2, P_tot, pb, pb + 2 * fb, st));
+            BA_LAUNCH(S, K_MISC, bs_pent_sorted_kernel, dim3((P_tot + 255) / 256), dim3(256), 0, st, pkey2, P_tot, pb, pent, pent_sorted);
             BA_LAUNCH(S, K_MISC, bs_heads_kernel, dim3((P_tot + 256) / 256), dim3(256), 0, st, pkey2, P_tot, head, pb);
             OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(tsort, tbytes, head, rank, P_tot + 1, st));
             BA_LAUNCH(S, K_MISC, bs_segs_kernel, dim3((P_tot + 255) / 256), dim3(256), 0, st, pkey2, P_tot, head, rank, seg_start, ukey, pb);
         }
         S.pcell_ptr = pcell_ptr; S.pcell_ent = pcell_ent; S.n_pairs = rank + P_tot;   // exclusive rank behind the last entry = number of pose pairs
-        S.seg_start = seg_start; S.pair_key = ukey; S.pair_val = pkey2; S.pair_ent = pent; S.pair_cap = P_tot > 0 ? pair_cap : 0;
+        S.seg_start = seg_start; S.pair_key = ukey; S.pair_val = pkey2; S.pair_ent = pent_sorted; S.pair_cap = P_tot > 0 ? pair_cap : 0;
     }
     return OV2_OK;
 }
@@ -2256,6 +2329,8 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     const ba_lmopt lo = make_lmopt(o);
     BA_LAUNCH(S, K_MISC, ba_skip_empty_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d);
     if (d.n_rows == 0 || d.nc == 0) return OV2_OK;
+    if (max_rounds > 62) max_rounds = 62;
+    OV2_HIP(c, hipMemsetAsync(d.n_active, 0, 64 * sizeof(int), st));
     // candidate buffers start as copies of x: blocks outside this program are never written by Plus, and x <- candidate
     // copies whole windows (after a first solve the buffers still hold its last, possibly rejected, candidate)
     if (S.n_pose) OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, 7 * (size_t)S.n_pose * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2273,7 +2348,7 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     };
     auto colnorm = [&](int mode) {
         BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, g_lm, dim3(256), 0, st, d, mode);
-        if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_colnorm_pose_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent, mode);
+        if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_pose_normal_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent, mode);
     };
     const int nb = d.n_e + d.n_f;
     double *part_step = d.part, *part_norm = d.part + nb, *part_model = d.part + 2 * (size_t)nb;
@@ -2283,7 +2358,9 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     colnorm(EV_ZERO);
     if (lo.jacobi) {
         BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
-        BA_LAUNCH(S, K_SCALE, ba_scale_rows_kernel, dim3((d.n_rows + 255) / 256), dim3(256), 0, st, d);
+        // the scaled jacobian is written by a second evaluation (same products as scaling the stored rows, without reading
+        // them back: 1.0 ms instead of 1.66 ms at 8.2 M rows)
+        eval(true, S.xp, S.xl, EV_ZERO_SCALED);
         // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute the norms on
         // it; its gradient is the scaled one, the tolerance test unscales it on the fly
         colnorm(EV_ZERO);
@@ -2291,7 +2368,8 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
         BA_LAUNCH(S, K_SCALE, ba_fill_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d.scale, (size_t)d.nc, 1.0);
     }
     BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm, part_model,
-              1, o->initial_radius);
+              1, o->initial_radius, 0);
+    static const int dbg_gather = getenv("OV2_BA_GATHER_ONLY") ? atoi(getenv("OV2_BA_GATHER_ONLY")) : 0;
     static const int chol_multi_min = getenv("OV2_CHOL_MULTI_MIN") ? atoi(getenv("OV2_CHOL_MULTI_MIN")) : CHOL_MULTI_MIN;
     for (int round = 0; round < max_rounds; ++round) {
         // ---- ComputeTrustRegionStep
@@ -2301,13 +2379,13 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
             if (e == 1) {
                 BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, g_lm, dim3(256), 0, st, d, S.cells);
                 if (gblocks > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
-                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val, S.pair_ent, S.fb, S.pb);
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_ent, S.fb, dbg_gather);
             } else {
                 BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, g_lm, dim3(256), 0, st, d, S.cells);
                 if (gblocks > 0)
-                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr, S.pcell_ent,
-                              S.n_pairs, S.pair_key, S.seg_start, S.pair_val, S.pair_ent, S.fb, S.pb);
+                    BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr,
+                              S.n_pairs, S.pair_key, S.seg_start, S.pair_ent, S.fb, dbg_gather);
             }
         }
         if (S.mmax > 0) {
@@ -2340,20 +2418,29 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
             else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3(bgrid), dim3(256), 0, st, d, part_model);
         }
         BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_MODEL>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
-                  part_model, 0, 0.0);
+                  part_model, 0, 0.0, 0);
         // ---- ComputeCandidatePointAndEvaluateCost (windows with a valid step)
         BA_LAUNCH(S, K_PLUS, ba_plus_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, d, S.xp, S.xl, S.cp, S.cl, d.step, lo.jacobi,
                   part_step, part_norm);
         eval(false, S.cp, S.cl, EV_CAND);
         BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_CAND>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
-                  part_model, 0, 0.0);
+                  part_model, 0, 0.0, 0);
         // ---- HandleSuccessfulStep (windows whose step was accepted): x <- candidate, jacobian at the new x
         BA_LAUNCH(S, K_MISC, ba_accept_kernel, dim3((std::max(S.n_pose, S.n_lm) + 255) / 256), dim3(256), 0, st, d, S.raw.pose_off,
                   S.raw.lm_off, S.xp, S.cp, S.xl, S.cl);
         eval(true, S.xp, S.xl, EV_ACC);
         colnorm(EV_ACC);
         BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
-                  part_model, 0, 0.0);
+                  part_model, 0, 0.0, round + 1);
+        // Rounds are enqueued blind (no host round trip) until the first one a typical solve can end in; from then on the
+        // host looks at how many windows entered the NEXT round and stops at zero (an idle round is ~14 launches whose
+        // grids still scale with the batch).
+        if (round + 1 >= 2 && round + 1 < max_rounds) {
+            int *h_na = (int *)c->ba_host;
+            OV2_HIP(c, hipMemcpyAsync(h_na, d.n_active + round + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            OV2_HIP(c, hipStreamSynchronize(st));
+            if (*h_na == 0) break;
+        }
     }
     OV2_HIP(c, hipGetLastError());
     return OV2_OK;
