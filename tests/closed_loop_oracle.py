@@ -1,0 +1,39 @@
+"""The stages of ov2slam_amd.slam_loop.SlamLoop served by the CPU oracle (test infrastructure): the same loop, the same
+bookkeeping, every arithmetic stage from oracle/ instead of libov2hip.so."""
+import numpy as np
+
+
+class OracleBackend:
+    def __init__(self, O, cell=35, dmaxquality=0.001):
+        self.O, self.cell, self.q = O, cell, dmaxquality
+
+    def preprocess(self, img):
+        c = self.O.clahe(img)
+        p = self.O.Pyramid(c)
+        p.clahe_img = c
+        return p
+
+    def klt_tracking(self, prev, cur, kps, priors, has):
+        out, st, _ = self.O.klt_tracking_frame(prev, cur, kps, priors, has, 9, 3, 30.0, 0.5, 30, 0.01)
+        return out, st.astype(bool)
+
+    def pnp(self, unpx, wpts, Twc, K4):
+        ok, T, outl, _ = self.O.pnp_solve(unpx, wpts, K4, Twc)
+        return ok, T, np.flatnonzero(outl).astype(np.int32)
+
+    def detect(self, pyr, img, cur_kps):
+        pts, self.q = self.O.detect_single_scale(pyr.clahe_img, self.cell, cur_kps, self.q)
+        return pts
+
+    def line_min_sad(self, lpyr, rpyr, pts):
+        return self.O.line_min_sad(lpyr, rpyr, 3, pts, 7, True)[0]
+
+    def stereo(self, lpyr, rpyr, kps, priors, has):
+        return self.O.stereo_matching(lpyr, rpyr, kps, priors, has, rectified=True)
+
+    def triangulate(self, T_lr, bv_l, bv_r, ul, ur, K4, Twc):
+        r = self.O.triangulate_pairs(T_lr, bv_l, bv_r, ul, ur, K4, K4, 3.0, method=0, Twc_a=Twc)
+        return r["wpt"], r["status"]
+
+    def ba(self, problem):
+        return self.O.ba_solve(problem)
