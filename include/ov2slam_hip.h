@@ -429,6 +429,60 @@ ov2_status ov2_triangulate_pairs_dev(ov2_ctx *ctx, int n, int method, int G, con
                                      float max_reproj_err, double *d_pt_a, double *d_wpt, double *d_parallax,
                                      uint8_t *d_status);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Keyframe descriptors and map matching (first half).
+ *
+ * ov2_describe_brief replaces FeatureExtractor::describeBRIEF(im, vpts) (include/feature_extractor.hpp:48,
+ * src/feature_extractor.cpp:224-285) = cv::xfeatures2d::BriefDescriptorExtractor::create()->compute (32 bytes, patch 48,
+ * 9 x 9 box sums at the ROUNDED keypoint, bit k of the descriptor = box(y1, x1) < box(y2, x2) of test k, first test in the
+ * most significant bit of byte 0; keypoints closer than 28 px to the border get no descriptor: valid[i] = 0, the reference
+ * returns an empty cv::Mat for them).  im = level 0 of pyramid `b` of `pyr` (the CLAHE'd frame).  The 256 test pairs of
+ * opencv_contrib (generated_32.i) are not in the reference tree: `pattern` (256 x {y1, x1, y2, x2}, int8, |v| <= 24) is
+ * supplied by the caller.  Host pointers; the _dev form takes device pointers (pattern too) + an image index per point. */
+ov2_status ov2_describe_brief(ov2_ctx *ctx, const ov2_pyr *pyr, int b, int n, const float *pts_xy, const int8_t *pattern,
+                              uint8_t *desc /* n x 32 */, uint8_t *valid /* n */);
+ov2_status ov2_describe_brief_dev(ov2_ctx *ctx, const ov2_pyr *pyr, int n, const float *d_pts_xy, const int32_t *d_img_idx,
+                                  const int8_t *d_pattern, uint8_t *d_desc, uint8_t *d_valid);
+
+/* Flat inputs of Mapper::matchToMap(frame, fmaxprojerr, fdistratio, set_local_lmids) (include/mapper.hpp:66,
+ * src/mapper.cpp:576-774).  Keypoints = the frame's keypoints that carry a map point (kp.lmid_ >= 0); candidates = the
+ * local map points to be matched, in the order the caller iterates set_local_lmids, WITHOUT those the frame already
+ * observes (Frame::isObservingKp, :613) or that are not 3-D (:622).  Descriptor sets = MapPoint::map_kf_desc_ (32 bytes
+ * each; an empty set = desc_.empty()).  Keyframe lists = MapPoint::set_kfids_, ascending; kp_kf_px = the pixel of the
+ * keypoint's map point in each of those keyframes (Frame::getKeypointById(lmid).px_); kf_Twc is indexed by kfid.
+ * grid = Frame::vgridkps_ restricted to the listed keypoints, cells row-major (nbwcells = ceil(img_w / cell)), ids in
+ * their vector order (they decide ties).  Cameras without distortion. */
+typedef struct ov2_match_input {
+    double Twc[7], K[4];
+    int32_t img_w, img_h, cell, nb3dkps;
+    int32_t n_kp;
+    const float *kp_px;            /* n_kp x 2 */
+    const int32_t *kp_desc_ptr;    /* n_kp + 1 */
+    const uint8_t *kp_descs;
+    const int32_t *kp_kf_ptr;      /* n_kp + 1 */
+    const int32_t *kp_kfids;
+    const float *kp_kf_px;         /* per kp_kfids entry x 2 */
+    const int32_t *grid_ptr;       /* cells + 1 */
+    const int32_t *grid_kp;        /* keypoint indices */
+    int32_t n_cand;
+    const double *cand_wpt;        /* n_cand x 3 */
+    const int32_t *cand_desc_ptr;  /* n_cand + 1 */
+    const uint8_t *cand_descs;
+    const int32_t *cand_kf_ptr;    /* n_cand + 1 */
+    const int32_t *cand_kfids;
+    int32_t n_kf;
+    const double *kf_Twc;          /* n_kf x 7 */
+} ov2_match_input;
+
+/* match_cand[k] = index of the candidate matched to keypoint k or -1 (the reference's map_previd_newid: keypoint lmid ->
+ * map point id), match_dist[k] = its descriptor distance.  Per candidate: projection + field-of-view gates (:626-645), the
+ * keypoints of the 2 x 2 grid cells around the projection (Frame::getSurroundingKeypoints, src/frame.cpp:624-650) within
+ * dmaxpxdist, never co-observed (:686-695), mean reprojection distance in the keypoint's keyframes <= dmaxpxdist
+ * (:700-719), MapPoint::computeMinDescDist (Hamming), best / second best with the 0.9 ratio (:723-740); per keypoint the
+ * candidate with the smallest distance, the later one on ties (:754-771).  Host pointers, synchronous. */
+ov2_status ov2_match_to_map(ov2_ctx *ctx, const ov2_match_input *in, float fmaxprojerr, float fdistratio,
+                            int32_t *match_cand /* n_kp */, float *match_dist /* n_kp */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -447,3 +447,30 @@ def stereo_matching(left, right, kps_xy, prior_xy, has_prior, win=9, nlevels=3, 
                                    _p(pri, f32p), _p(hp, u8p), None if lu is None else _p(lu, f32p), int(bool(rectified)),
                                    _p(F, f64p), _p(out, f32p), _p(st, u8p))
     return out, st.astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------------
+# keyframe descriptors and map matching (ov2_oracle_match.c)
+
+def describe_brief(img, pts, pattern):
+    """FeatureExtractor::describeBRIEF with a caller-supplied test table. returns (desc (n,32), valid (n,) bool)"""
+    L = lib()
+    L.ov2o_describe_brief.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(C.c_int8), u8p, u8p]
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    pat = np.ascontiguousarray(pattern, np.int8).reshape(256, 4)
+    n = len(pts)
+    desc, valid = np.zeros((max(n, 1), 32), np.uint8), np.zeros(max(n, 1), np.uint8)
+    L.ov2o_describe_brief(_p(img, u8p), w, h, w, n, _p(pts, f32p), pat.ctypes.data_as(C.POINTER(C.c_int8)), _p(desc, u8p), _p(valid, u8p))
+    return desc[:n], valid[:n].astype(bool)
+
+
+def match_to_map(inp, fmaxprojerr=2.0, fdistratio=0.2):
+    """Mapper::matchToMap on a ov2slam_amd.mapper.MatchInput. returns (match_cand, match_dist)"""
+    L = lib()
+    L.ov2o_match_to_map.argtypes = [C.c_void_p, C.c_float, C.c_float, i32p, f32p]
+    n = inp.c.n_kp
+    mc, md = np.full(max(n, 1), -1, np.int32), np.zeros(max(n, 1), np.float32)
+    L.ov2o_match_to_map(C.addressof(inp.c), fmaxprojerr, fdistratio, _p(mc, i32p), _p(md, f32p))
+    return mc[:n], md[:n]

@@ -23,6 +23,8 @@
 
 #include <stdint.h>
 
+#include "../include/ov2slam_hip.h"   /* shared PODs (ov2_ba_problem, ov2_match_input) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -126,6 +128,13 @@ void ov2o_stereo_matching(const ov2o_pyr *left, const ov2o_pyr *right, int win, 
                           int max_iter, float eps, int n, const float *kps_xy, const float *prior_xy,
                           const uint8_t *has_prior, const float *lunpx_xy, int rectified, const double F_rl[9],
                           float *out_rxy, uint8_t *out_status);
+
+/* ---- keyframe descriptors and map matching (ov2_oracle_match.c) ------------------------------------ */
+/* FeatureExtractor::describeBRIEF (src/feature_extractor.cpp:224-285) with a caller-supplied 256 x 4 test table */
+void ov2o_describe_brief(const uint8_t *img, int w, int h, int stride, int n, const float *pts_xy, const int8_t *pattern,
+                         uint8_t *desc, uint8_t *valid);
+/* Mapper::matchToMap (src/mapper.cpp:576-774) on the flat inputs of ov2_match_input (include/ov2slam_hip.h) */
+void ov2o_match_to_map(const ov2_match_input *in, float fmaxprojerr, float fdistratio, int32_t *match_cand, float *match_dist);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,9 @@ SIGNATURES = {
                                         vp, vp, vp, vp]),
     "ov2_triangulate_pairs_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
                                             vp, vp, vp, vp]),
+    "ov2_describe_brief": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "ov2_describe_brief_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ov2_match_to_map": (C.c_int, [vp, vp, C.c_float, C.c_float, vp, vp]),
     "ov2_pnp_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                       vp, vp, vp]),
 }
