@@ -726,6 +726,29 @@ static void log_iter(ov2_ba_result *R, double cost, double change, double radius
     it->model_cost_change = model; it->step_is_valid = valid; it->step_is_successful = ok;
 }
 
+/* LevenbergMarquardtStrategy: the three state updates minimize() uses, exported so that the values Ceres' own test holds
+ * (levenberg_marquardt_strategy_test.cc:81-150) pin THIS code (tests/test_oracle_ba.py). */
+void ov2o_lm_step_accepted(double *radius, double *decrease_factor, double step_quality, double max_radius)
+{   /* StepAccepted, levenberg_marquardt_strategy.cc:147-153 */
+    *radius = *radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * step_quality - 1.0, 3));
+    *radius = fmin(max_radius, *radius);
+    *decrease_factor = 2.0;
+}
+
+void ov2o_lm_step_rejected(double *radius, double *decrease_factor)
+{   /* StepRejected / StepIsInvalid, :155-164 */
+    *radius = *radius / *decrease_factor;
+    *decrease_factor *= 2.0;
+}
+
+void ov2o_lm_diagonal(int n, const double *colnorm2, double min_diag, double max_diag, double radius, double *diag, double *D)
+{   /* ComputeStep :76-89: diagonal_ = clamp(J'J diagonal), lm_diagonal_ = sqrt(diagonal_ / radius_) */
+    for (int k = 0; k < n; ++k) {
+        if (colnorm2) diag[k] = fmin(fmax(colnorm2[k], min_diag), max_diag);
+        D[k] = sqrt(diag[k] / radius);
+    }
+}
+
 /* eval_pose / eval_lm receive the state of the LAST residual evaluation (ResidualBlock::Evaluate -> the cost functors'
  * cached chi2err_ / isdepthpositive_, src/ceres_parametrization.cpp:136-146): x after IterationZero or an accepted step,
  * the candidate after a rejected step or a FTOL / PTOL exit (trust_region_minimizer.cc:108-131; Ceres does not
@@ -791,10 +814,11 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
 
         /* LevenbergMarquardtStrategy::ComputeStep */
         if (!reuse_diagonal) {
-            prog_colnorm_grad(&g, diag, NULL);
-            for (int k = 0; k < nc; ++k) diag[k] = fmin(fmax(diag[k], o->min_lm_diagonal), o->max_lm_diagonal);
+            prog_colnorm_grad(&g, tmp, NULL);
+            ov2o_lm_diagonal(nc, tmp, o->min_lm_diagonal, o->max_lm_diagonal, radius, diag, lmd);
+        } else {
+            ov2o_lm_diagonal(nc, NULL, o->min_lm_diagonal, o->max_lm_diagonal, radius, diag, lmd);
         }
-        for (int k = 0; k < nc; ++k) lmd[k] = sqrt(diag[k] / radius);
         ov2o_bs_problem bs;
         bs.R = 2; bs.E = e; bs.F = 6; bs.maxf = 2; bs.n_rows = g.n_act; bs.n_e = g.n_e; bs.n_f = g.n_f;
         bs.row_e = g.row_e; bs.row_f = g.row_f; bs.Je = g.Je; bs.Jf = g.Jf; bs.b = g.res; bs.D = lmd;
@@ -823,7 +847,7 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
         }
         if (!valid) {   /* HandleInvalidStep */
             if (++invalid_steps >= o->max_consecutive_invalid_steps) { term = OV2_BA_TERM_FAILURE; break; }
-            radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = 1;   /* StepIsInvalid == StepRejected */
+            ov2o_lm_step_rejected(&radius, &decrease_factor); reuse_diagonal = 1;   /* StepIsInvalid == StepRejected */
             last_ok = 0;
             log_iter(R, x_cost, 0.0, radius, 0.0, model_change, 0, 0);
             continue;
@@ -859,9 +883,7 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
                 for (int c = 0; c < e; ++c) gmax = fmax(gmax, fabs(xl[g.lm_of_e[k] * e + c] - cl[g.lm_of_e[k] * e + c]));
             for (int k = 0; k < g.n_f; ++k)
                 for (int c = 0; c < 7; ++c) gmax = fmax(gmax, fabs(xp[g.pose_of_f[k] * 7 + c] - cp[g.pose_of_f[k] * 7 + c]));
-            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));   /* StepAccepted */
-            radius = fmin(o->max_radius, radius);
-            decrease_factor = 2.0;
+            ov2o_lm_step_accepted(&radius, &decrease_factor, rel, o->max_radius);   /* StepAccepted */
             reuse_diagonal = 0;
             last_ok = 1;
             if (x_cost < minimum_cost) {
@@ -871,7 +893,7 @@ static int minimize(const ov2_ba_problem *P, double *poses, double *lms, const u
             }
             log_iter(R, x_cost, cost_change, radius, rel, model_change, 1, 1);
         } else {                                /* StepRejected */
-            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = 1;
+            ov2o_lm_step_rejected(&radius, &decrease_factor); reuse_diagonal = 1;
             last_ok = 0;
             log_iter(R, cand_cost, cost_change, radius, rel, model_change, 1, 0);
         }

@@ -47,6 +47,11 @@ int ov2o_pnp_solve(int n, const double *unpx, const double *wpts, const int *sca
 void ov2o_ba_default_options(ov2_ba_options *o, float robust_mono_th);
 int ov2o_ba_solve(const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R);
 
+/* LevenbergMarquardtStrategy state updates used by the oracle's minimize() (levenberg_marquardt_strategy.cc:76-164) */
+void ov2o_lm_step_accepted(double *radius, double *decrease_factor, double step_quality, double max_radius);
+void ov2o_lm_step_rejected(double *radius, double *decrease_factor);
+void ov2o_lm_diagonal(int n, const double *colnorm2, double min_diag, double max_diag, double radius, double *diag, double *D);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """CPU tests of the BA oracle (no GPU): pinned against the known answers the vendored Ceres 2.0.0 tests hold as
 text (tests/golden/ceres_known_answers.json), finite differences, an independent numpy/scipy restatement, and
 self-consistency (zero-noise windows converge to ground truth)."""
+import ctypes as C
 import json
 import os
 
@@ -118,21 +119,33 @@ def test_corrector_and_huber_known_answers(oracle):
             assert abs(rho[2] - fd2) < 1e-5
 
 
-def test_lm_radius_and_diagonal_known_answers():
-    """levenberg_marquardt_strategy_test.cc:81-150 replayed on the formulas the oracle's minimize() uses."""
+def test_lm_radius_and_diagonal_known_answers(oracle):
+    """levenberg_marquardt_strategy_test.cc:81-150 replayed on the C functions the oracle's minimize() calls for its
+    radius / LM-diagonal updates (ov2o_lm_step_accepted / _rejected / ov2o_lm_diagonal)."""
+    L = oracle.lib()
+    dp = C.POINTER(C.c_double)
+    L.ov2o_lm_step_accepted.argtypes = [dp, dp, C.c_double, C.c_double]
+    L.ov2o_lm_step_rejected.argtypes = [dp, dp]
+    L.ov2o_lm_diagonal.argtypes = [C.c_int, dp, C.c_double, C.c_double, C.c_double, dp, dp]
     g = GOLD["lm_radius_sequence"]
-    radius, dec = g["initial_radius"], 2.0
+    radius, dec = C.c_double(g["initial_radius"]), C.c_double(2.0)
     for kind, q, expect in g["events"]:
         if kind == "reject":
-            radius, dec = radius / dec, dec * 2
+            L.ov2o_lm_step_rejected(C.byref(radius), C.byref(dec))
         else:
-            radius = min(g["max_radius"], radius / max(1 / 3, 1 - (2 * q - 1) ** 3))
-            dec = 2.0
-        assert radius == pytest.approx(expect, rel=1e-15)
+            L.ov2o_lm_step_accepted(C.byref(radius), C.byref(dec), q, g["max_radius"])
+            assert dec.value == 2.0
+        assert radius.value == pytest.approx(expect, rel=1e-15)
     d = GOLD["lm_diagonal"]
-    J = np.array(d["jacobian"])
-    diag = np.clip((J ** 2).sum(0), d["min_lm_diagonal"], d["max_lm_diagonal"])
-    assert np.allclose(np.sqrt(diag / d["radius"]), d["expected_D"])
+    J = np.array(d["jacobian"], float)
+    cn = np.ascontiguousarray((J ** 2).sum(0))
+    diag, D = np.zeros(len(cn)), np.zeros(len(cn))
+    L.ov2o_lm_diagonal(len(cn), cn.ctypes.data_as(dp), d["min_lm_diagonal"], d["max_lm_diagonal"], d["radius"], diag.ctypes.data_as(dp),
+                       D.ctypes.data_as(dp))
+    assert np.allclose(D, d["expected_D"])
+    # reuse_diagonal: the stored diagonal with a new radius
+    L.ov2o_lm_diagonal(len(cn), None, d["min_lm_diagonal"], d["max_lm_diagonal"], 4 * d["radius"], diag.ctypes.data_as(dp), D.ctypes.data_as(dp))
+    assert np.allclose(D, np.array(d["expected_D"]) / 2)
 
 
 def test_se3_exp_against_matrix_exponential(oracle):
