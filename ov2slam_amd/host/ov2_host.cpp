@@ -999,6 +999,58 @@ ov2_status Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)
     return s;
 }
 
+ov2_status Optimizer::structureOnlyBA(const std::vector<int> &vlm2optids)
+{   // src/optimizer.cpp:2594-2781: every keyframe pose constant, the listed map points free (XYZ), Huber loss, 10 LM
+    // iterations, no chi2 flags / no L2 pass; the wall-clock cap (:2749) is not applied
+    auto pkf0 = pmap_->getKeyframe(0);
+    if (!pkf0) return OV2_OK;
+    LocalBAProblem pb;
+    for (const int lmid : vlm2optids) {
+        auto plm = pmap_->getMapPoint(lmid);
+        if (plm == nullptr) continue;
+        const int il = (int)pb.lm_lmid.size();
+        pb.lm_lmid.push_back(lmid);
+        const Vec3 pt = plm->getPoint();
+        pb.lm.push_back(pt.x); pb.lm.push_back(pt.y); pb.lm.push_back(pt.z);
+        for (const int kfid : plm->getKfObsSet()) {
+            auto pkf = pmap_->getKeyframe(kfid);
+            if (pkf == nullptr) continue;
+            const Keypoint kp = pkf->getKeypointById(lmid);
+            if (kp.lmid_ != lmid) continue;
+            auto it = pb.kfid_to_pose.find(kfid);
+            if (it == pb.kfid_to_pose.end()) {
+                it = pb.kfid_to_pose.emplace(kfid, (int)pb.pose_kfid.size()).first;
+                pb.pose_kfid.push_back(kfid);
+                const SE3 T = pkf->getTwc();
+                pb.pose.insert(pb.pose.end(), T.v.begin(), T.v.end());
+                pb.pose_const.push_back(1);                                            // SetParameterBlockConstant :2677
+            }
+            const double sigma = std::pow(2., kp.scale_);
+            pb.res_type.push_back(OV2_BA_L_XYZ); pb.res_pose.push_back(it->second); pb.res_lm.push_back(il);
+            pb.res_uv.push_back(kp.unpx_.x); pb.res_uv.push_back(kp.unpx_.y); pb.res_sigma.push_back(sigma);
+            if (kp.is_stereo_) {                                                       // :2682-2703
+                pb.res_type.push_back(OV2_BA_R_XYZ); pb.res_pose.push_back(it->second); pb.res_lm.push_back(il);
+                pb.res_uv.push_back(kp.runpx_.x); pb.res_uv.push_back(kp.runpx_.y); pb.res_sigma.push_back(sigma);
+            }
+        }
+    }
+    if (pb.res_type.empty()) return OV2_OK;
+    SlamParams st = *pslamstate_;
+    st.buse_inv_depth_ = false;
+    ov2_ba_problem p = pb.view(st, *pkf0);
+    p.lm_anchor_pose = nullptr; p.lm_anchor_uv = nullptr;
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    o.max_iters = 10;                                                                  // :2747
+    o.l2_refine = 0;
+    std::memset(&last_result_, 0, sizeof(last_result_));
+    const ov2_status s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    if (s != OV2_OK) return s;
+    for (size_t i = 0; i < pb.lm_lmid.size(); ++i)                                     // :2769-2777
+        pmap_->updateMapPoint(pb.lm_lmid[i], Vec3{pb.lm[3 * i], pb.lm[3 * i + 1], pb.lm[3 * i + 2]});
+    return OV2_OK;
+}
+
 ov2_status Estimator::applyLocalBA()
 {   // src/estimator.cpp:67-98
     const int nmincstkfs = pslamstate_->mono_ ? 2 : 1;

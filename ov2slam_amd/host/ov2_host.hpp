@@ -265,6 +265,8 @@ public:
     Optimizer(ov2_ctx *ctx, std::shared_ptr<SlamParams> pstate, std::shared_ptr<MapManager> pmap)
         : ctx_(ctx), pslamstate_(pstate), pmap_(pmap) {}
     ov2_status localBA(Frame &newframe, const bool buse_robust_cost);
+    // src/optimizer.cpp:2594-2781: points-only refinement (all poses constant, XYZ, Huber, 10 iterations) through ov2_ba_solve
+    ov2_status structureOnlyBA(const std::vector<int> &vlm2optids);
     // the three stages, exposed for tests
     void setupLocalBA(Frame &newframe, LocalBAProblem &pb);                                   // :43-430
     // the same stage from the device map mirror (ov2_map_local_ba_setup): linear scans instead of the hash-map walk

@@ -287,6 +287,17 @@ int ov2h_apply_local_ba(void *p, void *ctx, int newkf, int *n_outliers1, int *n_
     return s;
 }
 
+// Optimizer::structureOnlyBA(vlm2optids) on the GPU context `ctx`
+int ov2h_structure_only_ba(void *p, void *ctx, int n, const int *lmids, double *final_cost, int *n_iters)
+{
+    HostMap *m = (HostMap *)p;
+    Optimizer opt((ov2_ctx *)ctx, m->st, m->map);
+    const ov2_status s = opt.structureOnlyBA(std::vector<int>(lmids, lmids + n));
+    if (final_cost) *final_cost = opt.last_result_.final_cost;
+    if (n_iters) *n_iters = opt.last_result_.n_log - 1;
+    return s;
+}
+
 // VisualFrontEnd::computePose on keyframe `kfid` taken as the current frame, starting from pose Twc7_init
 int ov2h_compute_pose(void *p, void *ctx, int kfid, const double *Twc7_init, int *p3p_req)
 {

@@ -47,6 +47,7 @@ def lib():
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
         L.ov2h_count_keypoints.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ov2h_structure_only_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, dp, ip]
         fpp = C.POINTER(C.c_float)
         L.ov2h_map_add_kp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, dp]
         L.ov2h_frame_init_grid.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -177,6 +178,13 @@ class HostMap:
         req = C.c_int()
         st = lib().ov2h_compute_pose(self.h, ctx.h, kfid, _dp(np.ascontiguousarray(Twc_init, np.float64)), C.byref(req))
         return st, bool(req.value)
+
+    def structure_only_ba(self, ctx, lmids):
+        """Optimizer::structureOnlyBA(vlm2optids) (src/optimizer.cpp:2594-2781). returns (status, final cost, LM iterations)"""
+        ids = np.ascontiguousarray(lmids, np.int32)
+        cost, it = C.c_double(0), C.c_int(0)
+        st = lib().ov2h_structure_only_ba(self.h, ctx.h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cost), C.byref(it))
+        return st, cost.value, it.value
 
     def pose(self, kfid):
         out = np.zeros(7)

@@ -119,3 +119,31 @@ def test_compute_pose_equals_flat_pnp(ctx):
     nb_after, nb3d_after, _ = hm.counts(k)
     assert nb_before - nb_after == len(idx) and nb3d_before - nb3d_after == len(idx)
     assert 0 < len(idx) < 0.5 * len(lmids)
+
+
+@pytest.mark.gpu
+def test_structure_only_ba(ctx, oracle):
+    """Optimizer::structureOnlyBA (src/optimizer.cpp:2594-2781) through the C++ host mirror: every pose constant, the
+    listed map points free (XYZ), Huber loss, 10 LM iterations, no flags / L2 pass -- against the oracle's solve of the
+    same flat problem"""
+    from ov2slam_amd import local_ba
+    P = synth_ba.make_window(10, 400, inv_depth=False, seed=29)
+    P.res_uv = P.res_uv.astype(np.float32).astype(np.float64)          # keypoints are cv::Point2f in the map
+    hm = host_map.HostMap(P)
+    ids = np.arange(len(P.lm), dtype=np.int32)[::2]                     # refine every second map point
+    st, cost, its = hm.structure_only_ba(ctx, ids)
+    assert st == 0 and its >= 1
+    # the same problem, flat: rows of the chosen landmarks, all poses constant
+    keep = np.isin(P.res_lm, ids)
+    remap = -np.ones(len(P.lm), np.int32); remap[ids] = np.arange(len(ids))
+    Q = T.BaProblem(P.calib_l, P.calib_r, P.T_rl, 0, P.pose, np.ones(len(P.pose), np.uint8), P.lm[ids], None, None,
+                    P.res_type[keep], P.res_pose[keep], remap[P.res_lm[keep]], P.res_uv[keep])
+    o = oracle.ba_default_options()
+    o.max_iters, o.l2_refine = 10, 0
+    R = oracle.ba_solve(Q, o)
+    assert cost == pytest.approx(R.c.final_cost, rel=1e-9) and its == R.c.n_log - 1
+    for k, l in enumerate(ids):
+        xyz, _ = hm.landmark(int(l))
+        assert np.abs(xyz - Q.lm[k]).max() <= 1e-9 * max(1.0, np.abs(Q.lm[k]).max())
+    untouched, _ = hm.landmark(1)
+    assert np.array_equal(untouched, P.lm[1])
