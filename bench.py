@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--kps", type=int, default=2048, help="keypoints per frame (north_star: ~2k)")
     ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per stream (ping-pong cycle)")
+    ap.add_argument("--frame-gap", type=int, default=3, help="stream frames between consecutive bench frames (flow of ~0.6 px per unit)")
+    ap.add_argument("--prior-sigma", type=float, default=1.0,
+                    help="noise (px) of the motion-model priors; a harder stream (--frame-gap 9 --prior-sigma 3) makes every level "
+                         "pass take more LK iterations (the executed mean is reported in config.lk_iterations_per_level_pass)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH cpu_baseline leg (1 thread, N threads)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the N-thread LK leg (0 = host CPU share, at most 16)")
     ap.add_argument("--instr-batches", type=int, default=300, help="frame-batches of the instrumented (per-kernel hipEvent) pass")
@@ -100,12 +104,13 @@ def pyr_level_bytes(w, h, nlevels):
 class Workload:
     """everything resident in HBM: per cycle position c, the left/right image batches, keypoints, priors."""
 
-    def __init__(self, ctx, fe, synth, seqs, kps, nframes, seed):
+    def __init__(self, ctx, fe, synth, seqs, kps, nframes, seed, gap=3, prior_sigma=1.0):
         self.ctx, self.fe, self.B, self.N = ctx, fe, seqs, kps
+        self.gap, self.prior_sigma = gap, prior_sigma
         S = synth.StereoStream(seed=seed)
         F = nframes
-        left = [S.left(3 * t) for t in range(F)]    # 3 stream-frames apart: flow of 1-2 px per step
-        right = [S.right(3 * t) for t in range(F)]
+        left = [S.left(gap * t) for t in range(F)]    # `gap` stream-frames apart: flow of 1-2 px per step at gap 3
+        right = [S.right(gap * t) for t in range(F)]
         order = list(range(F)) + list(range(F - 2, 0, -1))   # ping-pong so consecutive frames are adjacent
         self.L = L = len(order)
         self.trk = fe.FeatureTracker(ctx, 30, 0.01)
@@ -122,9 +127,9 @@ class Workload:
                 il.upload(b, left[cur])
                 ir.upload(b, right[cur])
                 # keypoints live in the PREVIOUS frame; the prior is the motion-model prediction in the current one
-                gt = S.flow(3 * prv, 3 * cur, base)
-                pri, has = synth.make_priors(base, gt, seed=seed + 11 + 31 * c + b)
-                spri, shas = synth.make_priors(base, S.stereo_gt(base), seed=seed + 13 + 31 * c + b)
+                gt = S.flow(gap * prv, gap * cur, base)
+                pri, has = synth.make_priors(base, gt, sigma=prior_sigma, seed=seed + 11 + 31 * c + b)
+                spri, shas = synth.make_priors(base, S.stereo_gt(base), sigma=prior_sigma, seed=seed + 13 + 31 * c + b)
                 k_all.append(base); p_all.append(pri); h_all.append(has); sp_all.append(spri); sh_all.append(shas)
             self.left.append(il); self.right.append(ir)
             self.kps.append(ctx.to_device(np.concatenate(k_all)))
@@ -285,8 +290,8 @@ def cpu_baseline(workload, kf_every, budget_s, threads=1):
     tpri, spri = [], []
     for s in range(L):
         cur_i, prv_i = order[s % L], order[(s - 1) % L]
-        tpri.append(synth.make_priors(base, S.flow(3 * prv_i, 3 * cur_i, base), seed=1 + s))
-        spri.append(synth.make_priors(base, S.stereo_gt(base), seed=2 + s))
+        tpri.append(synth.make_priors(base, S.flow(workload.gap * prv_i, workload.gap * cur_i, base), sigma=workload.prior_sigma, seed=1 + s))
+        spri.append(synth.make_priors(base, S.stereo_gt(base), sigma=workload.prior_sigma, seed=2 + s))
     t0 = time.perf_counter()
     prev, frames, s = None, 0, 0
     while True:
@@ -331,7 +336,7 @@ def main():
 
     from ov2slam_amd import frontend as fe, synth
     ctx = fe.Context(local)
-    wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank)
+    wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank, gap=a.frame_gap, prior_sigma=a.prior_sigma)
 
     if a.mapper_ctx:
         wl.enable_mapper_ctx(local)
@@ -414,6 +419,14 @@ def main():
                            "windows_per_batch": (ba.solves / ba.batches) if ba.batches else 0.0,
                            "mode": ba.mode,
                            "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
+        # one LM iteration touches every residual block once (32 B record + 16 B residual + 208 B jacobian for
+        # the inverse-depth functors), S twice and the parameters once
+        n_free = int((ba.P0.pose_const == 0).sum())
+        it_bytes = ba.P0.n_res * 256.0 + 2.0 * (6 * n_free) ** 2 * 8.0 + (7 * len(ba.P0.pose) + len(ba.P0.lm)) * 8.0
+        lb = out["local_ba"]
+        lb["roofline"] = {"bound": "hbm", "alg_bytes_per_lm_iteration": it_bytes, "achieved": lb["value"] * it_bytes / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lb["value"] * it_bytes / 1e9 / HBM_PEAK_GBS,
+                          "note": "LM iterations/s of all windows x algorithmic bytes of one iteration, concurrent with the front-end"}
         out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"
 
     if rank == 0 and not a.no_roofline:
@@ -431,6 +444,7 @@ def main():
         # algorithmic bytes per launch: KLT from the executed work words of a representative pass over the cycle
         n = wl.n
         per_pos = []
+        lk_passes = lk_iters = 0.0
         for _ in range(wl.L):
             cpos = wl.step_no % wl.L
             wl.step(10 ** 9, want_work=True)      # no KF => work words belong to the temporal launch
@@ -441,6 +455,8 @@ def main():
             wa = np.concatenate([w[:n], w[n:][~hp]])
             wb = w[n:][hp]
             per_pos.append((lk_bytes(wa), lk_bytes(wb), lk_ops(wa), lk_ops(wb)))
+            wall = np.concatenate([wa, wb]).astype(np.uint32)
+            lk_passes += float((wall >> 16).sum()); lk_iters += float((wall & 0xffff).sum())
         b1 = float(np.mean([p[0] for p in per_pos]))
         b2 = float(np.mean([p[1] for p in per_pos]))
         ops = {"klt_stage1_kernel": float(np.mean([p[2] for p in per_pos])),
@@ -486,6 +502,10 @@ def main():
             out["roofline"]["valu"] = {"achieved": rl[dom]["achieved_Tops"], "peak": VALU_PEAK_TOPS, "unit": "Tiop/s",
                                        "frac": rl[dom]["valu_frac"]}
         out["kernels"] = rl
+        # executed LK work of the temporal tracking (work words of the kernels): how hard the stream is
+        out["config"]["lk_level_passes_per_keypoint"] = lk_passes / (wl.L * n)
+        out["config"]["lk_iterations_per_level_pass"] = lk_iters / max(lk_passes, 1.0)
+        out["config"]["frame_gap"], out["config"]["prior_sigma_px"] = a.frame_gap, a.prior_sigma
         out["ms_per_frame_batch_instrumented"] = 1e3 * el_instr / n_instr
 
     do_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline   # the CPU leg is reported at N = 1 only

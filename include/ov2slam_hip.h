@@ -483,6 +483,12 @@ typedef struct ov2_match_input {
 ov2_status ov2_match_to_map(ov2_ctx *ctx, const ov2_match_input *in, float fmaxprojerr, float fdistratio,
                             int32_t *match_cand /* n_kp */, float *match_dist /* n_kp */);
 
+/* ---- diagnostics -----------------------------------------------------------------------------------
+ * Reads a device buffer of nrows x stride_bytes exactly once with the access pattern of the KLT window staging (each lane of
+ * a wave loads 16 bytes from a different row): a known byte count to calibrate rocprofv3's FETCH_SIZE on that pattern
+ * (scripts/fetch_calib.sh).  d_out: nrows words.  Asynchronous. */
+ov2_status ov2_dbg_rowload16(ov2_ctx *ctx, const void *d_buf, size_t stride_bytes, size_t nrows, uint32_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

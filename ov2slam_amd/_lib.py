@@ -80,6 +80,7 @@ SIGNATURES = {
                                         vp, vp, vp, vp]),
     "ov2_triangulate_pairs_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
                                             vp, vp, vp, vp]),
+    "ov2_dbg_rowload16": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, vp]),
     "ov2_describe_brief": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "ov2_describe_brief_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
     "ov2_match_to_map": (C.c_int, [vp, vp, C.c_float, C.c_float, vp, vp]),

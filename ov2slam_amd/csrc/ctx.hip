@@ -337,3 +337,31 @@ extern "C" ov2_status ov2_ktime_report(ov2_ctx *c, int max_kernels, const char *
     *n_out = n;
     return OV2_OK;
 }
+
+// ---- diagnostics ------------------------------------------------------------------------------------------------
+// PMC calibration of the KLT staging pattern (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own
+// access pattern"): every lane of a wave loads 16 bytes from a DIFFERENT row (rows `stride` bytes apart, as the KLT
+// kernels fetch one window row per lane), column by column, until the whole buffer has been read exactly once.
+__global__ __launch_bounds__(64) void dbg_rowload16_kernel(const uint4 *__restrict__ buf, size_t stride16, size_t nrows,
+                                                           unsigned *__restrict__ out)
+{
+    const size_t r = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= nrows) return;
+    const uint4 *row = buf + r * stride16;
+    unsigned acc = 0;
+    for (size_t c = 0; c < stride16; ++c) {
+        const uint4 v = row[c];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    out[r] = acc;
+}
+
+extern "C" ov2_status ov2_dbg_rowload16(ov2_ctx *c, const void *d_buf, size_t stride_bytes, size_t nrows, uint32_t *d_out)
+{
+    if (!c || !d_buf || !d_out || stride_bytes % 16 || !nrows) return OV2_ERR_INVALID;
+    OV2_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(dbg_rowload16_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, c->stream, (const uint4 *)d_buf,
+                       stride_bytes / 16, nrows, d_out);
+    OV2_HIP(c, hipGetLastError());
+    return OV2_OK;
+}
