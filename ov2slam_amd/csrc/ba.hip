@@ -34,6 +34,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 
 #include <algorithm>
@@ -705,6 +706,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)   // lane mus
     return __longlong_as_double(((long long)hi << 32) | lo);
 }
 
+// n doubles (n even) from a 16-byte aligned address as 16-byte loads
+template <int N>
+__device__ __forceinline__ void load_d2(const double *__restrict__ p, double *out)
+{
+    const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) { const double2 v = q[i]; out[2 * i] = v.x; out[2 * i + 1] = v.y; }
+}
+
 __device__ __forceinline__ double row_sum(double v)
 {
     v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -773,11 +783,10 @@ __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int
     for (int c = 0; c < 27; ++c) acc[c] = 0.0;
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
         const int ent = pose_ent[k], r = ent >> 1;
-        const double *Jp = d.Jf + (size_t)r * 24 + (ent & 1) * 12;
-        double J[12];
-#pragma unroll
-        for (int c = 0; c < 12; ++c) J[c] = Jp[c];
-        const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
+        double J[12], bb[2];
+        load_d2<12>(d.Jf + (size_t)r * 24 + (ent & 1) * 12, J);
+        load_d2<2>(d.res + 2 * (size_t)r, bb);
+        const double b0 = bb[0], b1 = bb[1];
 #pragma unroll
         for (int t = 0; t < 21; ++t) acc[t] += J[c_tri_i[t]] * J[c_tri_j[t]] + J[6 + c_tri_i[t]] * J[6 + c_tri_j[t]];
 #pragma unroll
@@ -1723,18 +1732,15 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
         for (int i = 0; i < 36; ++i) ffa[i] = 0.0;
         for (int r2 = C.cell_row[c0 + c]; r2 < r1 && d.fk[r2] == fk; ++r2) {
             double J2[12], Je2[2 * E];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) J2[i] = d.Jf[(size_t)r2 * 24 + i];
-#pragma unroll
-            for (int i = 0; i < 2 * E; ++i) Je2[i] = d.Je[(size_t)r2 * 2 * E + i];
+            load_d2<12>(d.Jf + (size_t)r2 * 24, J2);
+            load_d2<2 * E>(d.Je + (size_t)r2 * 2 * E, Je2);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int k = 0; k < E; ++k) Wk[i * E + k] += J2[i] * Je2[k] + J2[6 + i] * Je2[E + k];
             if (do_ffa && d.fa[r2] >= 0) {
                 double Ja[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) Ja[i] = d.Jf[(size_t)r2 * 24 + 12 + i];
+                load_d2<12>(d.Jf + (size_t)r2 * 24 + 12, Ja);
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -2037,7 +2043,7 @@ ov2_status upload_batch(ba_solver &S)
     HC(R.res_off, h_ro, B + 1); HC(R.lm_off, h_lo, B + 1); HC(R.pose_off, h_po, B + 1);
     HC(d_xp, h_xp, 7 * NP); HC(d_xl, h_xl, e * L); HC(d_W, h_W, B); HC(d_wc, h_wc, B);
 #undef HC
-    for (int w = 0; w < B; ++w) {
+    auto stage_window = [&](int w) {
         const ov2_ba_problem &P = S.P[w];
         const size_t r0 = (size_t)S.res_off[w], l0 = (size_t)S.lm_off[w], p0 = (size_t)S.pose_off[w];
         const size_t nr = (size_t)P.n_res, nl = (size_t)P.n_lm, np = (size_t)P.n_pose;
@@ -2065,6 +2071,17 @@ ov2_status upload_batch(ba_solver &S)
         ba_wconst &K = h_wc[w];
         for (int i = 0; i < 4; ++i) { K.Kl[i] = P.calib_l[i]; K.Kr[i] = P.calib_r[i]; }
         pose_Rt(P.T_rl, K.Rrl, K.trl);
+    };
+    {   // a batch of 64 windows is ~200 MB of host copies: a few threads, windows dealt round-robin (disjoint destinations)
+        const int nthr = (n > (4u << 20) && B >= 4) ? std::min(8, B) : 1;
+        if (nthr <= 1) {
+            for (int w = 0; w < B; ++w) stage_window(w);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthr; ++t) th.emplace_back([&, t] { for (int w = t; w < B; w += nthr) stage_window(w); });
+            for (int w = 0; w < B; w += nthr) stage_window(w);
+            for (auto &x : th) x.join();
+        }
     }
     memcpy(h_ro, S.res_off.data(), sizeof(int) * (B + 1));
     memcpy(h_lo, S.lm_off.data(), sizeof(int) * (B + 1));
