@@ -6,7 +6,7 @@
  * Ceres 2.0.0 TrustRegionMinimizer / LevenbergMarquardtStrategy semantics as ov2_oracle_ba.c.  The reference asks for
  * DENSE_QR on [J; D]; the regularised normal equations (J'J + D'D) y = J'r solved here by Cholesky are the same
  * least-squares problem (6 unknowns, condition number small), differing at the 1e-15 level.
- * Deviations kept on purpose: no 5 ms wall-clock cap; outlier flags at the final accepted state.
+ * Deviations kept on purpose: no 5 ms wall-clock cap; outlier flags are read at the last EVALUATED pose, as the reference's cached functor fields are.
  * Parity: unpinned by any reference fixture; pinned by the shared BA pieces (see ov2_oracle_ba.c) and the tests.
  */
 #include "ov2_oracle_ba.h"
@@ -115,10 +115,14 @@ static double pnp_accumulate(const pnp_pb *P, const double *x, double *H, double
     return cost;
 }
 
-static int pnp_minimize(const pnp_pb *P, double *Twc, const ov2_ba_options *o, int max_iters, int *n_iter)
+/* Teval receives the pose of the LAST residual evaluation: the reference reads the cost functors' cached chi2err_ /
+ * isdepthpositive_ after Solve (src/multi_view_geometry.cpp:559-571), i.e. x after an accepted last step, the candidate
+ * after a rejected one or a FTOL / PTOL exit (Ceres does not re-evaluate after Solve) */
+static int pnp_minimize(const pnp_pb *P, double *Twc, const ov2_ba_options *o, int max_iters, int *n_iter, double *Teval)
 {
     double x[7], cand[7], H[36], g[6], scale[6], diag[6];
     memcpy(x, Twc, sizeof(x));
+    memcpy(Teval, x, sizeof(x));
     double x_cost = pnp_accumulate(P, x, H, g);
     for (int c = 0; c < 6; ++c) scale[c] = o->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[c * 6 + c])) : 1.0;
     double minimum_cost = x_cost, x_norm = -1.0, radius = o->initial_radius, dec = 2.0;
@@ -159,6 +163,7 @@ static int pnp_minimize(const pnp_pb *P, double *Twc, const ov2_ba_options *o, i
         for (int c = 0; c < 6; ++c) delta[c] = step[c] * scale[c];
         ov2o_se3_plus(x, delta, cand);
         const double cand_cost = pnp_accumulate(P, cand, NULL, NULL);
+        memcpy(Teval, cand, sizeof(cand));
         double sn = 0;
         for (int c = 0; c < 7; ++c) sn += (x[c] - cand[c]) * (x[c] - cand[c]);
         if (sqrt(sn) <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { term = OV2_BA_TERM_PTOL; break; }
@@ -194,13 +199,14 @@ int ov2o_pnp_solve(int n, const double *unpx, const double *wpts, const int *sca
     double T[7];
     memcpy(T, Twc, sizeof(T));
     int it1 = 0, it2 = 0;
-    int term = pnp_minimize(&P, T, &o, max_iters, &it1);
+    double Te[7];
+    int term = pnp_minimize(&P, T, &o, max_iters, &it1, Te);
     int nbad = 0;
     for (int i = 0; i < n; ++i) {
         double r[2], J[12], chi2;
         int dp;
         const double inv_sigma = 1.0 / (scales ? pow(2., scales[i]) : 1.0);
-        pnp_eval(T, K, wpts + 3 * i, unpx + 2 * i, inv_sigma, 0, r, J, &chi2, &dp);
+        pnp_eval(Te, K, wpts + 3 * i, unpx + 2 * i, inv_sigma, 0, r, J, &chi2, &dp);
         if (chi2 > (double)chi2th || !dp) {
             outlier[i] = 1; ++nbad;
             if (l2_after_robust) active[i] = 0;
@@ -210,7 +216,7 @@ int ov2o_pnp_solve(int n, const double *unpx, const double *wpts, const int *sca
     if (nbad == n) { free(active); return 0; }
     if (l2_after_robust && nbad > 0) {
         P.use_loss = 0;
-        term = pnp_minimize(&P, T, &o, max_iters, &it2);
+        term = pnp_minimize(&P, T, &o, max_iters, &it2, Te);
         if (iters) iters[1] = it2;
     }
     memcpy(Twc, T, sizeof(T));

@@ -235,11 +235,13 @@ __device__ inline bool chol6(const double *A, const double *b, double *x)
 }
 
 // TrustRegionMinimizer on one pose; T = best pose on return; returns termination code
+// Te receives the pose of the LAST residual evaluation (the reference flags outliers from the cost functors' cached
+// chi2err_ / isdepthpositive_, src/multi_view_geometry.cpp:559-571: x after an accepted last step, the candidate otherwise)
 __device__ inline int pnp_minimize(const pnp_frame &F, double *T, const pnp_params &P, bool use_removed, int use_loss,
-                                   double (*sh)[28], int *n_iter)
+                                   double (*sh)[28], int *n_iter, double *Te)
 {
     double x[7], acc[28], H[36], g[6], scale[6], diag[6];
-    for (int c = 0; c < 7; ++c) x[c] = T[c];
+    for (int c = 0; c < 7; ++c) { x[c] = T[c]; Te[c] = T[c]; }
     auto unpack = [&]() {
         int t = 7;
         for (int p = 0; p < 6; ++p) {
@@ -293,6 +295,7 @@ __device__ inline int pnp_minimize(const pnp_frame &F, double *T, const pnp_para
         pnp_accumulate<false>(F, cand, use_removed, use_loss, P.huber_a, cacc);
         block_sum<1>(cacc, sh);
         const double cand_cost = cacc[0];
+        for (int c = 0; c < 7; ++c) Te[c] = cand[c];
         double sn = 0;
         for (int c = 0; c < 7; ++c) sn += (x[c] - cand[c]) * (x[c] - cand[c]);
         if (sqrt(sn) <= P.ptol * (x_norm + P.ptol)) { term = OV2_BA_TERM_PTOL; break; }
@@ -335,15 +338,16 @@ __global__ __launch_bounds__(256) void pnp_kernel(int B, const int *__restrict__
     double T[7];
     for (int c = 0; c < 7; ++c) T[c] = Twc[7 * b + c];
     int it1 = 0, it2 = 0;
-    int term = pnp_minimize(F, T, P, false, P.use_robust, sh, &it1);
-    // chi2 / depth flags at the solution (:551-565)
+    double Te[7];
+    int term = pnp_minimize(F, T, P, false, P.use_robust, sh, &it1, Te);
+    // chi2 / depth flags as the functors cached them at their last evaluation (:551-565)
     double R[9];
-    quat_R(T, R);
+    quat_R(Te, R);
     int nbad = 0;
     for (int i = F.i0 + tid; i < F.i1; i += 256) {
         const double inv_sigma = 1.0 / (scales ? exp2((double)scales[i]) : 1.0);
         const double *wp = wpts + 3 * (size_t)i;
-        const double d[3] = {wp[0] - T[0], wp[1] - T[1], wp[2] - T[2]};
+        const double d[3] = {wp[0] - Te[0], wp[1] - Te[1], wp[2] - Te[2]};
         const double cam[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
                                R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
         const double invz = 1.0 / cam[2];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void pnp_kernel(int B, const int *__restrict__
     int ok = 1;
     if (nbad == n) ok = 0;   // every point flagged: return false, pose untouched (:567-569)
     else {
-        if (P.l2_after_robust && nbad > 0) term = pnp_minimize(F, T, P, true, 0, sh, &it2);
+        if (P.l2_after_robust && nbad > 0) term = pnp_minimize(F, T, P, true, 0, sh, &it2, Te);
         if (tid < 7) Twc[7 * b + tid] = T[tid];
         ok = term != OV2_BA_TERM_FAILURE;
     }
