@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--ba-workers", type=int, default=1,
                     help="Estimator threads per GPU (the reference runs one per SLAM instance; each owns a share of the "
                          "sequences and its own high-priority HIP context)")
+    ap.add_argument("--ba-priority", default="high", choices=["high", "normal"],
+                    help="HIP stream priority of the local-BA workers: high = a pending batch takes the device as soon as it has "
+                         "work (the reference's Estimator thread never waits for the front-end), normal = equal sharing")
     ap.add_argument("--ba-batch", type=int, default=64, help="most windows one ov2_ba_solve_batch call of a worker takes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnp", action="store_true",
@@ -235,18 +238,19 @@ class BaWorker:
     newest).  The loop is a NATIVE thread of libov2host.so (ov2slam_amd/host/ov2_host_capi.cpp): a Python thread here
     fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
-    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64):
+    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64, high_priority=True):
         from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
         workers = max(1, min(workers, seqs))
         share = [seqs // workers + (1 if k < seqs % workers else 0) for k in range(workers)]
-        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k], max_batch=max_batch) for k in range(workers)]
+        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k], max_batch=max_batch, high_priority=high_priority)
+                   for k in range(workers)]
         for w in self.ws:
             w.submit_all()                        # warm-up (allocations, code objects); not counted
         self.solves = self.iters = self.dropped = self.submitted = 0
         self.busy_s = 0.0
         self.batches = 0
-        self.mode = (f"{workers} native worker thread(s), each on its own high-priority HIP stream, concurrent with the front-end; a "
+        self.mode = (f"{workers} native worker thread(s), each on its own {'high' if high_priority else 'normal'}-priority HIP stream, concurrent with the front-end; a "
                      f"worker solves the windows of all its sequences that have a keyframe pending in ONE ov2_ba_solve_batch "
                      f"call (<= {max_batch} windows; reference: one Estimator thread per SLAM instance, src/estimator.cpp:32-98); "
                      "robust solve (<=5 it) + L2 (<=10 it); a newer keyframe of a sequence replaces its pending one")
@@ -344,7 +348,8 @@ def main():
         wl.enable_pnp(seed=777 + rank)
     ba = None
     if not a.no_ba:
-        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers, max_batch=a.ba_batch)
+        ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers, max_batch=a.ba_batch,
+                      high_priority=a.ba_priority == "high")
     def run_step():
         """one bench step = a.chunk frame-batches; returns the number of keyframe batches it held"""
         k = 0

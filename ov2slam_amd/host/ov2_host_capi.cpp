@@ -413,11 +413,11 @@ struct BaWorkerNative {
     }
 };
 
-void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq, int max_batch)
+void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq, int max_batch, int high_priority)
 {
     BaWorkerNative *w = new BaWorkerNative();
     w->max_batch = max_batch > 0 ? max_batch : 1;
-    if (ov2_ctx_create_ex(device, 1, &w->ctx) != OV2_OK) { delete w; return nullptr; }   // high-priority stream
+    if (ov2_ctx_create_ex(device, high_priority ? 1 : 0, &w->ctx) != OV2_OK) { delete w; return nullptr; }
     const int e = P->inv_depth ? 1 : 3;
     w->pose0.assign(P->pose, P->pose + 7 * (size_t)P->n_pose);
     w->lm0.assign(P->lm, P->lm + (size_t)e * P->n_lm);

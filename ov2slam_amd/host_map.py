@@ -33,7 +33,7 @@ def lib():
         L.ov2h_map_bad_lmids.argtypes = [C.c_void_p, ip, C.c_int]
         L.ov2h_local_ba_get.argtypes = [C.c_void_p, ip, u8, dp, ip, dp, ip, dp, u8, ip, ip, dp]
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
-        L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int]
         L.ov2h_ba_worker_create.restype = C.c_void_p
         L.ov2h_ba_worker_submit_all.argtypes = [C.c_void_p]
         L.ov2h_ba_worker_submit_all.restype = None
@@ -208,10 +208,10 @@ class EstimatorWorker:
     ov2_ba_solve_batch call (at most max_batch).  Python only submits keyframes and reads the counters, so the worker never
     competes for the interpreter lock."""
 
-    def __init__(self, device, problem, nseq, robust_mono_th=5.9915, max_batch=64):
+    def __init__(self, device, problem, nseq, robust_mono_th=5.9915, max_batch=64, high_priority=True):
         self.problem = problem              # keeps the arrays alive during the deep copy
         pc = problem.as_c()
-        self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq, max_batch)
+        self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq, max_batch, int(bool(high_priority)))
         if not self.h:
             raise RuntimeError("ov2h_ba_worker_create failed (no GPU?)")
 
