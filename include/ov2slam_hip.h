@@ -363,6 +363,13 @@ ov2_status ov2_map_set_obs_stereo(ov2_map *m, int n, const int32_t *kfid, const 
                                   const double *runpx);
 ov2_status ov2_map_remove_landmarks(ov2_map *m, int n, const int32_t *lmid);
 ov2_status ov2_map_remove_keyframe(ov2_map *m, int kfid);
+/* Removals leave dead rows in the observation table (the reference erases the entries from its hash maps,
+ * src/map_manager.cpp:885-1019).  ov2_map_local_ba_setup squeezes them out (stable: the order of the live rows, and so
+ * every result, is unchanged) when fewer than half of >= 4096 rows are live, so the table stays within 2x the live
+ * observations over any sequence length; ov2_map_compact does it on request.  kfid / lmid are never reused by the
+ * reference (nkfid_ / nlmid_ only grow), which is what makes a row of a removed keyframe or landmark dead for good. */
+ov2_status ov2_map_compact(ov2_map *m, int *rows_before, int *rows_after);
+ov2_status ov2_map_obs_rows(const ov2_map *m, int *rows, int *capacity, int *compactions);
 
 /* The flat problem of one local BA, in pinned host memory owned by the map (valid until the next set-up call):
  * exactly the arrays ov2_ba_problem wants plus the reference ids behind the indices. */

@@ -75,6 +75,8 @@ SIGNATURES = {
     "ov2_map_set_obs_stereo": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "ov2_map_remove_landmarks": (C.c_int, [vp, C.c_int, vp]),
     "ov2_map_remove_keyframe": (C.c_int, [vp, C.c_int]),
+    "ov2_map_compact": (C.c_int, [vp, ip, ip]),
+    "ov2_map_obs_rows": (C.c_int, [vp, ip, ip, ip]),
     "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ov2_triangulate_pairs": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
                                         vp, vp, vp, vp]),

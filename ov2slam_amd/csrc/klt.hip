@@ -18,6 +18,8 @@
 //   - template (I, Ix, Iy per window pixel) stays in registers for the whole level, two pixels per register;
 //   - bilinear taps as v_dot2_i32_i16 on v_perm_b32-spread pixel pairs.
 // The whole pyramid loop, the gates and the backward pass run inside one launch; no host round trip.
+#include <cstdlib>
+
 #include "ov2_internal.h"
 
 namespace {
@@ -196,10 +198,41 @@ __device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, (ov2_s16x2)(__builtin_bit_cast(ov2_s16x2, a) - __builtin_bit_cast(ov2_s16x2, b)));
 }
 
+typedef unsigned short ov2_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (ov2_u16x2)(__builtin_bit_cast(ov2_u16x2, a) + __builtin_bit_cast(ov2_u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_mul16(unsigned a, unsigned k)   // both halves times k (low 16 bits)
+{
+    return __builtin_bit_cast(unsigned, (ov2_u16x2)(__builtin_bit_cast(ov2_u16x2, a) * (ov2_u16x2)((unsigned short)k)));
+}
+__device__ __forceinline__ unsigned pk_mad16(unsigned a, unsigned k, unsigned c)   // a * k + c per half
+{
+    return __builtin_bit_cast(unsigned, (ov2_u16x2)(__builtin_bit_cast(ov2_u16x2, a) * (ov2_u16x2)((unsigned short)k) + __builtin_bit_cast(ov2_u16x2, c)));
+}
+
+// (acc >> SH) written into the HIGH 16 bits of `keep`, whose low half stays (SDWA destination select): shift and pack of the
+// second value of a 16-bit pair in one instruction
+template <int SH>
+__device__ __forceinline__ unsigned shr_pack_hi(unsigned keep, unsigned acc)
+{
+    asm("v_lshrrev_b32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(keep) : "v"(acc), "n"(SH));
+    return keep;
+}
+template <int SH>
+__device__ __forceinline__ unsigned ashr_pack_hi(unsigned keep, int acc)
+{
+    asm("v_ashrrev_i32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(keep) : "v"(acc), "n"(SH));
+    return keep;
+}
+
 struct level_ptrs {
     const unsigned char *img;
     const int *grad;   // (Ix,Iy) int16 pair per pixel
-    int istride, gstride, w, h;
+    int istride, gstride, w, h, rows;
+    const unsigned char *base;   // the pyramid allocation (wave-uniform) and the planes' byte offsets inside it: the three-lane
+    unsigned img_o, grad_o;      // path addresses memory as uniform base + 32-bit lane offset (one VGPR per address)
 };
 
 __device__ __forceinline__ level_ptrs level_of(const ov2_pyr_view &v, int l, int b)
@@ -208,7 +241,8 @@ __device__ __forceinline__ level_ptrs level_of(const ov2_pyr_view &v, int l, int
     const ov2_level_desc &L = v.lv[l];
     p.img = v.base + L.img_off + L.img_bstride * b;
     p.grad = reinterpret_cast<const int *>(v.base + L.grad_off + L.grad_bstride * b);
-    p.istride = L.istride; p.gstride = L.gstride; p.w = L.w; p.h = L.h;
+    p.istride = L.istride; p.gstride = L.gstride; p.w = L.w; p.h = L.h; p.rows = L.rows;
+    p.base = v.base; p.img_o = (unsigned)(L.img_off + L.img_bstride * b); p.grad_o = (unsigned)(L.grad_off + L.grad_bstride * b);
     return p;
 }
 
@@ -438,30 +472,414 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
     return iters;
 }
 
+// ---- three lanes per keypoint (9 x 9 windows) ---------------------------------------------------------------------
+// The 8-lane mapping above spends most of a level pass on per-keypoint arithmetic that every lane of the group repeats
+// (positions, weights, 2 x 2 solve, convergence tests: ~70 of the ~190 vector instructions of an LK iteration, and
+// more around the template).  Here a keypoint takes THREE lanes, each owning three adjacent columns of the 9 x 9 window,
+// so a wave carries 20 keypoints (five groups per 16-lane DPP row, lane 15 of every row idles) and that overhead is
+// shared by 2.5 x as many keypoints:
+//   - one aligned dword pair + v_alignbyte yields the four pixels (x .. x+3) a lane's three columns touch in a row;
+//   - the template rows (I: 8 B, gradient: 16 B per lane and row) go from global memory straight to registers -- no
+//     LDS for them;
+//   - the SEARCH image is staged once per level pass as a 14-row x 48-byte region around the start position
+//     (margin 2 rows / >= 11 columns): the later iterations of the pass read it from LDS without another trip to
+//     memory, and a window that leaves the region re-stages it (rare);
+//   - sums over the three lanes: two DPP row shifts + two selects.
+// Arithmetic per window pixel is the one of lk_level (same taps, exact integer sums), so results are bit-identical.
+#ifndef KLT3_RROWS
+#define KLT3_RROWS 14
+#endif
+struct klt3 {
+    // rows of 48 bytes = one 16-byte piece per lane: a load instruction touches ONE image row per keypoint.  The vector
+    // memory front end spends ~2 cycles per distinct cache line an instruction touches (+ ~28 per instruction;
+    // scripts/micro/ta_bench.hip), and that rate, not VALU issue or HBM, bounds these kernels.
+    static constexpr int RROWS = KLT3_RROWS, RBYTES = 48;
+    static constexpr int RSZ = RROWS * RBYTES + 16;   // +16: the regions of a wave start in different banks
+    static constexpr int ROW_SPAN = RROWS - 10, ROW_MARGIN = ROW_SPAN / 2;   // the window's first row may sit ROW_SPAN rows into the region
+    static constexpr int COL_LEAD = 12, COL_SPAN = 38;                       // ... and its first column 0 .. 38 bytes
+};
+
+// lane -> (keypoint slot of the wave, lane of the group); GL = 8 / 16: power-of-two groups, GL = 3: see above
+template <int GL>
+struct klt_map {
+    static constexpr int KPW = 64 / GL;
+    static __device__ __forceinline__ int slot(int tid) { return tid / GL; }
+    static __device__ __forceinline__ int sub(int tid) { return tid & (GL - 1); }
+    static __device__ __forceinline__ bool lane_ok(int) { return true; }
+};
+template <>
+struct klt_map<3> {
+    static constexpr int KPW = 20;
+    static __device__ __forceinline__ int slot(int tid) { return (tid >> 4) * 5 + min(((tid & 15) * 11) >> 5, 4); }   // (t * 11) >> 5 == t / 3 for t < 16
+    static __device__ __forceinline__ int sub(int tid) { const int t = tid & 15; return t - 3 * ((t * 11) >> 5); }
+    static __device__ __forceinline__ bool lane_ok(int tid) { return (tid & 15) != 15; }
+};
+
+template <int WIN, int GL>
+struct klt_smem {   // LDS bytes of one wave
+    static constexpr int BYTES = (64 / GL) * (2 * klt_lds<WIN>::WB + klt_lds<WIN>::GB);
+};
+template <int WIN>
+struct klt_smem<WIN, 3> {
+    static constexpr int BYTES = klt_map<3>::KPW * klt3::RSZ;
+};
+
+// sum over the three lanes of a group, result in all three (c = lane of the group)
+__device__ __forceinline__ int sum3_i32(int v, int c)
+{
+    int t = v + dpp_i32<0x111>(v);   // row_shr:1  lane l reads l - 1
+    t += dpp_i32<0x112>(v);          // row_shr:2  complete in lane c == 2
+    const int u1 = dpp_i32<0x101>(t), u2 = dpp_i32<0x102>(t);   // row_shl:1 / 2: lane l reads l + 1 / l + 2
+    return c == 2 ? t : (c == 1 ? u1 : u2);
+}
+__device__ __forceinline__ double sum3_f64(double v, int c)
+{
+    double t = v + dpp_f64k<0x111>(v);
+    t += dpp_f64k<0x112>(v);
+    const double u1 = dpp_f64k<0x101>(t), u2 = dpp_f64k<0x102>(t);
+    return c == 2 ? t : (c == 1 ? u1 : u2);
+}
+
+// (byte k, byte k + 1) of a dword as two zero-extended 16-bit halves
+template <int K>
+__device__ __forceinline__ unsigned spread_pair(unsigned t)
+{
+    return __builtin_amdgcn_perm(0u, t, 0x0c000c00u + (unsigned)K * 0x00010001u + 0x00010000u);
+}
+
+// origin of the staged search region (padded row, byte column) for a window at (inx, iny)
+__device__ __forceinline__ void klt3_region_origin(const level_ptrs &J, int pad, int inx, int iny, int &rr0, int &cc0)
+{
+    rr0 = min(max(iny + pad - klt3::ROW_MARGIN, 0), J.rows - klt3::RROWS);
+    cc0 = min(max((OV2_LM + inx - klt3::COL_LEAD) & ~15, 0), J.istride - klt3::RBYTES);
+}
+
+// the group's three lanes fetch the region row by row: lane c takes bytes 16c .. 16c + 15 of every row
+struct klt3_segs { uint4 v[klt3::RROWS]; };
+__device__ __forceinline__ void klt3_load_region(const level_ptrs &J, int rr0, int cc0, int c, klt3_segs &S)
+{
+    const unsigned o = J.img_o + (unsigned)(rr0 * J.istride + cc0 + 16 * c);
+#pragma unroll
+    for (int t = 0; t < klt3::RROWS; ++t) {
+#ifdef KLT_EXP_NOLOADS
+        S.v[t] = make_uint4(o + t, o ^ 0x5a5a5a5au, o * 3u + t, 0x40302010u);
+#else
+        S.v[t] = ld_b128(J.base + (size_t)(o + (unsigned)(t * J.istride)));
+#endif
+    }
+}
+__device__ __forceinline__ void klt3_store_region(const klt3_segs &S, int c, bool store, unsigned char *lj)
+{
+    if (store) {
+#pragma unroll
+        for (int t = 0; t < klt3::RROWS; ++t) *reinterpret_cast<uint4 *>(lj + t * klt3::RBYTES + 16 * c) = S.v[t];
+    }
+}
+
+// One LKTrackerInvoker pass for the keypoint of this three-lane group; lane c owns window columns 3c .. 3c + 2.
+// `lane_ok` is false for the idle sixteenth lane of a DPP row (it computes along on zeros and never stores).
+template <int WIN>
+__device__ __forceinline__ int lk_level3(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
+                                         bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
+                                         float &err, const klt_params &P, int c, bool lane_ok, unsigned &passes,
+                                         unsigned char *lj)
+{
+    static_assert(WIN == 9, "three lanes x three columns");
+    constexpr int NPX = 3 * WIN, NQ = (NPX + 1) / 2;   // window pixels per lane, flat e = 3 * row + column; pairs of them
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float half = (float)(WIN - 1) * 0.5f;
+    const float lscale = __builtin_ldexpf(1.f, -level);
+    float px = kx * lscale, py = ky * lscale;
+    float nx, ny;
+    if (level == max_level) { nx = nx_io * lscale; ny = ny_io * lscale; }
+    else { nx = nx_io * 2.f; ny = ny_io * 2.f; }
+    if (run) { nx_io = nx; ny_io = ny; }
+
+    px -= half; py -= half;
+    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    if (run && (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h)) {
+        if (level == 0) { status = 0; err = 0.f; }
+        run = false;
+    }
+    if (!__any(run)) return 0;
+    if (run) passes += 1u;
+    int w00, w01, w10, w11;
+    lk_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+
+    unsigned Iv2[NQ], Ix2[NQ], Iy2[NQ];
+    int sA11 = 0, sA12 = 0, sA22 = 0;
+    int rr0, cc0;
+    {
+        // search region around the first iteration's window, fetched together with the template rows
+        const float sx = nx - half, sy = ny - half;
+        const int inx0 = (int)floorf(sx), iny0 = (int)floorf(sy);
+        const bool in0 = run && !(inx0 < -WIN || inx0 >= J.w || iny0 < -WIN || iny0 >= J.h);
+        klt3_region_origin(J, pad, in0 ? inx0 : 0, in0 ? iny0 : 0, rr0, cc0);
+        const int bx0 = (run ? (OV2_LM + ipx) : OV2_LM) + 3 * c, by = run ? (ipy + pad) : pad;
+        // Template rows.  The Scharr derivatives are formed HERE from the image rows (one 12-byte load per lane and row, 12
+        // rows: the window's 10 plus a ring of one) instead of being read from a gradient plane: the int16 (Ix, Iy)
+        // planes are 4 of the 5 bytes per pixel a pyramid holds and their windows made this kernel HBM-bound (and the
+        // pyramid build write-bound).  Same integers as calcSharrDeriv / level_kernel's Scharr part: [3 10 3]' x [-1 0 1]
+        // and its transpose in any order, zero outside the image (the derivative border of buildOpticalFlowPyramid).
+        const int ax = bx0 - 1;   // lane's first byte: window column 3c - 1
+        const unsigned io = I.img_o + (unsigned)(by * I.istride + (ax & ~3));
+        const unsigned shI = (unsigned)ax & 3u;
+        struct row3 { unsigned x, y, z; };
+        row3 irow[WIN + 3];
+        // loaded row p = image row by - 1 + p; only the first / last can leave the plane, and then only under positions the
+        // border mask zeroes: they re-read their neighbour
+#ifdef KLT_EXP_NOLOADS
+#define KLT3_LOAD_ROW(p) (irow[p].x = io + (p), irow[p].y = io * 7u + (p), irow[p].z = io ^ ((p) * 0x01010101u))
+#else
+#define KLT3_LOAD_ROW(p)                                                                                                  \
+    do {                                                                                                                  \
+        const int dr = (p) == 0 ? (by > 0 ? -1 : 0) : ((p) == WIN + 2 ? (by + WIN + 1 < I.rows ? WIN + 1 : WIN) : (p) - 1); \
+        __builtin_memcpy(&irow[p], __builtin_assume_aligned(I.base + (size_t)(io + (unsigned)(dr * I.istride)), 4), 12);   \
+    } while (0)
+#endif
+        // two batches (the first travels with the region, the second sits behind the barrier that publishes the region):
+        // keeps the registers in flight down
+        constexpr int R1 = 6;
+        __syncthreads();   // the previous pass may still read the region
+        klt3_segs S;
+        klt3_load_region(J, rr0, cc0, c, S);
+#pragma unroll
+        for (int p = 0; p < R1; ++p) KLT3_LOAD_ROW(p);
+        klt3_store_region(S, c, lane_ok, lj);
+        __syncthreads();   // region staged
+#pragma unroll
+        for (int p = R1; p < WIN + 3; ++p) KLT3_LOAD_ROW(p);
+#undef KLT3_LOAD_ROW
+
+        const unsigned W01 = pack_lo16((unsigned)w00, (unsigned)w01), W23 = pack_lo16((unsigned)w10, (unsigned)w11);
+        // derivative positions outside the image are zero: masks per column pair and per row (always applied: a
+        // wave-uniform branch around them costs 60 more registers than it saves time); idle lanes / groups get all-zero
+        // masks, so their gradients -- and with them everything they add to the sums below -- vanish
+        const int x0 = ipx + 3 * c;
+        const unsigned wlim = (run && lane_ok) ? (unsigned)I.w : 0u, hlim = (run && lane_ok) ? (unsigned)I.h : 0u;
+        unsigned cm[2];   // columns (0, 1) and (2, 3) of the lane
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            cm[j] = ((unsigned)(x0 + 2 * j) < wlim ? 0xffffu : 0u) | ((unsigned)(x0 + 2 * j + 1) < wlim ? 0xffff0000u : 0u);
+        // per loaded row: pixel pairs P_k = (q_k, q_k+1), k = 0..4, of the lane's six pixels q_0..q_5 (window columns
+        // 3c - 1 .. 3c + 4); horizontal terms for the column pairs (0, 1) and (2, 3): Hd = P_k+2 - P_k, Sm = 3 (P_k + P_k+2)
+        // + 10 P_k+1 with k = 0 / 2 (packed 16-bit); the middle pair (1, 2) of a derivative row is cut out of the two
+        unsigned Pm[2][3] = {};              // P_1..P_3 (the window's own pixel pairs) of the two previous loaded rows
+        unsigned Hd[3][2] = {}, Sm[3][2] = {};   // [age][pair]: ages 0 / 1 / 2 = loaded rows p - 2 / p - 1 / p
+        unsigned GXp[3] = {0, 0, 0}, GYp[3] = {0, 0, 0};   // derivative pairs of the previous window row
+        unsigned piv = 0, pix = 0, piy = 0;
+#pragma unroll
+        for (int p = 0; p < WIN + 3; ++p) {
+            const unsigned e0 = __builtin_amdgcn_alignbyte(irow[p].y, irow[p].x, shI);
+            const unsigned e1 = __builtin_amdgcn_alignbyte(irow[p].z, irow[p].y, shI);
+            unsigned P[5];
+            P[0] = spread_pair<0>(e0); P[1] = spread_pair<1>(e0); P[2] = spread_pair<2>(e0);
+            P[3] = __builtin_amdgcn_perm(e1, e0, 0x0c040c03u);   // (e0 byte 3, e1 byte 0)
+            P[4] = spread_pair<0>(e1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                Hd[0][j] = Hd[1][j]; Hd[1][j] = Hd[2][j]; Sm[0][j] = Sm[1][j]; Sm[1][j] = Sm[2][j];
+                Hd[2][j] = pk_sub16(P[2 * j + 2], P[2 * j]);
+                Sm[2][j] = pk_mad16(P[2 * j + 1], 10u, pk_mul16(pk_add16(P[2 * j], P[2 * j + 2]), 3u));
+            }
+            if (p >= 2) {
+                // derivative pairs of window row r = p - 2 (loaded rows p - 2, p - 1, p)
+                const unsigned rm = (unsigned)(ipy + p - 2) < hlim ? 0xffffffffu : 0u;
+                unsigned GX[3], GY[3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned m = cm[j] & rm;
+                    GX[2 * j] = pk_mad16(Hd[1][j], 10u, pk_mul16(pk_add16(Hd[0][j], Hd[2][j]), 3u)) & m;
+                    GY[2 * j] = pk_sub16(Sm[2][j], Sm[0][j]) & m;
+                }
+                // (column 1, column 2) = (high half of pair 0, low half of pair 2)
+                GX[1] = __builtin_amdgcn_perm(GX[2], GX[0], 0x05040302u); GY[1] = __builtin_amdgcn_perm(GY[2], GY[0], 0x05040302u);
+                if (p >= 3) {
+                    // window pixel row y = p - 3: intensities from loaded rows y + 1, y + 2, derivatives of rows y, y + 1
+                    const int y = p - 3;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int e = 3 * y + i;
+                        const unsigned av = (unsigned)dot2(Pm[1][i], W23, dot2k(Pm[0][i], W01, 1 << (W_BITS - 5 - 1)));
+                        const int ax_ = dot2(GX[i], W23, dot2k(GXp[i], W01, 1 << (W_BITS - 1)));
+                        const int ay_ = dot2(GY[i], W23, dot2k(GYp[i], W01, 1 << (W_BITS - 1)));
+                        if (e & 1) {
+                            Iv2[e >> 1] = shr_pack_hi<W_BITS - 5>(piv, av);
+                            Ix2[e >> 1] = ashr_pack_hi<W_BITS>(pix, ax_);
+                            Iy2[e >> 1] = ashr_pack_hi<W_BITS>(piy, ay_);
+                        } else if (e == NPX - 1) {   // the odd last pixel: its phantom partner has zero gradients
+                            Iv2[e >> 1] = av >> (W_BITS - 5);
+                            Ix2[e >> 1] = (unsigned)(ax_ >> W_BITS) & 0xffffu; Iy2[e >> 1] = (unsigned)(ay_ >> W_BITS) & 0xffffu;
+                        } else {
+                            piv = av >> (W_BITS - 5); pix = (unsigned)(ax_ >> W_BITS); piy = (unsigned)(ay_ >> W_BITS);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { GXp[j] = GX[j]; GYp[j] = GY[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { Pm[0][j] = Pm[1][j]; Pm[1][j] = P[j + 1]; }
+        }
+        // |Ix|, |Iy| <= 4080: 27 products per lane and 81 per group stay below 2^31 -> exact in int32
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            sA11 = dot2(Ix2[q], Ix2[q], sA11); sA12 = dot2(Ix2[q], Iy2[q], sA12); sA22 = dot2(Iy2[q], Iy2[q], sA22);
+        }
+    }
+    const float A11 = (float)(double)sum3_i32(sA11, c) * FLT_SCALE;
+    const float A12 = (float)(double)sum3_i32(sA12, c) * FLT_SCALE;
+    const float A22 = (float)(double)sum3_i32(sA22, c) * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float min_eig = __fdiv_rn(A22 + A11 - __fsqrt_rn((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
+                                    (float)(2 * WIN * WIN));
+#ifndef KLT_EXP_FIXED_ITERS
+    if (run) {
+        err = min_eig;  // OPTFLOW_LK_GET_MIN_EIGENVALS
+        if (min_eig < P.min_eig_thr || D < 1.1920929e-07f /* FLT_EPSILON */) {
+            if (level == 0) status = 0;
+            run = false;
+        }
+    }
+#else
+    err = min_eig * 1e-9f;
+#endif
+    D = __fdiv_rn(1.f, D);
+
+    nx -= half; ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    int iters = 0;
+    for (int j = 0; j < P.max_iter; ++j) {
+        if (!__any(run)) break;
+        const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+        if (run && (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h)) {
+            if (level == 0) status = 0;
+            run = false;
+        }
+        int w00j, w01j, w10j, w11j;
+        lk_weights(nx - (float)inx, ny - (float)iny, w00j, w01j, w10j, w11j);
+        int rb = run ? iny + pad - rr0 : 0, cb = run ? OV2_LM + inx - cc0 : 0;
+        const bool out = (unsigned)rb > (unsigned)klt3::ROW_SPAN || (unsigned)cb > (unsigned)klt3::COL_SPAN;
+        if (__any(out)) {   // the window left the staged region: fetch a new one around it
+            __syncthreads();
+            if (out) {
+                klt3_region_origin(J, pad, inx, iny, rr0, cc0);
+                klt3_segs S;
+                klt3_load_region(J, rr0, cc0, c, S);
+                klt3_store_region(S, c, lane_ok, lj);
+                rb = iny + pad - rr0; cb = OV2_LM + inx - cc0;
+            }
+            __syncthreads();
+        }
+        const unsigned W01 = pack_lo16((unsigned)w00j, (unsigned)w01j), W23 = pack_lo16((unsigned)w10j, (unsigned)w11j);
+        const int cq = cb + 3 * c;
+        const unsigned *q = reinterpret_cast<const unsigned *>(lj + rb * klt3::RBYTES + (cq & ~3));
+        const unsigned sh = (unsigned)cq & 3u;
+        int pb1 = 0, pb2 = 0;
+        unsigned T[3];
+        {
+            const unsigned p4 = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+            T[0] = spread_pair<0>(p4); T[1] = spread_pair<1>(p4); T[2] = spread_pair<2>(p4);
+        }
+        unsigned pj = 0;
+#pragma unroll
+        for (int y = 0; y < WIN; ++y) {
+            const unsigned *qr = q + (klt3::RBYTES / 4) * (y + 1);
+            const unsigned p4 = __builtin_amdgcn_alignbyte(qr[1], qr[0], sh);
+            unsigned B[3];
+            B[0] = spread_pair<0>(p4); B[1] = spread_pair<1>(p4); B[2] = spread_pair<2>(p4);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = 3 * y + i;
+                // taps + rounding >= 1 (w11 >= -1), so the logical shift is the arithmetic one
+                const unsigned aj = (unsigned)dot2(B[i], W23, dot2k(T[i], W01, 1 << (W_BITS - 5 - 1)));
+                if ((e & 1) || e == NPX - 1) {
+                    // |jv - I| <= 8160 fits int16: v_pk_sub_i16 on the pixel pair, then one dot2 per gradient component
+                    const unsigned d2 = pk_sub16((e & 1) ? shr_pack_hi<W_BITS - 5>(pj, aj) : (aj >> (W_BITS - 5)), Iv2[e >> 1]);
+                    pb1 = dot2(d2, Ix2[e >> 1], pb1);
+                    pb2 = dot2(d2, Iy2[e >> 1], pb2);
+                } else {
+                    pj = aj >> (W_BITS - 5);
+                }
+                T[i] = B[i];
+            }
+        }
+        // a lane holds 27 products of <= 3.4e7: fits int32; the group total may not, so sum exactly in f64 unless every
+        // partial of the wave is below 2^27 (then the total fits int32 and v_cvt_f32_i32 rounds it once, like
+        // (float)(double)total)
+        float b1, b2;
+        if (__all((unsigned)(pb1 + (1 << 27)) < (1u << 28) && (unsigned)(pb2 + (1 << 27)) < (1u << 28))) {
+            b1 = (float)sum3_i32(pb1, c) * FLT_SCALE;
+            b2 = (float)sum3_i32(pb2, c) * FLT_SCALE;
+        } else {
+            b1 = (float)sum3_f64((double)pb1, c) * FLT_SCALE;
+            b2 = (float)sum3_f64((double)pb2, c) * FLT_SCALE;
+        }
+        const float dx = (A12 * b2 - A22 * b1) * D;
+        const float dy = (A12 * b1 - A11 * b2) * D;
+        if (run) {
+            ++iters;
+            nx += dx; ny += dy;
+            nx_io = nx + half; ny_io = ny + half;
+#ifdef KLT_EXP_FIXED_ITERS   // timing experiments: every pass runs exactly this many iterations around the start position
+            nx -= dx; ny -= dy;
+            if (j + 1 >= KLT_EXP_FIXED_ITERS) run = false;
+#else
+            if ((double)dx * dx + (double)dy * dy <= P.eps2) run = false;
+            else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                nx_io -= dx * 0.5f; ny_io -= dy * 0.5f;
+                run = false;
+            }
+#endif
+            pdx = dx; pdy = dy;
+        }
+    }
+    return iters;
+}
+
 // FeatureTracker::fbKltTracking for the keypoint of this DPP row (act = row has a keypoint).
 // returns status (0/1); fx,fy = forward result; work = iterations | level passes << 16.
+// `smem` = the wave's LDS block (klt_smem<WIN, GL>::BYTES), `slot` = the keypoint's slot in the wave
+template <int WIN, int GL>
+__device__ __forceinline__ int lk_pass(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level, bool run,
+                                       float kx, float ky, float &nx_io, float &ny_io, int &status, float &err,
+                                       const klt_params &P, int sub, bool lane_ok, unsigned &passes, unsigned char *smem, int slot)
+{
+    if constexpr (GL == 3) {
+        return lk_level3<WIN>(I, J, pad, level, max_level, run, kx, ky, nx_io, ny_io, status, err, P, sub, lane_ok, passes,
+                              smem + slot * klt3::RSZ);
+    } else {
+        constexpr int KPW = 64 / GL, WB = klt_lds<WIN>::WB, GB = klt_lds<WIN>::GB;
+        return lk_level<WIN, GL>(I, J, pad, level, max_level, run, kx, ky, nx_io, ny_io, status, err, P, sub, passes,
+                                 smem + slot * WB, smem + KPW * WB + slot * WB, smem + 2 * KPW * WB + slot * GB);
+    }
+}
+
 template <int WIN, int GL>
 __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx,
                                           float ky, float &fx, float &fy, const klt_params &P, int nlevels, int sub,
-                                          unsigned &work, unsigned char *lwI, unsigned char *lwJ, unsigned char *lg)
+                                          bool lane_ok, unsigned &work, unsigned char *smem, int slot)
 {
     int status = 1;
     float err = 0.f;
     unsigned it = 0, passes = 0;
     for (int l = nlevels; l >= 0; --l) {
         const level_ptrs I = level_of(pv, l, b), J = level_of(cv, l, b);
-        it += lk_level<WIN, GL>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, passes, lwI, lwJ, lg);
+        it += lk_pass<WIN, GL>(I, J, pv.pad, l, nlevels, act, kx, ky, fx, fy, status, err, P, sub, lane_ok, passes, smem, slot);
     }
     // gates of src/feature_tracker.cpp:79-101
     const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
     int ok = act && status && !(err > P.err_th) &&
              (1.f <= fx && fx < (float)W0 - 1.f && 1.f <= fy && fy < (float)H0 - 1.f);
+#ifdef KLT_EXP_FIXED_ITERS
+    ok = act;
+#endif
     // backward pass cur -> prev on level 0 from the original keypoint (src/feature_tracker.cpp:113)
     int st2 = 1;
     float e2 = 0.f, bx = kx, by = ky;
     {
         const level_ptrs I = level_of(cv, 0, b), J = level_of(pv, 0, b);
-        it += lk_level<WIN, GL>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, passes, lwI, lwJ, lg);
+        it += lk_pass<WIN, GL>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, lane_ok, passes, smem, slot);
     }
     if (ok) {
         if (!st2) ok = 0;
@@ -486,7 +904,10 @@ __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_vi
 #ifndef KLT_WAVE_CAP
 #define KLT_WAVE_CAP 4
 #endif
-#define KLT_WAVES(W, G) 1, KLT_WAVE_CAP
+#ifndef KLT3_WAVE_MIN
+#define KLT3_WAVE_MIN 2
+#endif
+#define KLT_WAVES(W, G) ((G) == 3 ? KLT3_WAVE_MIN : 1), KLT_WAVE_CAP
 
 // 64 threads = 64 / GL keypoints.  grid = ceil(n / (64 / GL))
 template <int WIN, int KLT_GL>
@@ -495,19 +916,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                     unsigned char *__restrict__ status,
                                                     const int *__restrict__ img_idx, unsigned *__restrict__ iters)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
-    const int lgrp = (int)(threadIdx.x / KLT_GL);
-    constexpr int KLT_KPW = 64 / KLT_GL;
-    const int sub = threadIdx.x & (KLT_GL - 1), i = blockIdx.x * KLT_KPW + (int)(threadIdx.x / KLT_GL);
-    const bool act = i < n;
-    const int ii = act ? i : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
+    using M = klt_map<KLT_GL>;
+    constexpr int KLT_KPW = M::KPW;
+    const int slot = M::slot((int)threadIdx.x), sub = M::sub((int)threadIdx.x), i = blockIdx.x * KLT_KPW + slot;
+    const bool lane_ok = M::lane_ok((int)threadIdx.x);
+    const bool act = i < n && lane_ok;
+    const int ii = i < n ? i : 0;
     const int b = img_idx ? img_idx[ii] : 0;
     const float2 kp = kps[ii];
     float2 pr = priors[ii];
     unsigned work = 0;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, lane_ok, work, smem, slot);
     if (act && sub == 0) {
         priors[i] = pr;
         status[i] = (unsigned char)ok;
@@ -576,11 +996,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_a,
                                                         const int *__restrict__ list_b, const unsigned *__restrict__ cnt)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
-    const int lgrp = (int)(threadIdx.x / KLT_GL);
-    constexpr int KLT_KPW = 64 / KLT_GL;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
+    using M = klt_map<KLT_GL>;
+    constexpr int KLT_KPW = M::KPW;
     const int total_a = (int)cnt[0], total_b = (int)cnt[1];
     // list B first: its waves run the full pyramid (about twice the work of a list-A wave), so the short list-A waves
     // fill the tail of the launch instead of the long ones forming it
@@ -589,9 +1007,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     const int g = is_a ? (int)blockIdx.x - groups_b : (int)blockIdx.x;
     const int total = is_a ? total_a : total_b;
     if (g * KLT_KPW >= total) return;
-    const int sub = threadIdx.x & (KLT_GL - 1), idx = g * KLT_KPW + (int)(threadIdx.x / KLT_GL);
-    const bool act = idx < total;
-    const int i = (is_a ? list_a : list_b)[act ? idx : total - 1];
+    const int slot = M::slot((int)threadIdx.x), sub = M::sub((int)threadIdx.x), idx = g * KLT_KPW + slot;
+    const bool lane_ok = M::lane_ok((int)threadIdx.x);
+    const bool act = idx < total && lane_ok;
+    const int i = (is_a ? list_a : list_b)[idx < total ? idx : total - 1];
     const float2 kp = kps[i];
     const int b = img_idx ? img_idx[i] : 0;
     // kltTracking: keypoints without a prior start from their own position (vpriors = vkps, :181-183); stereoMatching's
@@ -599,7 +1018,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     float2 pr = (is_a || !P.rule33) ? prior[i] : kp;
     unsigned work = 0;
     const int nl = is_a ? min(1, pv.nlevels - 1) : P.nlevels;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, lane_ok, work, smem, slot);
     if (act && sub == 0) {
         out_xy[i] = pr;   // tracked position, or the failed forward result that seeds the re-tracking (:217-219)
         out_status[i] = (unsigned char)ok;
@@ -621,47 +1040,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_c,
                                                         const unsigned *__restrict__ cnt, int batch)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wi[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_wj[64 / KLT_GL][klt_lds<WIN>::WB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_g[64 / KLT_GL][klt_lds<WIN>::GB];
-    const int lgrp = (int)(threadIdx.x / KLT_GL);
-    constexpr int KLT_KPW = 64 / KLT_GL;
-    const int sub = threadIdx.x & (KLT_GL - 1), grp = (int)(threadIdx.x / KLT_GL);
-    // the 33 % flag is per image and must be raised even when no failure of that image is re-tracked
-    if (p3p_req && P.rule33) {
-        for (int b = blockIdx.x * KLT_KPW + grp; b < batch; b += gridDim.x * KLT_KPW) {
-            int n3 = 0, good = 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
+    using M = klt_map<KLT_GL>;
+    constexpr int KLT_KPW = M::KPW;
+    const int slot = M::slot((int)threadIdx.x), sub = M::sub((int)threadIdx.x);
+    const bool lane_ok = M::lane_ok((int)threadIdx.x);
+    // per-image tally of the first launch: its 64 slots shared out over the lanes of the group
+    auto tally = [&](int b, int &n3, int &good) {
+        n3 = 0; good = 0;
+        if constexpr (KLT_GL == 3) {
+            for (int q = sub; q < 64; q += 3) {
+                const unsigned cw = counts[64 * b + q];
+                n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
+            }
+            n3 = sum3_i32(n3, sub); good = sum3_i32(good, sub);
+        } else {
             for (int q = 0; q < 64 / KLT_GL; ++q) {
                 const unsigned cw = counts[64 * b + sub * (64 / KLT_GL) + q];
                 n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
             }
             n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
-            if (sub == 0 && n3 > 0 && (double)good < 0.33 * (double)n3) p3p_req[b] = 1;
+        }
+    };
+    // the 33 % flag is per image and must be raised even when no failure of that image is re-tracked
+    if (p3p_req && P.rule33) {
+        for (int b0 = blockIdx.x * KLT_KPW; b0 < batch; b0 += gridDim.x * KLT_KPW) {   // wave-uniform trip count (DPP sums inside)
+            const int b = b0 + slot;
+            int n3, good;
+            tally(min(b, batch - 1), n3, good);
+            if (b < batch && lane_ok && sub == 0 && n3 > 0 && (double)good < 0.33 * (double)n3) p3p_req[b] = 1;
         }
     }
     const int total = (int)cnt[2];
     if ((int)blockIdx.x * KLT_KPW >= total) return;
-    const int idx = blockIdx.x * KLT_KPW + grp;
-    const bool act = idx < total;
-    const int i = list_c[act ? idx : total - 1];
+    const int idx = blockIdx.x * KLT_KPW + slot;
+    const bool act = idx < total && lane_ok;
+    const int i = list_c[idx < total ? idx : total - 1];
     const int b = img_idx ? img_idx[i] : 0;
-    // per-image tally of the first launch: 64 slots shared out over the lanes of the group
-    int n3 = 0, good = 0;
-    for (int q = 0; q < 64 / KLT_GL; ++q) {
-        const unsigned cw = counts[64 * b + sub * (64 / KLT_GL) + q];
-        n3 += (int)(cw & 0xffffu); good += (int)(cw >> 16);
-    }
-    n3 = row_sum_i32<KLT_GL>(n3); good = row_sum_i32<KLT_GL>(good);
+    int n3, good;
+    tally(b, n3, good);
     const bool drop = P.rule33 && n3 > 0 && (double)good < 0.33 * (double)n3;  // :228
     const float2 kp = kps[i];
     float2 pr = drop ? kp : out_xy[i];
     unsigned work = 0;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, work, lds_wi[lgrp], lds_wj[lgrp], lds_g[lgrp]);
+    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, P.nlevels, sub, lane_ok, work, smem, slot);
     if (act && sub == 0) {
         out_xy[i] = pr;
         out_status[i] = (unsigned char)ok;
         if (iters) iters[n + i] = work;
     }
+}
+
+// Lanes per keypoint for a call of n keypoints.  9 x 9 windows (the reference's nklt_win_size) have the three-lane
+// mapping (20 keypoints per wave) once the call fills the device with such waves; OV2_KLT_LANES = 3 / 8 / 16 forces one
+// (kernel experiments).
+#define KLT_GL3_MIN_KPS 40960
+int klt_lanes_for(int n, int win)
+{
+    static const int forced = [] { const char *e = getenv("OV2_KLT_LANES"); return e ? atoi(e) : 0; }();
+    if (forced == 8 || forced == 16 || (forced == 3 && win == 9)) return forced;
+    if (win == 9 && n >= KLT_GL3_MIN_KPS) return 3;
+    return n >= KLT_GL8_MIN_KPS ? 8 : 16;
 }
 
 ov2_status make_params(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels, int max_iter,
@@ -707,19 +1146,22 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
 #define KLT_FB_GL(W, G)                                                                                        \
-    OV2_LAUNCH(c, OV2_K_KLT_FB, (klt_fb_kernel<W, G>), dim3((n + 64 / G - 1) / (64 / G)), dim3(64), 0, c->stream,    \
+    OV2_LAUNCH(c, OV2_K_KLT_FB, (klt_fb_kernel<W, G>), dim3((n + klt_map<G>::KPW - 1) / klt_map<G>::KPW), dim3(64), 0, c->stream,    \
                prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),                 \
                reinterpret_cast<float2 *>(d_priors), d_status, d_img_idx, d_iters)
 #define KLT_FB(W)                                                                                              \
     do {                                                                                                       \
-        if (n >= KLT_GL8_MIN_KPS) KLT_FB_GL(W, 8);                                                             \
+        if (klt_lanes_for(n, W) == 8) KLT_FB_GL(W, 8);                                                         \
         else KLT_FB_GL(W, 16);                                                                                 \
     } while (0)
     switch (win) {
     case 3: KLT_FB(3); break;
     case 5: KLT_FB(5); break;
     case 7: KLT_FB(7); break;
-    case 9: KLT_FB(9); break;
+    case 9:
+        if (klt_lanes_for(n, 9) == 3) KLT_FB_GL(9, 3);
+        else KLT_FB(9);
+        break;
     default: KLT_FB(11); break;
     }
 #undef KLT_FB
@@ -790,7 +1232,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     const dim3 cgrid((n + 255) / 256);
 #define KLT_STAGES_GL(W, G)                                                                                     \
     do {                                                                                                        \
-        const dim3 tgrid((n + 64 / G - 1) / (64 / G) + 1);   /* groups of list A + groups of list B <= n/KPW + 2 */ \
+        const dim3 tgrid((n + klt_map<G>::KPW - 1) / klt_map<G>::KPW + 1);   /* groups of list A + groups of list B <= n/KPW + 2 */ \
         OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 1, d_has_prior,  \
                    d_out_status, d_iters, list_a, list_b, live_cnt, d_p3p_req, B);                              \
         OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), dim3(tgrid.x + 1), dim3(64), 0, c->stream,   \
@@ -806,14 +1248,17 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     } while (0)
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \
-        if (n >= KLT_GL8_MIN_KPS) KLT_STAGES_GL(W, 8);                                                          \
+        if (klt_lanes_for(n, W) == 8) KLT_STAGES_GL(W, 8);                                                      \
         else KLT_STAGES_GL(W, 16);                                                                              \
     } while (0)
     switch (win) {
     case 3: KLT_STAGES(3); break;
     case 5: KLT_STAGES(5); break;
     case 7: KLT_STAGES(7); break;
-    case 9: KLT_STAGES(9); break;
+    case 9:
+        if (klt_lanes_for(n, 9) == 3) KLT_STAGES_GL(9, 3);
+        else KLT_STAGES(9);
+        break;
     default: KLT_STAGES(11); break;
     }
 #undef KLT_STAGES

@@ -19,6 +19,7 @@
 struct ov2_map {
     ov2_ctx *c;
     int max_kf, max_lm, max_obs, n_obs;
+    int n_compactions;                                              // times the observation table was squeezed
     // tables
     double *kf_pose; unsigned char *kf_state;                       // [max_kf]
     double *lm_xyz; unsigned char *lm_state;                        // [max_lm]
@@ -40,9 +41,10 @@ struct ov2_map {
 
 namespace {
 
-enum { MH_NBKPS = 0, MH_NB3D, MH_ABORT, MH_NMAXKF, MH_NPOSE, MH_NRES, MH_NLM, MH_NBAD, MH_N = 16 };   // NLM|NBAD: one 64-bit scan total
+enum { MH_NBKPS = 0, MH_NB3D, MH_ABORT, MH_NMAXKF, MH_NPOSE, MH_NRES, MH_NLM, MH_NBAD, MH_NLIVE, MH_N = 16 };   // NLM|NBAD: one 64-bit scan total
 #define ANCH_TOP 0x40000000   // anchor keyframe stored as ANCH_TOP - kfid under atomicMax: 0 = none, so the array lives in the zeroed block
 enum { OBS_ALIVE = 1, OBS_STEREO = 2 };
+enum { MAP_COMPACT_MIN_ROWS = 4096 };   // below this the scans cost nothing worth a reallocation
 
 struct map_view {
     int max_kf, max_lm, n_obs;
@@ -116,14 +118,43 @@ __global__ __launch_bounds__(256) void ms_count_kernel(map_view M, int newkf, in
                                                        unsigned char *__restrict__ lm_new, int *__restrict__ hdr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int kf, lm;
-    if (i >= M.n_obs || !obs_live(M, i, kf, lm)) return;
+    int kf = 0, lm = 0;
+    const bool live = i < M.n_obs && obs_live(M, i, kf, lm);
+    // live rows of the table (one atomic per wave): the host compacts the table when most rows are dead
+    const unsigned long long bal = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&hdr[MH_NLIVE], __popcll(bal));
+    if (!live) return;
     atomicAdd(&lm_nobs[lm], 1);
     if (kf == newkf) {
         lm_new[lm] = 1;
         atomicAdd(&hdr[MH_NBKPS], 1);
         if (M.lm_state[lm] & OV2_LM_KP3D) atomicAdd(&hdr[MH_NB3D], 1);
     }
+}
+
+// ---- compaction of the observation table ------------------------------------------------------------
+// Observations are appended and killed in place (tombstones), so a long sequence leaves mostly dead rows behind
+// (the reference erases them from its hash maps: src/map_manager.cpp:885-1019).  Dead rows (flag cleared, or keyframe /
+// landmark gone -- neither id is ever reused) are squeezed out by a stable scatter: the row order, and so every set-up
+// result, stays what it was.
+__global__ __launch_bounds__(256) void mc_mark_kernel(map_view M, int *__restrict__ keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M.n_obs) return;
+    int kf, lm;
+    keep[i] = obs_live(M, i, kf, lm) ? 1 : 0;
+}
+
+struct obs_cols { int *kf, *lm, *scale; double *uv, *ruv; unsigned char *flag; };
+
+__global__ __launch_bounds__(256) void mc_scatter_kernel(map_view M, const int *__restrict__ keep, const int *__restrict__ pos, obs_cols O)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M.n_obs || !keep[i]) return;
+    const int j = pos[i];
+    O.kf[j] = M.obs_kf[i]; O.lm[j] = M.obs_lm[i]; O.scale[j] = M.obs_scale[i]; O.flag[j] = M.obs_flag[i];
+    reinterpret_cast<double2 *>(O.uv)[j] = reinterpret_cast<const double2 *>(M.obs_uv)[i];
+    reinterpret_cast<double2 *>(O.ruv)[j] = reinterpret_cast<const double2 *>(M.obs_ruv)[i];
 }
 
 // MapManager::updateFrameCovisibility (src/map_manager.cpp:117-193): co-observed landmarks per other keyframe
@@ -532,6 +563,62 @@ static ov2_status ensure_capacity(ov2_map *m, int need_kf, int need_lm, int need
     return OV2_OK;
 }
 
+// squeezes the dead rows out of the observation table (stable); one synchronisation, fresh column arrays of the same capacity
+static ov2_status compact_obs(ov2_map *m)
+{
+    ov2_ctx *c = m->c;
+    hipStream_t st = c->stream;
+    const int N = m->n_obs;
+    if (N <= 0) return OV2_OK;
+    obs_cols O = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t cap = (size_t)m->max_obs;
+    ov2_status s = OV2_OK;
+#define A(p, n) if (s == OV2_OK) s = dmalloc(c, &O.p, (n))
+    A(kf, cap); A(lm, cap); A(scale, cap); A(uv, 2 * cap); A(ruv, 2 * cap); A(flag, cap);
+#undef A
+    void *fresh[] = {O.kf, O.lm, O.scale, O.uv, O.ruv, O.flag};
+    if (s != OV2_OK) {
+        for (void *p : fresh) if (p) (void)hipFree(p);
+        return s;
+    }
+    const map_view M = view_of(m);
+    const dim3 g((N + 255) / 256), b(256);
+    OV2_HIP(c, hipMemsetAsync(O.flag, 0, cap, st));
+    OV2_LAUNCH(c, OV2_K_MAP, mc_mark_kernel, g, b, 0, st, M, m->obs_cnt);
+    if ((s = exclusive_scan<int>(m, m->obs_cnt, N, m->obs_off, m->hdr + MH_NLIVE)) != OV2_OK) {
+        for (void *p : fresh) (void)hipFree(p);
+        return s;
+    }
+    OV2_LAUNCH(c, OV2_K_MAP, mc_scatter_kernel, g, b, 0, st, M, (const int *)m->obs_cnt, (const int *)m->obs_off, O);
+    OV2_HIP(c, hipMemcpyAsync(m->hdr_host, m->hdr, MH_N * sizeof(int), hipMemcpyDeviceToHost, st));
+    OV2_HIP(c, hipStreamSynchronize(st));
+    void *old[] = {m->obs_kf, m->obs_lm, m->obs_scale, m->obs_uv, m->obs_ruv, m->obs_flag};
+    for (void *p : old) (void)hipFree(p);
+    m->obs_kf = O.kf; m->obs_lm = O.lm; m->obs_scale = O.scale; m->obs_uv = O.uv; m->obs_ruv = O.ruv; m->obs_flag = O.flag;
+    m->n_obs = m->hdr_host[MH_NLIVE];
+    m->n_compactions++;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_map_compact(ov2_map *m, int *rows_before, int *rows_after)
+{
+    if (!m || !m->c) return OV2_ERR_INVALID;
+    OV2_HIP(m->c, hipSetDevice(m->c->device));
+    if (rows_before) *rows_before = m->n_obs;
+    const ov2_status s = compact_obs(m);
+    if (rows_after) *rows_after = m->n_obs;
+    return s;
+}
+
+extern "C" ov2_status ov2_map_obs_rows(const ov2_map *m, int *rows, int *capacity, int *compactions)
+{
+    if (!m) return OV2_ERR_INVALID;
+    if (rows) *rows = m->n_obs;
+    if (capacity) *capacity = m->max_obs;
+    if (compactions) *compactions = m->n_compactions;
+    return OV2_OK;
+}
+
 extern "C" ov2_status ov2_map_create(ov2_ctx *c, int max_kf, int max_lm, int max_obs, ov2_map **out)
 {
     if (!c || !out || max_kf <= 0 || max_lm <= 0 || max_obs <= 0) return OV2_ERR_INVALID;
@@ -783,7 +870,9 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     OV2_HIP(c, hipStreamSynchronize(st));
     const int *H = m->hdr_host;
     out->aborted = H[MH_ABORT];
-    if (out->aborted) return OV2_OK;
+    // mostly tombstones left: squeeze the table once this set-up has read it (amortised like a growth)
+    const bool squeeze = N >= MAP_COMPACT_MIN_ROWS && 2 * (long long)H[MH_NLIVE] < N;
+    if (out->aborted) return squeeze ? compact_obs(m) : OV2_OK;
     const size_t P = H[MH_NPOSE], NL = H[MH_NLM], R = H[MH_NRES], NB = H[MH_NBAD];
     const int e = inv ? 1 : 3;
     // carve the flat problem (same layout on the device and in the pinned mirror)
@@ -821,5 +910,5 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     out->res_type = at(Hh, o_rt); out->res_pose = (const int32_t *)at(Hh, o_rp); out->res_lm = (const int32_t *)at(Hh, o_rl);
     out->res_uv = (const double *)at(Hh, o_ru); out->res_sigma = (const double *)at(Hh, o_rs);
     out->bad_lmid = (const int32_t *)at(Hh, o_bl);
-    return OV2_OK;
+    return squeeze ? compact_obs(m) : OV2_OK;
 }

@@ -319,20 +319,30 @@ void MapManager::updateMapPoint(int lmid, const Vec3 &wpt, double kfanch_invdept
 
 void MapManager::removeMapPointObs(int lmid, int kfid)
 {
+    // src/map_manager.cpp:970-1003
     auto pkf = getKeyframe(kfid);
     if (pkf) pkf->removeKeypointById(lmid);
-    auto plm = getMapPoint(lmid);
-    if (plm) plm->removeKfObs(kfid);
     if (dev_) { dev_rm_kf_.push_back(kfid); dev_rm_lm_.push_back(lmid); }
+    auto plm = getMapPoint(lmid);
+    if (!plm) return;
+    plm->removeKfObs(kfid);
+    if (pkf)
+        for (int cokfid : plm->getKfObsSet()) {
+            auto pcokf = getKeyframe(cokfid);
+            if (pcokf) { pkf->decreaseCovisibleKf(cokfid); pcokf->decreaseCovisibleKf(kfid); }
+        }
 }
 
 void MapManager::removeMapPoint(int lmid)
 {
     auto plm = getMapPoint(lmid);
     if (!plm) return;
-    for (int kfid : plm->getKfObsSet()) {
+    for (int kfid : plm->getKfObsSet()) {   // src/map_manager.cpp:930-944
         auto pkf = getKeyframe(kfid);
-        if (pkf) pkf->removeKeypointById(lmid);
+        if (!pkf) continue;
+        pkf->removeKeypointById(lmid);
+        for (int cokfid : plm->getKfObsSet())
+            if (cokfid != kfid) pkf->decreaseCovisibleKf(cokfid);
     }
     if (plm->isobs_ && pcurframe_) pcurframe_->removeKeypointById(lmid);
     map_plms_.erase(lmid);

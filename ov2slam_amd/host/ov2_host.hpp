@@ -95,6 +95,12 @@ public:
     Keypoint getKeypointById(int lmid) const;   // returns Keypoint with lmid_ = -1 if absent (src/frame.cpp)
     std::map<int, int> getCovisibleKfMap() const { return map_covkfs_; }
     void removeCovisibleKf(int kfid) { map_covkfs_.erase(kfid); }
+    void decreaseCovisibleKf(int kfid)   // src/frame.cpp:689-705
+    {
+        if (kfid == kfid_) return;
+        auto it = map_covkfs_.find(kfid);
+        if (it != map_covkfs_.end() && it->second != 0 && --it->second == 0) map_covkfs_.erase(it);
+    }
     void addKeypoint(const Keypoint &kp);
     void updateKeypoint(int lmid, const Point2f &pt);   // src/frame.cpp: px_ / unpx_ update (pinhole: unpx = px)
     void removeKeypointById(int lmid);

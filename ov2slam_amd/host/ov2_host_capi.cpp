@@ -217,6 +217,14 @@ int ov2h_map_attach_device(void *p, void *ctx, int max_kf, int max_lm, int max_o
     return (int)m->map->attachDevice((ov2_ctx *)ctx, max_kf, max_lm, max_obs);
 }
 
+// rows / capacity / compactions of the device mirror's observation table (ov2_map_obs_rows)
+int ov2h_map_device_rows(void *p, int *rows, int *capacity, int *compactions)
+{
+    HostMap *m = (HostMap *)p;
+    if (!m->map->dev_) return -1;
+    return (int)ov2_map_obs_rows(m->map->dev_, rows, capacity, compactions);
+}
+
 int ov2h_local_ba_setup_dev(void *p, int newkf, int *n_pose, int *n_lm, int *n_res)
 {
     HostMap *m = (HostMap *)p;

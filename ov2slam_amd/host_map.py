@@ -27,6 +27,7 @@ def lib():
         L.ov2h_local_ba_setup.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_map_attach_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ov2h_local_ba_setup_dev.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.ov2h_map_device_rows.argtypes = [C.c_void_p, ip, ip, ip]
         L.ov2h_map_remove_obs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ov2h_map_remove_landmark.argtypes = [C.c_void_p, C.c_int]
         L.ov2h_map_set_isobs.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -129,6 +130,12 @@ class HostMap:
                                           max_obs or n_obs + 64)
         if rc != 0:
             raise RuntimeError(f"attachDevice failed (status {rc})")
+
+    def device_rows(self):
+        """(rows, capacity, compactions) of the device mirror's observation table"""
+        r, c, n = C.c_int(), C.c_int(), C.c_int()
+        assert lib().ov2h_map_device_rows(self.h, C.byref(r), C.byref(c), C.byref(n)) == 0
+        return r.value, c.value, n.value
 
     def remove_obs(self, kfid, lmid):
         lib().ov2h_map_remove_obs(self.h, int(kfid), int(lmid))

@@ -155,3 +155,29 @@ def test_tables_grow_from_tiny_capacities(ctx, inv_depth):
     hm.attach_device(ctx, max_kf=2, max_lm=3, max_obs=5)     # everything has to grow, several times
     a = assert_same(hm)
     assert len(a["res_type"]) > 5000
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_observation_table_is_squeezed_when_mostly_dead(ctx, inv_depth):
+    """removals leave tombstones; once fewer than half of the rows are live the set-up squeezes the table (stable), and
+    every later set-up still equals the hash-map walk; further removals and an explicit ov2_map_compact likewise"""
+    P = synth_ba.make_window(40, 6000, inv_depth=inv_depth, seed=91, max_obs=7)
+    hm = host_map.HostMap(P)
+    hm.attach_device(ctx)
+    rows0, cap0, n0 = hm.device_rows()
+    assert rows0 > 4096 and n0 == 0
+    rng = np.random.default_rng(5)
+    for l in rng.permutation(len(P.lm))[:int(0.7 * len(P.lm))]:
+        hm.remove_landmark(int(l))
+    assert_same(hm)                              # reads the table with its tombstones, then squeezes it
+    rows1, cap1, n1 = hm.device_rows()
+    assert n1 == 1 and rows1 < 0.5 * rows0 and cap1 == cap0
+    assert_same(hm)                              # the squeezed table gives the same problem
+    assert hm.device_rows() == (rows1, cap1, 1)  # nothing dead any more: no second squeeze
+    # single observations go too; the next squeeze happens only when half of the rows are dead again
+    a = hm.setup_local_ba(dev=False)
+    pairs = sorted({(int(k), int(l)) for k, l in zip(a["res_kfid"], a["res_lmid"])})
+    for k, l in pairs[::3]:
+        hm.remove_obs(k, l)
+    assert_same(hm)
+    assert hm.device_rows()[2] == 1
