@@ -95,11 +95,13 @@ VALU_PEAK_TOPS = 78.6   # MI355X vector peak in lane-instructions/s: 157.3 TFLOP
 
 
 def pyr_level_bytes(w, h, nlevels):
-    """per level_kernel launch: read level l (u8), write Scharr (4 B/px) + level l+1 (u8)."""
+    """per level_kernel launch of a build: read level l (u8), write level l+1 (u8).  The Scharr planes (4 B/px) are no
+    longer part of a build: the 9x9 tracking kernels derive them from the image windows, and the planes are only written
+    when a consumer asks for them (ov2_pyr_need_grad)."""
     out, cw, ch = [], w, h
-    for l in range(nlevels):
+    for l in range(nlevels - 1):
         nw, nh = (cw + 1) // 2, (ch + 1) // 2
-        out.append(cw * ch * 5 + (nw * nh if l + 1 < nlevels else 0))
+        out.append(cw * ch + nw * nh)
         cw, ch = nw, nh
     return out
 

@@ -48,6 +48,7 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->scratch_bytes = 0;
     c->tmp_img = nullptr;
     c->ktime_on = false;
+    c->klt_lanes = 0;
     c->ba_arena = nullptr;
     c->ba_arena_cap = 0;
     c->ba_host = nullptr;

@@ -45,6 +45,10 @@ struct ov2_pyr_buf {  // pooled allocation; geometry key = (w,h,pad,max_level,ba
     bool has_free_ev;
     hipEvent_t free_ev2; // recorded on ANOTHER context's main stream by ov2_pyr_release_from (the mapper's readers); the next build waits on it too
     bool has_free_ev2;
+    // the int16 (Ix, Iy) planes are written on demand (ov2_pyr_need_grad): the 9 x 9 tracking path derives the Scharr
+    // values inside its kernel and never reads them.  Both fields are guarded by the owning ctx's mutex.
+    bool grad_built;
+    hipEvent_t grad_ev;  // recorded behind the kernels that wrote the gradient planes
     ov2_pyr_view view;
 };
 
@@ -83,6 +87,7 @@ struct ov2_ctx {
     size_t ba_arena2_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
     size_t ba_host_cap;
+    int klt_lanes;                       // ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = forced lanes per keypoint
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
     bool ktime_on;
     std::vector<ov2_ktime_rec> ktime_recs;   // recorded (kernel id, event pair) since the last report
@@ -123,6 +128,8 @@ void ov2_ktime_begin(ov2_ctx *c, int id, hipStream_t st);
 void ov2_ktime_end(ov2_ctx *c, hipStream_t st);
 // make the ctx main stream wait for the build of `p` (enqueued on the pyramid stream)
 ov2_status ov2_pyr_wait_ready(ov2_ctx *c, const ov2_pyr *p);
+// ... and, for consumers of the gradient planes, for those planes as well (writes them on c's main stream if no one has yet)
+ov2_status ov2_pyr_need_grad(ov2_ctx *c, const ov2_pyr *p);
 // klt.hip: two-stage forward-backward tracking (see ov2_klt_tracking_frame_dev); rule33 = 0 for stereo matching
 ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int win, int nlevels_full, int max_iter,
                                  float eps, float err_th, float fb_th, int n, const float *d_kps, const float *d_prior,

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void level0_clahe_tiled_kernel(const unsigned 
 #define LDS_ROWS (TILE_H + 4)  // rows y0-2 .. y0+TILE_H+1
 #define LDS_DW 18              // dwords per row: cols x0-4 .. x0+67
 
-__global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int has_next)
+__global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int has_next, int do_scharr)
 {
     __shared__ unsigned int tile[LDS_ROWS][LDS_DW];
     const int tid = threadIdx.x;
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int 
     __syncthreads();
 
     // ---- Scharr: 4 px per thread ------------------------------------------------------------------
+    if (do_scharr)
     for (int rr = 0; rr < TILE_H / 16; ++rr) {
         const int tx = tid & 15, ty = (tid >> 4) + 16 * rr;
         const int x = x0 + 4 * tx, y = y0 + ty;
@@ -500,6 +501,7 @@ ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int bat
         return ov2_set_err(c, OV2_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (hipEventCreateWithFlags(&b->ready_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->grad_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->free_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->free_ev2, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(b->base);
@@ -508,6 +510,7 @@ ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int bat
     }
     b->has_free_ev = false;
     b->has_free_ev2 = false;
+    b->grad_built = false;
     v.base = b->base;
     *out = b;
     return OV2_OK;
@@ -584,10 +587,12 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
     else
     OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, sp, im->base, im->w,
                        im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
-    for (int l = 0; l < v.nlevels; ++l) {
+    // pyrDown chain only: the gradient planes are written when a consumer asks for them (ov2_pyr_need_grad)
+    { std::lock_guard<std::mutex> g(c->mu); buf->grad_built = false; }
+    for (int l = 0; l + 1 < v.nlevels; ++l) {
         const ov2_level_desc &L = v.lv[l];
         OV2_LAUNCH_ON(c, OV2_K_LEVEL, sp, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
-                           0, sp, v, l, (l + 1 < v.nlevels) ? 1 : 0);
+                           0, sp, v, l, 1, 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -679,6 +684,10 @@ extern "C" ov2_status ov2_pyr_download_level(ov2_ctx *c, const ov2_pyr *p, int b
     const ov2_level_desc &L = v.lv[level];
     const int pw = L.w + 2 * v.pad, ph = L.h + 2 * v.pad;
     const int x_off = OV2_LM - v.pad;
+    if (grad) {
+        const ov2_status gs = ov2_pyr_need_grad(c, p);
+        if (gs != OV2_OK) return gs;
+    }
     OV2_HIP(c, hipStreamSynchronize(c->stream_pyr));
     OV2_HIP(c, hipStreamSynchronize(c->stream));
     if (img)
@@ -687,6 +696,30 @@ extern "C" ov2_status ov2_pyr_download_level(ov2_ctx *c, const ov2_pyr *p, int b
     if (grad)
         OV2_HIP(c, hipMemcpy2D(grad, (size_t)pw * 4, v.base + L.grad_off + L.grad_bstride * b + (size_t)x_off * 4,
                                (size_t)L.gstride * 4, (size_t)pw * 4, ph, hipMemcpyDeviceToHost));
+    return OV2_OK;
+}
+
+// Scharr planes of every level, written once per pyramid by the first consumer that needs them (the 8 / 16-lane KLT
+// kernels, ov2_pyr_download_level) on ITS main stream, behind the build; later consumers wait for that point.
+ov2_status ov2_pyr_need_grad(ov2_ctx *c, const ov2_pyr *p)
+{
+    if (!c || !p) return OV2_ERR_INVALID;
+    ov2_pyr_buf *buf = p->buf;
+    std::lock_guard<std::mutex> g(p->ctx->mu);
+    if (buf->grad_built) {
+        OV2_HIP(c, hipStreamWaitEvent(c->stream, buf->grad_ev, 0));
+        return OV2_OK;
+    }
+    OV2_HIP(c, hipStreamWaitEvent(c->stream, buf->ready_ev, 0));
+    const ov2_pyr_view &v = buf->view;
+    for (int l = 0; l < v.nlevels; ++l) {
+        const ov2_level_desc &L = v.lv[l];
+        OV2_LAUNCH(c, OV2_K_LEVEL, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, buf->batch), dim3(256), 0,
+                   c->stream, v, l, 0, 1);
+    }
+    OV2_HIP(c, hipGetLastError());
+    OV2_HIP(c, hipEventRecord(buf->grad_ev, c->stream));
+    buf->grad_built = true;
     return OV2_OK;
 }
 

@@ -40,6 +40,10 @@ class Context:
     def __del__(self):
         self.close()
 
+    def set_klt_lanes(self, lanes):
+        """ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = lanes per keypoint in the tracking kernels"""
+        _check(self.h, self.lib.ov2_klt_set_lanes(self.h, int(lanes)))
+
     def synchronize(self):
         _check(self.h, self.lib.ov2_ctx_synchronize(self.h))
 

@@ -293,3 +293,60 @@ def test_klt_large_call_eight_lane_path(ctx, oracle, stream, win):
         assert p3p == ep3p
         assert np.array_equal(st, est.astype(bool))
         assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+
+
+@pytest.mark.parametrize("lanes", [3, 8, 16])
+def test_klt_every_lane_mapping_matches_the_oracle(ctx, oracle, stream, lanes):
+    """ov2_klt_set_lanes forces one wave mapping (3 lanes per keypoint = the 9x9 path that derives the Scharr values in
+    the kernel and stages the search region once per level pass; 8 / 16 = the gradient-plane kernels): each is bit-equal
+    to the oracle on (a) large flow on few levels (the window leaves the staged region: re-staging), (b) windows over every
+    border / flat regions / priors far outside, (c) the two-stage batching, (d) the batched frame call with image indices."""
+    ctx.set_klt_lanes(lanes)
+    try:
+        trk = fe.FeatureTracker(ctx, 30, 0.01)
+        # (a) flow of several pixels with 1 and 2 levels only
+        g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, 12)
+        kps = synth.grid_keypoints(1500)
+        moved = 0
+        for nl in (0, 1, 3):
+            out, st = trk.fbKltTracking(g0, g1, 9, nl, 30.0, 0.5, kps, kps)
+            eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, kps, 9, nl, 30.0, 0.5, 30, 0.01)
+            assert np.array_equal(st, est.astype(bool)), nl
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), nl
+            moved = max(moved, float(np.abs(out - kps)[:, 1].max()))
+        assert moved > 3.0   # windows did travel more rows than the region's margin
+        # (b) borders, flat block, wild priors
+        I0, I1 = stream.left(0).copy(), stream.left(4).copy()
+        I0[100:200, 100:300] = 128
+        I1[100:200, 100:300] = 128
+        h0, h1 = fe.preprocess_image(ctx, I0, use_clahe=False), fe.preprocess_image(ctx, I1, use_clahe=False)
+        p0, p1 = oracle.Pyramid(I0), oracle.Pyramid(I1)
+        rng = np.random.default_rng(lanes)
+        edge = np.array([[0, 0], [751, 479], [0.4, 479.6], [-3.0, 10.0], [760.0, 100.0], [150.0, 150.0], [200.0, 150.0], [1.0, 1.0],
+                         [750.0, 478.0], [375.5, 239.5], [5.2, 300.7], [746.9, 5.1], [3.9, 3.9], [747.2, 475.1]], np.float32)
+        ring = np.concatenate([np.stack([rng.uniform(-2, 12, 40), rng.uniform(-2, 481, 40)], 1),
+                               np.stack([rng.uniform(740, 754, 40), rng.uniform(-2, 481, 40)], 1),
+                               np.stack([rng.uniform(-2, 753, 40), rng.uniform(-2, 12, 40)], 1),
+                               np.stack([rng.uniform(-2, 753, 40), rng.uniform(468, 482, 40)], 1)]).astype(np.float32)
+        kps = np.concatenate([edge, ring])
+        pri = kps + rng.normal(0, 1.5, kps.shape).astype(np.float32)
+        pri[9] = [900.0, -50.0]
+        pri[10] = [-8.0, 300.0]
+        for nl in (0, 3):
+            out, st = trk.fbKltTracking(h0, h1, 9, nl, 30.0, 0.5, kps, pri)
+            eout, est, _ = oracle.fb_klt_tracking(p0, p1, kps, pri, 9, nl, 30.0, 0.5, 30, 0.01)
+            assert np.array_equal(st, est.astype(bool)), nl
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), nl
+        # (c) two-stage batching incl. the 33 % rule
+        g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, 10)
+        kps = synth.grid_keypoints(2000)
+        gt = stream.flow(0, 10, kps)
+        for sigma, expect_p3p in ((1.0, False), (25.0, True)):
+            pri, has = synth.make_priors(kps, gt, sigma=sigma)
+            out, st, p3p = trk.kltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, pri, has)
+            eout, est, ep3p = oracle.klt_tracking_frame(o0, o1, kps, pri, has)
+            assert p3p == ep3p == expect_p3p
+            assert np.array_equal(st, est.astype(bool))
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+    finally:
+        ctx.set_klt_lanes(0)
