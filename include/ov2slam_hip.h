@@ -132,7 +132,7 @@ ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const o
                                       int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* 2n work words: [0,n) stage 1, [n,2n) stage 2; may be NULL */);
 
 /* Tuning / test knob: lanes of a wavefront that share one keypoint in the tracking kernels.  0 (default) picks by call
- * size: 9 x 9 windows (nklt_win_size of every parameter file of the reference) take THREE lanes per keypoint from 40 960
+ * size: 9 x 9 windows (nklt_win_size of every parameter file of the reference) take THREE lanes per keypoint from 32 768
  * keypoints per call on (20 keypoints per wave, Scharr derivatives formed in the kernel, no gradient planes read);
  * otherwise 8 lanes from 65 536 keypoints on, 16 below.  All mappings give bit-identical results. */
 ov2_status ov2_klt_set_lanes(ov2_ctx *ctx, int lanes);

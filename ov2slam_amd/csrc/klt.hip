@@ -489,14 +489,19 @@ __device__ __forceinline__ int lk_level(const level_ptrs &I, const level_ptrs &J
 #ifndef KLT3_RROWS
 #define KLT3_RROWS 14
 #endif
+#ifndef KLT3_RBYTES
+#define KLT3_RBYTES 48
+#endif
 struct klt3 {
-    // rows of 48 bytes = one 16-byte piece per lane: a load instruction touches ONE image row per keypoint.  The vector
-    // memory front end spends ~2 cycles per distinct cache line an instruction touches (+ ~28 per instruction;
-    // scripts/micro/ta_bench.hip), and that rate, not VALU issue or HBM, bounds these kernels.
-    static constexpr int RROWS = KLT3_RROWS, RBYTES = 48;
+    // Region rows are 48 bytes (one 16-byte piece per lane: a load instruction touches ONE image row per keypoint; the
+    // vector memory front end spends ~2 cycles per distinct cache line of an instruction, scripts/micro/ta_bench.hip) or
+    // 32 bytes (pieces dealt out 3 per instruction over the 2 x RROWS pieces: smaller LDS block and fewer registers in flight).
+    static constexpr int RROWS = KLT3_RROWS, RBYTES = KLT3_RBYTES;
     static constexpr int RSZ = RROWS * RBYTES + 16;   // +16: the regions of a wave start in different banks
+    static constexpr int NLD = RBYTES == 48 ? RROWS : (2 * RROWS + 2) / 3;   // 16-byte loads per lane
     static constexpr int ROW_SPAN = RROWS - 10, ROW_MARGIN = ROW_SPAN / 2;   // the window's first row may sit ROW_SPAN rows into the region
-    static constexpr int COL_LEAD = 12, COL_SPAN = 38;                       // ... and its first column 0 .. 38 bytes
+    static constexpr int COL_ALIGN = RBYTES == 48 ? 16 : 4;
+    static constexpr int COL_LEAD = RBYTES == 48 ? 12 : 9, COL_SPAN = RBYTES == 48 ? 38 : 20;   // ... and its first column 0 .. COL_SPAN bytes
 };
 
 // lane -> (keypoint slot of the wave, lane of the group); GL = 8 / 16: power-of-two groups, GL = 3: see above
@@ -551,20 +556,27 @@ __device__ __forceinline__ unsigned spread_pair(unsigned t)
 __device__ __forceinline__ void klt3_region_origin(const level_ptrs &J, int pad, int inx, int iny, int &rr0, int &cc0)
 {
     rr0 = min(max(iny + pad - klt3::ROW_MARGIN, 0), J.rows - klt3::RROWS);
-    cc0 = min(max((OV2_LM + inx - klt3::COL_LEAD) & ~15, 0), J.istride - klt3::RBYTES);
+    cc0 = min(max((OV2_LM + inx - klt3::COL_LEAD) & ~(klt3::COL_ALIGN - 1), 0), J.istride - klt3::RBYTES);
 }
 
-// the group's three lanes fetch the region row by row: lane c takes bytes 16c .. 16c + 15 of every row
-struct klt3_segs { uint4 v[klt3::RROWS]; };
+// the group's three lanes fetch the region: 48-byte rows: lane c takes bytes 16c .. 16c + 15 of every row; 32-byte rows:
+// the 2 x RROWS pieces are dealt out three per instruction (piece s = 3t + c: row s / 2, half s % 2)
+struct klt3_segs { uint4 v[klt3::NLD]; };
 __device__ __forceinline__ void klt3_load_region(const level_ptrs &J, int rr0, int cc0, int c, klt3_segs &S)
 {
-    const unsigned o = J.img_o + (unsigned)(rr0 * J.istride + cc0 + 16 * c);
+    const unsigned o = J.img_o + (unsigned)(rr0 * J.istride + cc0);
 #pragma unroll
-    for (int t = 0; t < klt3::RROWS; ++t) {
+    for (int t = 0; t < klt3::NLD; ++t) {
+        unsigned a;
+        if (klt3::RBYTES == 48) a = o + (unsigned)(t * J.istride + 16 * c);
+        else {
+            const int sg = min(3 * t + c, 2 * klt3::RROWS - 1);
+            a = o + (unsigned)((sg >> 1) * J.istride + (sg & 1) * 16);
+        }
 #ifdef KLT_EXP_NOLOADS
-        S.v[t] = make_uint4(o + t, o ^ 0x5a5a5a5au, o * 3u + t, 0x40302010u);
+        S.v[t] = make_uint4(a + t, a ^ 0x5a5a5a5au, a * 3u + t, 0x40302010u);
 #else
-        S.v[t] = ld_b128(J.base + (size_t)(o + (unsigned)(t * J.istride)));
+        S.v[t] = ld_b128(J.base + (size_t)a);
 #endif
     }
 }
@@ -572,7 +584,10 @@ __device__ __forceinline__ void klt3_store_region(const klt3_segs &S, int c, boo
 {
     if (store) {
 #pragma unroll
-        for (int t = 0; t < klt3::RROWS; ++t) *reinterpret_cast<uint4 *>(lj + t * klt3::RBYTES + 16 * c) = S.v[t];
+        for (int t = 0; t < klt3::NLD; ++t) {
+            if (klt3::RBYTES == 48) *reinterpret_cast<uint4 *>(lj + t * klt3::RBYTES + 16 * c) = S.v[t];
+            else if (3 * t + c < 2 * klt3::RROWS) *reinterpret_cast<uint4 *>(lj + (3 * t + c) * 16) = S.v[t];
+        }
     }
 }
 
@@ -1094,7 +1109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
 // Lanes per keypoint for a call of n keypoints.  9 x 9 windows (the reference's nklt_win_size) have the three-lane
 // mapping (20 keypoints per wave) once the call fills the device with such waves; ov2_klt_set_lanes (or OV2_KLT_LANES
 // = 3 / 8 / 16 in the environment) forces one mapping: tests run every mapping against the oracle.
-#define KLT_GL3_MIN_KPS 40960
+#define KLT_GL3_MIN_KPS 32768
 int klt_lanes_for(const ov2_ctx *c, int n, int win)
 {
     static const int env = [] { const char *e = getenv("OV2_KLT_LANES"); return e ? atoi(e) : 0; }();
