@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--kps", type=int, default=2048, help="keypoints per frame (north_star: ~2k)")
     ap.add_argument("--kf-every", type=int, default=6, help="keyframe period (EuRoC sample: 322 KFs / ~2020 frames)")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames per stream (ping-pong cycle)")
+    ap.add_argument("--no-hard-stream", action="store_true", help="skip the harder-stream leg (reported beside the headline, outside the timed region)")
     ap.add_argument("--frame-gap", type=int, default=3, help="stream frames between consecutive bench frames (flow of ~0.6 px per unit)")
     ap.add_argument("--prior-sigma", type=float, default=1.0,
                     help="noise (px) of the motion-model priors; a harder stream (--frame-gap 9 --prior-sigma 3) makes every level "
@@ -514,6 +515,34 @@ def main():
         out["config"]["lk_iterations_per_level_pass"] = lk_iters / max(lk_passes, 1.0)
         out["config"]["frame_gap"], out["config"]["prior_sigma_px"] = a.frame_gap, a.prior_sigma
         out["ms_per_frame_batch_instrumented"] = 1e3 * el_instr / n_instr
+
+    if rank == 0 and not a.no_roofline and not a.no_hard_stream:
+        # a HARDER stream beside the headline one (front-end alone, outside the timed region): three times the flow per
+        # frame and priors 3 px off, so the LK passes iterate about twice as often -- how the rate degrades with difficulty
+        hw = Workload(ctx, fe, synth, a.seqs, a.kps, 4, seed=synth.SEED_IMG + 101 * rank + 7, gap=3 * a.frame_gap,
+                      prior_sigma=3.0 * a.prior_sigma)
+        for _ in range(2 * hw.L):
+            hw.step(a.kf_every)
+        ctx.synchronize()
+        nb_h = max(4 * a.kf_every, min(120, nbatches))
+        t1 = time.perf_counter()
+        for _ in range(nb_h):
+            hw.step(a.kf_every)
+        ctx.synchronize()
+        el_h = time.perf_counter() - t1
+        hp_, hi_ = 0.0, 0.0
+        for _ in range(hw.L):
+            hw.step(10 ** 9, want_work=True)
+            ctx.synchronize()
+            wv = hw.work.get()
+            hp_ += float((wv >> 16).sum()); hi_ += float((wv & 0xffff).sum())
+        tracked = float(hw.out_st.get().mean())
+        out["hard_stream"] = {"frames_per_sec_front_end_alone": nb_h * a.seqs / el_h, "frame_gap": 3 * a.frame_gap,
+                              "prior_sigma_px": 3.0 * a.prior_sigma, "lk_level_passes_per_keypoint": hp_ / (hw.L * hw.n),
+                              "lk_iterations_per_level_pass": hi_ / max(hp_, 1.0), "tracked_fraction": tracked,
+                              "frame_batches": nb_h,
+                              "note": "same pipeline on a stream with 3x the flow and 3x the prior error; no BA worker beside it"}
+        del hw
 
     do_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline   # the CPU leg is reported at N = 1 only
     if do_cpu:

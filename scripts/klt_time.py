@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""isolated timing of the two KLT stage kernels (nothing else on the GPU): python scripts/klt_time.py [seqs]"""
+"""isolated timing of the two KLT stage kernels (nothing else on the GPU): python scripts/klt_time.py [seqs [frame_gap [prior_sigma]]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ov2slam_amd import frontend as fe, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+GAP = int(sys.argv[2]) if len(sys.argv) > 2 else 3          # stream frames between the two images
+SIGMA = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0  # prior error (px)
 N = 2048
 ctx = fe.Context(0)
 S = synth.StereoStream()
@@ -13,9 +15,9 @@ i0, i1 = fe.Images(ctx, B, 752, 480), fe.Images(ctx, B, 752, 480)
 base = synth.grid_keypoints(N)
 ks, ps, hs = [], [], []
 for b in range(B):
-    t0, t1 = 3 * (b % 5), 3 * (b % 5) + 3
+    t0, t1 = GAP * (b % 5), GAP * (b % 5) + GAP
     i0.upload(b, S.left(t0)); i1.upload(b, S.left(t1))
-    pri, has = synth.make_priors(base, S.flow(t0, t1, base), seed=b)
+    pri, has = synth.make_priors(base, S.flow(t0, t1, base), sigma=SIGMA, seed=b)
     ks.append(base); ps.append(pri); hs.append(has)
 p0, p1 = fe.preprocess_images(ctx, i0), fe.preprocess_images(ctx, i1)
 n = B * N
