@@ -435,6 +435,66 @@ __global__ __launch_bounds__(256) void level_kernel(ov2_pyr_view pv, int l, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// pyrDown alone (what a build runs: the Scharr planes are written on demand).  Tile = 128 x 32 px of level l in LDS
+// (+ 2-px halo, rows as dwords from the column 4 left of the tile), a thread owns FOUR adjacent outputs: per source row
+// one 16-byte LDS read holds the 11 pixels they touch, the 5 x 5 binomial is applied as 1-4-6-4-1 along the row and
+// down the five rows (exact integers), and the four results leave as one dword store.  Same arithmetic as
+// level_kernel's pyrDown part (oracle: pyr_down_rows); grid (ceil(w/128), ceil(h/32), batch), 256 threads.
+#define PD_TW 128
+#define PD_TH 32
+#define PD_ROWS (PD_TH + 4)       // rows y0-2 .. y0+PD_TH+1
+#define PD_DW (PD_TW / 4 + 4)     // dwords per row: cols x0-4 .. x0+PD_TW+11
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(ov2_pyr_view pv, int l)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int tile[PD_ROWS][PD_DW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
+    const ov2_level_desc L = pv.lv[l], N = pv.lv[l + 1];
+    const int pad = pv.pad;
+    const unsigned char *img = pv.base + L.img_off + L.img_bstride * b;
+    for (int i = tid; i < PD_ROWS * PD_DW; i += 256) {
+        const int r = i / PD_DW, c = i - r * PD_DW;
+        const int row = min(y0 - 2 + r + pad, L.h + 2 * pad - 1);            // tiles hanging over the bottom edge
+        const int dw = min((OV2_LM + x0 - 4) / 4 + c, L.istride / 4 - 1);    // ... and over the right edge
+        tile[r][c] = *reinterpret_cast<const unsigned int *>(img + (size_t)row * L.istride + 4 * dw);
+    }
+    __syncthreads();
+    // thread -> outputs (xo .. xo+3, yo): 16 groups per output row, 16 output rows
+    const int gx = tid & 15, ly = tid >> 4;
+    const int xo = (x0 >> 1) + 4 * gx, yo = (y0 >> 1) + ly;
+    if (yo >= N.h || xo >= N.w) return;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        // source columns 2 xo - 2 .. 2 xo + 8 = bytes 2 .. 12 of the 16 bytes from LDS column 8 gx (tile column 0 = x0 - 4);
+        // output o takes bytes 2 + 2o .. 6 + 2o: v_dot4_u32_u8 with (1, 4, 6, 4) on the first four, the fifth as addend
+        const uint4 q = *reinterpret_cast<const uint4 *>(&tile[2 * ly + j][2 * gx]);
+        const unsigned d0 = __builtin_amdgcn_alignbyte(q.y, q.x, 2), d2 = __builtin_amdgcn_alignbyte(q.z, q.y, 2);
+        const unsigned wts = 0x04060401u;
+        int r[4];
+        r[0] = (int)__builtin_amdgcn_udot4(d0, wts, (q.y >> 16) & 255u, false);
+        r[1] = (int)__builtin_amdgcn_udot4(q.y, wts, q.z & 255u, false);
+        r[2] = (int)__builtin_amdgcn_udot4(d2, wts, (q.z >> 16) & 255u, false);
+        r[3] = (int)__builtin_amdgcn_udot4(q.z, wts, q.w & 255u, false);
+        const int kj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] += kj * r[o];
+    }
+    unsigned char out[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) out[o] = (unsigned char)((acc[o] + 128) >> 8);
+    unsigned char *nplane = pv.base + N.img_off + N.img_bstride * b;
+    unsigned char *dp = nplane + (size_t)(yo + pad) * N.istride + OV2_LM + xo;
+    const int nv = min(4, N.w - xo);
+    if (nv == 4) *reinterpret_cast<unsigned int *>(dp) = (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16) | ((unsigned)out[3] << 24);
+    else for (int o = 0; o < nv; ++o) dp[o] = out[o];
+    const bool edge = (xo <= pad) || (xo + 3 >= N.w - 1 - pad) || (yo <= pad) || (yo >= N.h - 1 - pad);
+    if (edge)
+        for (int o = 0; o < nv; ++o) store_reflections(nplane, N.istride, pad, N.w, N.h, xo + o, yo, out[o], false);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 
 ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int batch, ov2_pyr_buf **out)
@@ -591,8 +651,8 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
     { std::lock_guard<std::mutex> g(c->mu); buf->grad_built = false; }
     for (int l = 0; l + 1 < v.nlevels; ++l) {
         const ov2_level_desc &L = v.lv[l];
-        OV2_LAUNCH_ON(c, OV2_K_LEVEL, sp, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, B), dim3(256),
-                           0, sp, v, l, 1, 0);
+        OV2_LAUNCH_ON(c, OV2_K_LEVEL, sp, pyrdown_kernel, dim3((L.w + PD_TW - 1) / PD_TW, (L.h + PD_TH - 1) / PD_TH, B), dim3(256), 0, sp,
+                      v, l);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
