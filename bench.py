@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--ba-workers", type=int, default=1,
                     help="Estimator threads per GPU (the reference runs one per SLAM instance; each owns a share of the "
                          "sequences and its own high-priority HIP context)")
+    ap.add_argument("--fe-priority", default="normal", choices=["high", "normal"],
+                    help="HIP stream priority of the front-end context (the reference's tracking thread is the real-time one)")
     ap.add_argument("--ba-priority", default="high", choices=["high", "normal"],
                     help="HIP stream priority of the local-BA workers: high = a pending batch takes the device as soon as it has "
                          "work (the reference's Estimator thread never waits for the front-end), normal = equal sharing")
@@ -342,7 +344,7 @@ def main():
         torch.cuda.synchronize()
 
     from ov2slam_amd import frontend as fe, synth
-    ctx = fe.Context(local)
+    ctx = fe.Context(local, high_priority=a.fe_priority == "high")
     wl = Workload(ctx, fe, synth, a.seqs, a.kps, a.frames, seed=synth.SEED_IMG + 101 * rank, gap=a.frame_gap, prior_sigma=a.prior_sigma)
 
     if a.mapper_ctx:

@@ -79,6 +79,10 @@ void ov2_images_destroy(ov2_images *imgs);
  * use_clahe=0 skips CLAHE (`use_clahe: 0`).  tiles = (w/50, h/50) in the reference (src/ov2slam.cpp:85-89).
  * The returned pyramid holds levels 0..L (L <= max_level, same early stop as OpenCV), each level a u8 image
  * padded by `win` px of REFLECT_101 and an int16 (Ix,Iy) Scharr gradient padded by `win` px of zeros.
+ * The gradient planes (withDerivatives = true in OpenCV: 4 of the 5 bytes per pixel) are written ON DEMAND, by the first
+ * consumer that reads them (the tracking kernels for other window sizes than 9 or calls below 32 768 keypoints,
+ * ov2_pyr_download_level with a gradient pointer); the 9 x 9 path of large calls derives the same Scharr integers from
+ * the image windows inside its kernel and a build that only feeds it never writes them.
  * Handles are ref-counted because the reference shares pyramids by value between threads
  * (src/ov2slam.cpp:175-180). */
 ov2_status ov2_pyramid_build(ov2_ctx *ctx, const uint8_t *img, int w, int h, int stride, int win, int max_level,
