@@ -2,6 +2,9 @@
 // the flat C ABI.  Reference line numbers (in /root/reference) are cited at each block.
 #include "ov2_host.hpp"
 
+#include <climits>
+#include <set>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -917,7 +920,7 @@ ov2_status Optimizer::setupLocalBADevice(Frame &newframe, LocalBAProblem &pb)
     return OV2_OK;
 }
 
-void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res)
+void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res, bool cur_frame_obs)
 {   // flags :500-592 / :637-735, update :741-882
     const bool inv = pslamstate_->buse_inv_depth_;
     std::vector<std::pair<int, int>> vbadkflmids, vbadstereokflmids;
@@ -937,7 +940,7 @@ void Optimizer::updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov
     for (const auto &b : vbadkflmids) {         // :753-764
         auto it = pb.map_local_pkfs.find(b.first);
         if (it != pb.map_local_pkfs.end()) pmap_->removeMapPointObs(b.second, b.first);
-        if (pmap_->pcurframe_ && b.first == pmap_->pcurframe_->kfid_) pmap_->removeObsFromCurFrameById(b.second);
+        if (cur_frame_obs && pmap_->pcurframe_ && b.first == pmap_->pcurframe_->kfid_) pmap_->removeObsFromCurFrameById(b.second);
         pb.set_badlmids.insert(b.second);
     }
     for (const auto &kv : pb.map_local_pkfs) {   // :767-786 poses of the non-constant keyframes
@@ -1007,6 +1010,224 @@ ov2_status Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)
     if (s == OV2_OK) updateAfterLocalBA(newframe, pb, last_result_);
     last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr;
     return s;
+}
+
+// ---- fullBA / looseBA: the same functors and solver over another selection of keyframes ----------------------------
+void Optimizer::setupRangeBA(int kf_lo, int kf_hi, int kf_obs_max, size_t min_obs, LocalBAProblem &pb)
+{   // src/optimizer.cpp:985-1270 (looseBA) / :1768-2026 (fullBA)
+    const size_t nmincstkfs = pslamstate_->stereo_ ? 1 : 2;
+    const bool inv = pslamstate_->buse_inv_depth_;
+    auto add_pose = [&](int kfid, const std::shared_ptr<Frame> &pkf, bool cst) {
+        const int idx = (int)pb.pose_const.size();
+        pb.kfid_to_pose.emplace(kfid, idx);
+        pb.pose_kfid.push_back(kfid);
+        const SE3 T = pkf->getTwc();
+        pb.pose.insert(pb.pose.end(), T.v.begin(), T.v.end());
+        pb.pose_const.push_back(cst ? 1 : 0);
+        pb.map_local_pkfs.emplace(kfid, pkf);
+        if (cst) pb.set_cstkfids.insert(kfid);
+    };
+    std::set<int> set_lmids2opt;   // the reference's std::set: ascending lmid
+    for (int kfid = kf_lo; kfid <= kf_hi; ++kfid) {
+        auto pkf = pmap_->getKeyframe(kfid);
+        if (!pkf) continue;
+        if (pb.set_cstkfids.size() < nmincstkfs) add_pose(kfid, pkf, true);
+        else {
+            add_pose(kfid, pkf, false);
+            for (const auto &kp : pkf->getKeypoints3d()) set_lmids2opt.insert(kp.lmid_);
+        }
+    }
+    for (int lmid : set_lmids2opt) {
+        auto plm = pmap_->getMapPoint(lmid);
+        if (!plm || plm->isBad() || plm->getKfObsSet().size() < min_obs) { pb.set_badlmids.insert(lmid); continue; }
+        pb.map_local_plms.emplace(lmid, plm);
+        int lmidx = -1;
+        if (!inv) {
+            lmidx = (int)pb.lm_lmid.size();
+            pb.lmid_to_lm.emplace(lmid, lmidx);
+            pb.lm_lmid.push_back(lmid);
+            const Vec3 p = plm->getPoint();
+            pb.lm.push_back(p.x); pb.lm.push_back(p.y); pb.lm.push_back(p.z);
+            pb.lm_anchor_pose.push_back(-1); pb.lm_anchor_uv.push_back(0); pb.lm_anchor_uv.push_back(0);
+        }
+        int kfanchid = -1;
+        for (int kfid : plm->getKfObsSet()) {
+            if (kfid > kf_obs_max) continue;
+            std::shared_ptr<Frame> pkf;
+            auto pkfit = pb.map_local_pkfs.find(kfid);
+            if (pkfit == pb.map_local_pkfs.end()) {   // observers outside the range enter as constants
+                pkf = pmap_->getKeyframe(kfid);
+                if (!pkf) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+                add_pose(kfid, pkf, true);
+            } else {
+                pkf = pkfit->second;
+            }
+            const Keypoint kp = pkf->getKeypointById(lmid);
+            if (kp.lmid_ != lmid) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+            const double sigma = std::pow(2., kp.scale_);
+            auto add_res = [&](int type, const Point2f &uv) {
+                pb.res_type.push_back((uint8_t)type);
+                pb.res_pose.push_back(pb.kfid_to_pose.at(kfid));
+                pb.res_lm.push_back(lmidx);
+                pb.res_uv.push_back(uv.x); pb.res_uv.push_back(uv.y);
+                pb.res_sigma.push_back(sigma);
+            };
+            if (inv && kfanchid < 0) {
+                kfanchid = kfid;
+                const double zanch = (pkf->getTcw() * plm->getPoint()).z;
+                lmidx = (int)pb.lm_lmid.size();
+                pb.lmid_to_lm.emplace(lmid, lmidx);
+                pb.lm_lmid.push_back(lmid);
+                pb.lm.push_back(1. / zanch);
+                pb.lm_anchor_pose.push_back(pb.kfid_to_pose.at(kfid));
+                pb.lm_anchor_uv.push_back(kp.unpx_.x); pb.lm_anchor_uv.push_back(kp.unpx_.y);
+                if (kp.is_stereo_) { add_res(OV2_BA_RANCH_INV, kp.runpx_); pb.nbstereo++; }
+                else pb.nbmono++;
+                continue;
+            }
+            add_res(inv ? OV2_BA_L_INV : OV2_BA_L_XYZ, kp.unpx_);
+            if (kp.is_stereo_) { add_res(inv ? OV2_BA_R_INV : OV2_BA_R_XYZ, kp.runpx_); pb.nbstereo++; }
+            else pb.nbmono++;
+        }
+    }
+}
+
+ov2_status Optimizer::fullBA(const bool buse_robust_cost)
+{
+    auto pkf0 = pmap_->getKeyframe(0);   // Frame &newframe = *pmap_->getKeyframe(0)  (:1680)
+    if (!pkf0) return OV2_ERR_INVALID;
+    int nkfid = -1;
+    for (const auto &kv : pmap_->map_pkfs_) nkfid = std::max(nkfid, kv.first);
+    LocalBAProblem pb;
+    setupRangeBA(0, nkfid, INT_MAX, 3, pb);   // no observer filter (:1830), landmarks need 3 observers (:1813)
+    if (pb.res_type.empty()) return OV2_OK;
+    ov2_ba_problem p = pb.view(*pslamstate_, *pkf0);
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    if (!buse_robust_cost) o.huber_delta = 0.0;
+    o.max_iters = 100; o.l2_max_iters = 100;     // options.max_num_iterations = 100, reused by the refinement (:2056, :2150)
+    o.function_tolerance = 1e-6;                 // Ceres default: fullBA sets none
+    o.l2_refine = pslamstate_->apply_l2_after_robust_ ? 1 : 0;
+    std::vector<double> chi2(p.n_res);
+    std::vector<uint8_t> depth(p.n_res), outlier(p.n_res);
+    std::memset(&last_result_, 0, sizeof(last_result_));
+    last_result_.chi2 = chi2.data(); last_result_.depth_positive = depth.data(); last_result_.outlier = outlier.data();
+    const ov2_status s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    if (s == OV2_OK) updateAfterLocalBA(*pkf0, pb, last_result_, false);   // same update stage (:2232-2330); kfid_ - 3 < 0: no age culling
+    last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr;
+    return s;
+}
+
+ov2_status Optimizer::looseBA(int inikfid, const int nkfid, const bool buse_robust_cost)
+{
+    auto pnew = pmap_->getKeyframe(nkfid);
+    if (!pnew) return OV2_ERR_INVALID;
+    Frame &newframe = *pnew;
+    LocalBAProblem pb;
+    setupRangeBA(inikfid, nkfid, newframe.kfid_, 0, pb);   // observers younger than the loop keyframe are left out (:1056)
+    if (pb.res_type.empty() || !pb.kfid_to_pose.count(newframe.kfid_)) return OV2_OK;
+    ov2_ba_problem p = pb.view(*pslamstate_, newframe);
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    if (!buse_robust_cost) o.huber_delta = 0.0;
+    o.max_iters = 5; o.function_tolerance = 1e-4;   // :1298-1299
+    o.l2_refine = 0;                                // one solve; the flags only pick what is removed
+    std::vector<double> chi2(p.n_res);
+    std::vector<uint8_t> depth(p.n_res), outlier(p.n_res);
+    std::memset(&last_result_, 0, sizeof(last_result_));
+    last_result_.chi2 = chi2.data(); last_result_.depth_positive = depth.data(); last_result_.outlier = outlier.data();
+    const ov2_status s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    if (s != OV2_OK) { last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr; return s; }
+    const bool inv = pslamstate_->buse_inv_depth_;
+    // flags (:1330-1426)
+    std::vector<std::pair<int, int>> vbadkflmids, vbadstereokflmids;
+    for (size_t i = 0; i < pb.res_type.size(); ++i) {
+        if (!outlier[i]) continue;
+        const int kfid = pb.pose_kfid[pb.res_pose[i]], lmid = pb.lm_lmid[pb.res_lm[i]];
+        const int t = pb.res_type[i];
+        if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) vbadkflmids.emplace_back(kfid, lmid);
+        else vbadstereokflmids.emplace_back(kfid, lmid);
+        pb.set_badlmids.insert(lmid);
+    }
+    last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr;
+    // new states (:1432-1526)
+    const SE3 iniTnewkfw = newframe.getTcw();
+    SE3 optTwnewkf;
+    { const int idx = pb.kfid_to_pose.at(newframe.kfid_); for (int k = 0; k < 7; ++k) optTwnewkf.v[k] = pb.pose[7 * idx + k]; }
+    std::vector<std::pair<int, Vec3>> vlm;
+    for (const auto &kv : pb.map_local_plms) {
+        const int lmid = kv.first;
+        auto plm = kv.second;
+        if (!plm) continue;
+        if (plm->isBad()) { pb.set_badlmids.insert(lmid); continue; }
+        auto lit = pb.lmid_to_lm.find(lmid);
+        if (lit == pb.lmid_to_lm.end()) { pb.set_badlmids.insert(lmid); continue; }
+        if (inv) {
+            const double zanch = 1. / pb.lm[lit->second];
+            if (zanch <= 0.) { pb.set_badlmids.insert(lmid); continue; }
+            auto it = pb.map_local_pkfs.find(plm->kfid_);
+            if (it == pb.map_local_pkfs.end() || !it->second) { pb.set_badlmids.insert(lmid); continue; }
+            auto pkfanch = it->second;
+            const Keypoint kp = pkfanch->getKeypointById(lmid);
+            const CameraCalibration &c = *pkfanch->pcalib_leftcam_;
+            const Vec3 cam{zanch * (kp.unpx_.x - c.cx_) / c.fx_, zanch * (kp.unpx_.y - c.cy_) / c.fy_, zanch};
+            vlm.emplace_back(lmid, pkfanch->getTwc() * cam);   // with the keyframe's pose BEFORE the update, as the reference does
+        } else {
+            vlm.emplace_back(lmid, Vec3{pb.lm[3 * lit->second], pb.lm[3 * lit->second + 1], pb.lm[3 * lit->second + 2]});
+        }
+    }
+    // update (:1533-1548)
+    for (const auto &e : vlm) pmap_->updateMapPoint(e.first, e.second);
+    for (const auto &kv : pb.map_local_pkfs) {
+        if (pb.set_cstkfids.count(kv.first) || !kv.second) continue;
+        const int idx = pb.kfid_to_pose.at(kv.first);
+        SE3 T;
+        for (int k = 0; k < 7; ++k) T.v[k] = pb.pose[7 * idx + k];
+        kv.second->setTwc(T);
+        pmap_->touchPose(kv.first);
+    }
+    // propagate the correction of the loop keyframe to the younger keyframes and the landmarks they anchor (:1552-1593)
+    int nkfid_max = -1;
+    for (const auto &kv : pmap_->map_pkfs_) nkfid_max = std::max(nkfid_max, kv.first);
+    std::unordered_set<int> uplmid_set;
+    for (int kfid = newframe.kfid_ + 1; kfid <= nkfid_max; ++kfid) {
+        if (pb.map_local_pkfs.count(kfid)) continue;
+        auto pkf = pmap_->getKeyframe(kfid);
+        if (!pkf) continue;
+        const SE3 updTwkf = optTwnewkf * (iniTnewkfw * pkf->getTwc());
+        for (const auto &kp : pkf->getKeypoints3d()) {
+            if (uplmid_set.count(kp.lmid_) || pb.map_local_plms.count(kp.lmid_)) continue;
+            auto plm = pmap_->getMapPoint(kp.lmid_);
+            if (!plm) { pmap_->removeMapPointObs(kp.lmid_, kfid); continue; }
+            if (plm->kfid_ == kfid) {
+                pmap_->updateMapPoint(kp.lmid_, updTwkf * pkf->projWorldToCam(plm->getPoint()));
+                uplmid_set.insert(plm->lmid_);
+            }
+        }
+        pkf->setTwc(updTwkf);
+        pmap_->touchPose(kfid);
+    }
+    // bad observations (:1596-1620), culling (:1623-1650)
+    for (const auto &b : vbadstereokflmids) {
+        auto it = pb.map_local_pkfs.find(b.first);
+        if (it != pb.map_local_pkfs.end()) { it->second->removeStereoKeypointById(b.second); pmap_->touchStereoOff(b.first, b.second); }
+    }
+    for (const auto &b : vbadkflmids) {
+        if (pb.map_local_pkfs.count(b.first)) pmap_->removeMapPointObs(b.second, b.first);
+        if (pmap_->pcurframe_ && b.first == pmap_->pcurframe_->kfid_) pmap_->removeObsFromCurFrameById(b.second);
+    }
+    for (int lmid : pb.set_badlmids) {
+        auto it = pb.map_local_plms.find(lmid);
+        std::shared_ptr<MapPoint> plm = (it == pb.map_local_plms.end()) ? pmap_->getMapPoint(lmid) : it->second;
+        if (!plm) continue;
+        if (plm->isBad()) pmap_->removeMapPoint(lmid);
+        else if (plm->getKfObsSet().size() < 3 && plm->kfid_ < newframe.kfid_ - 3 && !plm->isobs_) pmap_->removeMapPoint(lmid);
+    }
+    if (pmap_->pcurframe_) {   // :1653-1656
+        auto pc = pmap_->pcurframe_;
+        pc->setTwc(optTwnewkf * (iniTnewkfw * pc->getTwc()));
+    }
+    return OV2_OK;
 }
 
 ov2_status Optimizer::structureOnlyBA(const std::vector<int> &vlm2optids)

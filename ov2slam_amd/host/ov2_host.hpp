@@ -273,11 +273,21 @@ public:
     ov2_status localBA(Frame &newframe, const bool buse_robust_cost);
     // src/optimizer.cpp:2594-2781: points-only refinement (all poses constant, XYZ, Huber, 10 iterations) through ov2_ba_solve
     ov2_status structureOnlyBA(const std::vector<int> &vlm2optids);
+    // src/optimizer.cpp:1674-2332 (Mapper::runFullBA, src/mapper.cpp:780): every keyframe (the first nmincstkfs constant), every
+    // 3D landmark with >= 3 observers, 100 iterations, flags / L2 refinement / update as in localBA -- through ov2_ba_solve
+    ov2_status fullBA(const bool buse_robust_cost);
+    // src/optimizer.cpp:900-1670 (LoopCloser, src/loop_closer.cpp:368): keyframes inikfid .. nkfid (the first nmincstkfs
+    // constant), one robust solve of 5 iterations (function_tolerance 1e-4), then the corrections are propagated to the
+    // younger keyframes, their own landmarks and the current frame
+    ov2_status looseBA(int inikfid, const int nkfid, const bool buse_robust_cost);
+    // problem assembly shared by the three: keyframes kf_lo .. kf_hi, observers above kf_obs_max ignored, landmarks with
+    // fewer than min_obs observers set aside as bad
+    void setupRangeBA(int kf_lo, int kf_hi, int kf_obs_max, size_t min_obs, LocalBAProblem &pb);
     // the three stages, exposed for tests
     void setupLocalBA(Frame &newframe, LocalBAProblem &pb);                                   // :43-430
     // the same stage from the device map mirror (ov2_map_local_ba_setup): linear scans instead of the hash-map walk
     ov2_status setupLocalBADevice(Frame &newframe, LocalBAProblem &pb);
-    void updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res);   // :741-882
+    void updateAfterLocalBA(Frame &newframe, LocalBAProblem &pb, const ov2_ba_result &res, bool cur_frame_obs = true);   // :741-882
     bool stopLocalBA() const { return bstop_localba_; }
     void signalStopLocalBA() { bstop_localba_ = true; }
     ov2_ba_result last_result_{};

@@ -306,6 +306,43 @@ int ov2h_structure_only_ba(void *p, void *ctx, int n, const int *lmids, double *
     return s;
 }
 
+// set-up stage shared by Optimizer::fullBA / looseBA (keyframes kf_lo .. kf_hi, observers above kf_obs_max ignored,
+// landmarks with fewer than min_obs observers set aside); read back with ov2h_local_ba_get
+int ov2h_range_ba_setup(void *p, int kf_lo, int kf_hi, int kf_obs_max, int min_obs, int *n_pose, int *n_lm, int *n_res)
+{
+    HostMap *m = (HostMap *)p;
+    Optimizer opt(nullptr, m->st, m->map);
+    m->pb = LocalBAProblem();
+    opt.setupRangeBA(kf_lo, kf_hi, kf_obs_max, (size_t)min_obs, m->pb);
+    *n_pose = (int)m->pb.pose_const.size(); *n_lm = (int)m->pb.lm_lmid.size(); *n_res = (int)m->pb.res_type.size();
+    return 0;
+}
+
+// Optimizer::fullBA(buse_robust_cost) on the GPU context `ctx`
+int ov2h_full_ba(void *p, void *ctx, int robust, int *n_out1, int *n_out2, double *final_cost, int *n_iters)
+{
+    HostMap *m = (HostMap *)p;
+    Optimizer opt((ov2_ctx *)ctx, m->st, m->map);
+    const ov2_status s = opt.fullBA(robust != 0);
+    const ov2_ba_result &r = opt.last_result_;
+    if (n_out1) *n_out1 = r.n_outliers_pass1;
+    if (n_out2) *n_out2 = r.n_outliers_pass2;
+    if (final_cost) *final_cost = r.l2_done ? r.l2_final_cost : r.final_cost;
+    if (n_iters) *n_iters = r.n_log;
+    return s;
+}
+
+// Optimizer::looseBA(inikfid, nkfid, buse_robust_cost)
+int ov2h_loose_ba(void *p, void *ctx, int inikfid, int nkfid, int robust, int *n_out1, double *final_cost)
+{
+    HostMap *m = (HostMap *)p;
+    Optimizer opt((ov2_ctx *)ctx, m->st, m->map);
+    const ov2_status s = opt.looseBA(inikfid, nkfid, robust != 0);
+    if (n_out1) *n_out1 = opt.last_result_.n_outliers_pass1;
+    if (final_cost) *final_cost = opt.last_result_.final_cost;
+    return s;
+}
+
 // VisualFrontEnd::computePose on keyframe `kfid` taken as the current frame, starting from pose Twc7_init
 int ov2h_compute_pose(void *p, void *ctx, int kfid, const double *Twc7_init, int *p3p_req)
 {

@@ -28,6 +28,9 @@ def lib():
         L.ov2h_map_attach_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ov2h_local_ba_setup_dev.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_map_device_rows.argtypes = [C.c_void_p, ip, ip, ip]
+        L.ov2h_range_ba_setup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+        L.ov2h_full_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, C.POINTER(C.c_double), ip]
+        L.ov2h_loose_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, ip, C.POINTER(C.c_double)]
         L.ov2h_map_remove_obs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ov2h_map_remove_landmark.argtypes = [C.c_void_p, C.c_int]
         L.ov2h_map_set_isobs.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -161,6 +164,28 @@ class HostMap:
         rc = fn(self.h, self.newkf, C.byref(npose), C.byref(nlm), C.byref(nres))
         if rc < 0:
             raise RuntimeError(f"local BA set-up failed ({rc})")
+        return self._read_problem(rc, npose, nlm, nres)
+
+    def setup_range_ba(self, kf_lo, kf_hi, kf_obs_max=2 ** 31 - 1, min_obs=0):
+        """Optimizer::setupRangeBA: the set-up stage of fullBA (0, last, no observer filter, min_obs 3) / looseBA"""
+        npose, nlm, nres = C.c_int(), C.c_int(), C.c_int()
+        lib().ov2h_range_ba_setup(self.h, int(kf_lo), int(kf_hi), int(kf_obs_max), int(min_obs), C.byref(npose), C.byref(nlm), C.byref(nres))
+        return self._read_problem(0, npose, nlm, nres)
+
+    def full_ba(self, ctx, robust=True):
+        """Optimizer::fullBA on the GPU. returns (status, outliers pass 1, pass 2, final cost, logged iterations)"""
+        n1, n2, fc, it = C.c_int(), C.c_int(), C.c_double(), C.c_int()
+        st = lib().ov2h_full_ba(self.h, ctx.h, int(robust), C.byref(n1), C.byref(n2), C.byref(fc), C.byref(it))
+        return st, n1.value, n2.value, fc.value, it.value
+
+    def loose_ba(self, ctx, inikfid, nkfid, robust=True):
+        """Optimizer::looseBA on the GPU. returns (status, flagged observations, final cost)"""
+        n1, fc = C.c_int(), C.c_double()
+        st = lib().ov2h_loose_ba(self.h, ctx.h, int(inikfid), int(nkfid), int(robust), C.byref(n1), C.byref(fc))
+        return st, n1.value, fc.value
+
+    def _read_problem(self, rc, npose, nlm, nres):
+        L = lib()
         e = 1 if self.prob.inv_depth else 3
         ip, u8 = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
         out = dict(aborted=rc == 1, pose_kfid=np.zeros(npose.value, np.int32), pose_const=np.zeros(npose.value, np.uint8),

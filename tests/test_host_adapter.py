@@ -147,3 +147,111 @@ def test_structure_only_ba(ctx, oracle):
         assert np.abs(xyz - Q.lm[k]).max() <= 1e-9 * max(1.0, np.abs(Q.lm[k]).max())
     untouched, _ = hm.landmark(1)
     assert np.array_equal(untouched, P.lm[1])
+
+
+def _flat_from(hm, P, pb):
+    """the flat problem the host mirror assembled (ids -> indices), as a BaProblem for the oracle / the flat GPU solve"""
+    pidx = {int(k): i for i, k in enumerate(pb["pose_kfid"])}
+    lidx = {int(l): i for i, l in enumerate(pb["lm_lmid"])}
+    Trl = np.asarray(P.T_rl, np.float64)
+    return T.BaProblem(P.calib_l, P.calib_r, Trl, P.inv_depth, pb["pose"], pb["pose_const"], pb["lm"],
+                       np.array([pidx[int(k)] for k in pb["lm_anchor_kfid"]], np.int32) if P.inv_depth else None,
+                       pb["lm_anchor_uv"] if P.inv_depth else None, pb["res_type"],
+                       np.array([pidx[int(k)] for k in pb["res_kfid"]], np.int32),
+                       np.array([lidx[int(l)] for l in pb["res_lmid"]], np.int32), pb["res_uv"])
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_full_and_loose_ba_selection(inv_depth):
+    """Optimizer::fullBA (src/optimizer.cpp:1768-1830): every keyframe, the first one constant (stereo), only landmarks
+    with >= 3 observers; looseBA (:985-1060): keyframes ini..n, the first constant, older observers enter as constants,
+    younger ones are left out."""
+    P = synth_ba.make_window(12, 500, inv_depth=inv_depth, seed=21, max_obs=6)
+    hm = host_map.HostMap(P)
+    full = hm.setup_range_ba(0, 11, min_obs=3)
+    assert sorted(full["pose_kfid"]) == list(range(12))
+    assert {int(k) for k, c in zip(full["pose_kfid"], full["pose_const"]) if c} == {0}
+    nobs = {}
+    for i in range(P.n_res):
+        k = int(P.lm_anchor_pose[P.res_lm[i]]) if P.res_type[i] == T.RANCH_INV else int(P.res_pose[i])
+        nobs.setdefault(int(P.res_lm[i]), set()).add(k)
+    if inv_depth:
+        for l in range(len(P.lm)):
+            nobs.setdefault(l, set()).add(int(P.lm_anchor_pose[l]))
+    # landmarks seen by keyframes 1.. (3D keypoints of the optimised keyframes) with at least 3 observers
+    want = {l for l, ks in nobs.items() if len(ks) >= 3 and any(k >= 1 for k in ks)}
+    assert set(int(l) for l in full["lm_lmid"]) == want
+    loose = hm.setup_range_ba(4, 9, kf_obs_max=9, min_obs=0)
+    ks = {int(k): int(c) for k, c in zip(loose["pose_kfid"], loose["pose_const"])}
+    assert all(ks[k] == 0 for k in range(5, 10)) and ks[4] == 1
+    assert all(c == 1 for k, c in ks.items() if k < 4) and max(ks) == 9
+    assert int(loose["res_kfid"].max()) <= 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_full_ba_equals_flat_solve(ctx, oracle, inv_depth):
+    """Optimizer::fullBA end to end (set-up, 100-iteration solve + refinement on the GPU, update stage) against the CPU
+    oracle solving the same flat problem with the same options"""
+    P = synth_ba.make_window(10, 500, inv_depth=inv_depth, seed=33, max_obs=6)
+    hm, href = host_map.HostMap(P), host_map.HostMap(P)
+    pb = href.setup_range_ba(0, 9, min_obs=3)
+    Q = _flat_from(href, P, pb)
+    o = oracle.ba_default_options()
+    o.max_iters, o.l2_max_iters, o.function_tolerance = 100, 100, 1e-6
+    R = oracle.ba_solve(Q, o)
+    st, n1, n2, fc, nlog = hm.full_ba(ctx)
+    assert st == 0
+    assert (n1, n2) == (R.c.n_outliers_pass1, R.c.n_outliers_pass2)
+    assert fc == pytest.approx(R.c.l2_final_cost if R.c.l2_done else R.c.final_cost, rel=1e-6)
+    assert nlog == R.c.n_log
+    for i, k in enumerate(pb["pose_kfid"]):
+        assert np.allclose(hm.pose(int(k)), Q.pose[i], atol=1e-6), k
+    checked = 0
+    for i, l in enumerate(pb["lm_lmid"][::5]):
+        j = 5 * i
+        xyz, _ = hm.landmark(int(l))
+        if xyz is None:
+            continue
+        if inv_depth:
+            a = int(Q.lm_anchor_pose[j])
+            z = 1.0 / Q.lm[j, 0]
+            u, v = Q.lm_anchor_uv[j]
+            pc = z * np.array([(u - Q.calib_l[2]) / Q.calib_l[0], (v - Q.calib_l[3]) / Q.calib_l[1], 1.0])
+            want = synth_ba.quat_to_rot(Q.pose[a, 3:]) @ pc + Q.pose[a, :3]
+        else:
+            want = Q.lm[j]
+        assert np.allclose(xyz, want, atol=1e-5), l
+        checked += 1
+    assert checked > 20
+
+
+@pytest.mark.gpu
+def test_loose_ba_propagates_the_correction(ctx, oracle):
+    """Optimizer::looseBA over keyframes 3..8 of a 12-keyframe map: the optimised poses equal the oracle's solve of the same
+    flat problem, and keyframes 9..11 move rigidly with keyframe 8 (src/optimizer.cpp:1552-1593)"""
+    P = synth_ba.make_window(12, 600, inv_depth=False, seed=35, max_obs=6)
+    hm, href = host_map.HostMap(P), host_map.HostMap(P)
+    pb = href.setup_range_ba(3, 8, kf_obs_max=8, min_obs=0)
+    Q = _flat_from(href, P, pb)
+    o = oracle.ba_default_options()
+    o.max_iters, o.function_tolerance, o.l2_refine = 5, 1e-4, 0
+    R = oracle.ba_solve(Q, o)
+    before = {k: hm.pose(k) for k in range(12)}
+    st, n1, fc = hm.loose_ba(ctx, 3, 8)
+    assert st == 0 and n1 == R.c.n_outliers_pass1
+    assert fc == pytest.approx(R.c.final_cost, rel=1e-6)
+    for i, k in enumerate(pb["pose_kfid"]):
+        assert np.allclose(hm.pose(int(k)), Q.pose[i], atol=1e-6), k
+
+    def mat(p7):
+        M = np.eye(4)
+        M[:3, :3] = synth_ba.quat_to_rot(p7[3:])
+        M[:3, 3] = p7[:3]
+        return M
+    D = mat(hm.pose(8)) @ np.linalg.inv(mat(before[8]))      # optTwnewkf * iniTnewkfw
+    for k in (9, 10):
+        assert np.allclose(mat(hm.pose(k)), D @ mat(before[k]), atol=1e-9), k
+    # keyframe 11 doubles as MapManager::pcurframe_ in this test map (one Frame object), so it receives the keyframe update
+    # AND the current-frame update (:1653-1656)
+    assert np.allclose(mat(hm.pose(11)), D @ D @ mat(before[11]), atol=1e-9)
