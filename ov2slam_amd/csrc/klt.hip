@@ -1110,12 +1110,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
 // mapping (20 keypoints per wave) once the call fills the device with such waves; ov2_klt_set_lanes (or OV2_KLT_LANES
 // = 3 / 8 / 16 in the environment) forces one mapping: tests run every mapping against the oracle.
 #define KLT_GL3_MIN_KPS 32768
-int klt_lanes_for(const ov2_ctx *c, int n, int win)
+int klt_lanes_for(const ov2_ctx *c, int n, int win, const ov2_pyr *a, const ov2_pyr *b)
 {
     static const int env = [] { const char *e = getenv("OV2_KLT_LANES"); return e ? atoi(e) : 0; }();
     const int forced = c->klt_lanes ? c->klt_lanes : env;
-    if (forced == 8 || forced == 16 || (forced == 3 && win == 9)) return forced;
-    if (win == 9 && n >= KLT_GL3_MIN_KPS) return 3;
+    // the three-lane kernels address a pyramid as base + 32-bit offset: allocations of 4 GB and more take the other kernels
+    const bool fits32 = a->buf->bytes < (1ull << 32) && b->buf->bytes < (1ull << 32);
+    if (forced == 8 || forced == 16 || (forced == 3 && win == 9 && fits32)) return forced;
+    if (win == 9 && n >= KLT_GL3_MIN_KPS && fits32) return 3;
     return n >= KLT_GL8_MIN_KPS ? 8 : 16;
 }
 
@@ -1169,14 +1171,15 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
-    if (klt_lanes_for(c, n, win) != 3 && ((s = ov2_pyr_need_grad(c, prev)) != OV2_OK || (s = ov2_pyr_need_grad(c, cur)) != OV2_OK)) return s;
+    const int lanes = klt_lanes_for(c, n, win, prev, cur);
+    if (lanes != 3 && ((s = ov2_pyr_need_grad(c, prev)) != OV2_OK || (s = ov2_pyr_need_grad(c, cur)) != OV2_OK)) return s;
 #define KLT_FB_GL(W, G)                                                                                        \
     OV2_LAUNCH(c, OV2_K_KLT_FB, (klt_fb_kernel<W, G>), dim3((n + klt_map<G>::KPW - 1) / klt_map<G>::KPW), dim3(64), 0, c->stream,    \
                prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),                 \
                reinterpret_cast<float2 *>(d_priors), d_status, d_img_idx, d_iters)
 #define KLT_FB(W)                                                                                              \
     do {                                                                                                       \
-        if (klt_lanes_for(c, n, W) == 8) KLT_FB_GL(W, 8);                                                         \
+        if (lanes == 8) KLT_FB_GL(W, 8);                                                                          \
         else KLT_FB_GL(W, 16);                                                                                 \
     } while (0)
     switch (win) {
@@ -1184,7 +1187,7 @@ extern "C" ov2_status ov2_klt_track_fb_dev(ov2_ctx *c, const ov2_pyr *prev, cons
     case 5: KLT_FB(5); break;
     case 7: KLT_FB(7); break;
     case 9:
-        if (klt_lanes_for(c, n, 9) == 3) KLT_FB_GL(9, 3);
+        if (lanes == 3) KLT_FB_GL(9, 3);
         else KLT_FB(9);
         break;
     default: KLT_FB(11); break;
@@ -1245,7 +1248,8 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     P.rule33 = rule33 ? 1 : 0;
     OV2_HIP(c, hipSetDevice(c->device));
     if ((s = ov2_pyr_wait_ready(c, prev)) != OV2_OK || (s = ov2_pyr_wait_ready(c, cur)) != OV2_OK) return s;
-    if (klt_lanes_for(c, n, win) != 3 && ((s = ov2_pyr_need_grad(c, prev)) != OV2_OK || (s = ov2_pyr_need_grad(c, cur)) != OV2_OK)) return s;
+    const int lanes = klt_lanes_for(c, n, win, prev, cur);
+    if (lanes != 3 && ((s = ov2_pyr_need_grad(c, prev)) != OV2_OK || (s = ov2_pyr_need_grad(c, cur)) != OV2_OK)) return s;
     const int B = prev->buf->batch;
     // scratch: [tallies B x 64 | list lengths (3)] zeroed per call, then the three keypoint lists
     const size_t cnt_bytes = ((size_t)B * 64 + 16) * sizeof(unsigned);
@@ -1274,7 +1278,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     } while (0)
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \
-        if (klt_lanes_for(c, n, W) == 8) KLT_STAGES_GL(W, 8);                                                      \
+        if (lanes == 8) KLT_STAGES_GL(W, 8);                                                                       \
         else KLT_STAGES_GL(W, 16);                                                                              \
     } while (0)
     switch (win) {
@@ -1282,7 +1286,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     case 5: KLT_STAGES(5); break;
     case 7: KLT_STAGES(7); break;
     case 9:
-        if (klt_lanes_for(c, n, 9) == 3) KLT_STAGES_GL(9, 3);
+        if (lanes == 3) KLT_STAGES_GL(9, 3);
         else KLT_STAGES(9);
         break;
     default: KLT_STAGES(11); break;

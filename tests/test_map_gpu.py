@@ -181,3 +181,67 @@ def test_observation_table_is_squeezed_when_mostly_dead(ctx, inv_depth):
         hm.remove_obs(k, l)
     assert_same(hm)
     assert hm.device_rows()[2] == 1
+
+
+class _SetupC(C.Structure):
+    _fields_ = [("aborted", C.c_int32), ("n_pose", C.c_int32), ("n_lm", C.c_int32), ("n_res", C.c_int32), ("n_bad", C.c_int32),
+                ("pose_kfid", C.c_void_p), ("pose_const", C.c_void_p), ("pose", C.c_void_p), ("lm_lmid", C.c_void_p),
+                ("lm", C.c_void_p), ("lm_anchor_pose", C.c_void_p), ("lm_anchor_uv", C.c_void_p), ("res_type", C.c_void_p),
+                ("res_pose", C.c_void_p), ("res_lm", C.c_void_p), ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p),
+                ("bad_lmid", C.c_void_p)]
+
+
+def test_long_sequence_keeps_the_observation_table_bounded(ctx):
+    """3000 keyframes through the raw hooks, a sliding window of 40 of them alive (older keyframes and their landmarks are
+    removed as MapManager::removeKeyframe / removeMapPoint would): the table is squeezed again and again, stays within a
+    small multiple of the live observations instead of growing with the sequence, and the last set-up equals the set-up of
+    a fresh map holding only the live window."""
+    L = ctx.lib
+    vp = lambda a: a.ctypes.data
+    rng = np.random.default_rng(3)
+    NKF, WIN, PER, NEW = 3000, 40, 120, 12          # keyframes, live window, keypoints per keyframe, new landmarks per keyframe
+
+    def frame(k):
+        lm = np.arange(max(0, NEW * k - (PER - NEW)), NEW * (k + 1), dtype=np.int32)[-PER:]   # the newest PER landmark ids
+        T = np.array([0.1 * k, 0, 0, 0, 0, 0, 1.0])
+        uv = np.ascontiguousarray(rng.uniform(20, 700, (len(lm), 2)))
+        return T, lm, uv
+
+    def add(m, k):
+        T, lm, uv = frame(k)
+        xyz = np.ascontiguousarray(np.stack([0.1 * k + 0.01 * (lm % 7), 0.02 * (lm % 5), 3.0 + 0.001 * lm], 1))
+        st = np.full(len(lm), 1 | 2 | 8, np.uint8)   # alive, 3D, keypoints 3D
+        assert L.ov2_map_set_landmarks(m, len(lm), vp(lm), vp(xyz), vp(st)) == 0
+        assert L.ov2_map_add_keyframe(m, k, vp(T), len(lm), vp(lm), vp(uv), None, None, None) == 0
+
+    m = C.c_void_p()
+    assert L.ov2_map_create(ctx.h, 64, 1024, 4096, C.byref(m)) == 0
+    out = _SetupC()
+    for k in range(NKF):
+        add(m, k)
+        if k >= WIN:
+            old = k - WIN
+            assert L.ov2_map_remove_keyframe(m, old) == 0
+            gone = np.arange(NEW * old, NEW * (old + 1), dtype=np.int32) - (PER - NEW)   # landmarks only the removed keyframes saw
+            gone = gone[gone >= 0]
+            if len(gone):
+                assert L.ov2_map_remove_landmarks(m, len(gone), vp(gone)) == 0
+        if k % 25 == 24:
+            assert L.ov2_map_local_ba_setup(m, k, 25, 1, 0, None, C.byref(out)) == 0
+    assert L.ov2_map_local_ba_setup(m, NKF - 1, 25, 1, 0, None, C.byref(out)) == 0
+    rows, cap, nsq = C.c_int(), C.c_int(), C.c_int()
+    assert L.ov2_map_obs_rows(m, C.byref(rows), C.byref(cap), C.byref(nsq)) == 0
+    live = WIN * PER
+    assert nsq.value >= 10 and rows.value <= 2.6 * live and cap.value <= 8 * live, (rows.value, cap.value, nsq.value)
+    got = (out.aborted, out.n_pose, out.n_lm, out.n_res)
+    # the same window in a fresh map
+    f = C.c_void_p()
+    assert L.ov2_map_create(ctx.h, NKF + 8, NEW * (NKF + 1) + 8, 8192, C.byref(f)) == 0
+    for k in range(NKF - WIN, NKF):
+        add(f, k)
+    gone = np.arange(0, NEW * (NKF - WIN) - (PER - NEW), dtype=np.int32)
+    ref = _SetupC()
+    assert L.ov2_map_local_ba_setup(f, NKF - 1, 25, 1, 0, None, C.byref(ref)) == 0
+    assert got == (ref.aborted, ref.n_pose, ref.n_lm, ref.n_res) and not out.aborted and out.n_res > 1000
+    L.ov2_map_destroy(m)
+    L.ov2_map_destroy(f)
