@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
 // Lanes per keypoint for a call of n keypoints.  9 x 9 windows (the reference's nklt_win_size) have the three-lane
 // mapping (20 keypoints per wave) once the call fills the device with such waves; ov2_klt_set_lanes (or OV2_KLT_LANES
 // = 3 / 8 / 16 in the environment) forces one mapping: tests run every mapping against the oracle.
-#define KLT_GL3_MIN_KPS 32768
+#define KLT_GL3_MIN_KPS 4096
 int klt_lanes_for(const ov2_ctx *c, int n, int win, const ov2_pyr *a, const ov2_pyr *b)
 {
     static const int env = [] { const char *e = getenv("OV2_KLT_LANES"); return e ? atoi(e) : 0; }();

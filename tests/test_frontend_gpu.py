@@ -262,7 +262,8 @@ def test_fb_klt_full_size_properties(ctx, stream):
 @pytest.mark.parametrize("win", [5, 7, 9, 11])
 def test_klt_large_call_eight_lane_path(ctx, oracle, stream, win):
     """calls with >= 65536 keypoints switch the kernels to 8 lanes per keypoint (eight keypoints per wave; for
-    win 9 / 11 the columns beyond the eighth are dealt out pixel by pixel): bit parity with the oracle on 66k keypoints,
+    win 11 the columns beyond the eighth are dealt out pixel by pixel; win 9 takes the three-lane kernels from 4096
+    keypoints on, test_klt_every_lane_mapping_matches_the_oracle forces the others): bit parity with the oracle on 66k keypoints,
     through both entry points, incl. the saturated stripe images that force the wide b-sum path."""
     rng = np.random.default_rng(win)
     n = 66000
