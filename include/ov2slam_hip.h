@@ -334,6 +334,37 @@ ov2_status ov2_pnp_solve_batch_dev(ov2_ctx *ctx, int B, const int32_t *d_off, co
                                    int32_t *d_success, int32_t *d_iters);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Pose graphs: Optimizer::localPoseGraph (src/optimizer.cpp:2346-2592, the loop closer's chain of
+ * keyframes loop .. new + the loop edge) and Optimizer::fullPoseGraph (:2783-2870, the chain of all frames between
+ * constant keyframes at the end of a run) = LeftSE3RelativePoseError (src/ceres_parametrization.cpp:30-102,
+ * se3left_parametrization.hpp:76-99) on SE3LeftParameterization blocks, LEVENBERG_MARQUARDT, no loss function.
+ *   residual of edge (i, j):  log( Twc_j^-1 * Twc_i * T_ij ),  T_ij = the measured pose of camera j in camera i
+ *   (parameters[0] = pose i, parameters[1] = pose j; sigma = 1), jacobians as the reference writes them
+ *   ((I + J_c / 2) Adj, "adapted from Strasdat").
+ * Structure: both graphs are CHAINS -- every edge joins two free poses that are neighbours in the order of the free
+ * poses, or has a constant end -- so the normal equations are block tridiagonal per run of free poses; other graphs
+ * return OV2_ERR_UNSUPPORTED.  The whole minimisation is one launch (one workgroup; runs of free poses in parallel).
+ * Options: the trust-region fields of ov2_ba_options (max_iters, function_tolerance, radii, diagonal clamps, tolerances,
+ * jacobi_scaling); localPoseGraph: 10 iterations, 1e-4; fullPoseGraph: 100, 1e-6. */
+typedef struct ov2_pg_problem {
+    int32_t n_pose;
+    double *pose;                 /* n_pose x 7 Twc (tx ty tz qx qy qz qw), in / out */
+    const uint8_t *pose_const;    /* n_pose */
+    int32_t n_edge;
+    const int32_t *edge_i, *edge_j;
+    const double *T_ij;           /* n_edge x 7 */
+} ov2_pg_problem;
+
+typedef struct ov2_pg_result {
+    double initial_cost, final_cost;
+    int32_t termination;          /* OV2_BA_TERM_* */
+    int32_t n_log;
+    ov2_ba_iter log[OV2_BA_MAX_LOG];
+} ov2_pg_result;
+
+ov2_status ov2_pose_graph_solve(ov2_ctx *ctx, const ov2_pg_problem *p, const ov2_ba_options *o, ov2_pg_result *r);
+
+/* ---------------------------------------------------------------------------------------------------
  * Flat device-resident map mirror: keyframe poses, landmark states and the observation table
  * (keyframe, landmark, unpx, runpx, scale, stereo flag) as SoA arrays in HBM, kept in step with the reference's
  * MapManager by the hooks below, so that the set-up stage of Optimizer::localBA (src/optimizer.cpp:43-430: the walk

@@ -189,6 +189,9 @@ def _ba_lib():
         L.ov2o_pnp_solve.argtypes = [C.c_int, f64p, f64p, i32p, f64p, f64p, C.c_int, C.c_float, C.c_int, C.c_int,
                                      u8p, i32p]
         L.ov2o_pnp_solve.restype = C.c_int
+        L.ov2o_pg_eval_edge.argtypes = [f64p, f64p, f64p, f64p, f64p, f64p]
+        L.ov2o_pose_graph_solve.argtypes = [C.POINTER(T.PgProblemC), C.POINTER(T.BaOptionsC), C.POINTER(T.PgResultC)]
+        L.ov2o_pose_graph_solve.restype = C.c_int
         L._ba_bound = True
     return L
 
@@ -260,6 +263,32 @@ def ba_solve(prob, options=None):
     pc = prob.as_c()
     rc = L.ov2o_ba_solve(C.byref(pc), C.byref(o), C.byref(res.c))
     assert rc == 0
+    return res
+
+
+def pg_eval_edge(pose_i, pose_j, T_ij, want_jac=True):
+    """LeftSE3RelativePoseError::Evaluate on one edge. returns (r[6], Ji[6,6], Jj[6,6])"""
+    a, b, t = (np.ascontiguousarray(v, np.float64) for v in (pose_i, pose_j, T_ij))
+    r, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+    _ba_lib().ov2o_pg_eval_edge(_p(a, f64p), _p(b, f64p), _p(t, f64p), _p(r, f64p), _p(Ji, f64p) if want_jac else None,
+                                _p(Jj, f64p) if want_jac else None)
+    return r, Ji, Jj
+
+
+def pg_default_options(max_iters=10, function_tolerance=1e-4):
+    """the options of Optimizer::localPoseGraph (src/optimizer.cpp:2442-2446) on the trust-region defaults"""
+    o = ba_default_options()
+    o.max_iters, o.function_tolerance = max_iters, function_tolerance
+    return o
+
+
+def pose_graph_solve(prob, options=None):
+    """LM solve of a PgProblem (poses updated in place). returns PgResultC"""
+    from ov2slam_amd import ba_types as T
+    o = options if options is not None else pg_default_options()
+    res = T.PgResultC()
+    pc = prob.as_c()
+    assert _ba_lib().ov2o_pose_graph_solve(C.byref(pc), C.byref(o), C.byref(res)) == 0
     return res
 
 

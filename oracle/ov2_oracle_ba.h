@@ -47,6 +47,11 @@ int ov2o_pnp_solve(int n, const double *unpx, const double *wpts, const int *sca
 void ov2o_ba_default_options(ov2_ba_options *o, float robust_mono_th);
 int ov2o_ba_solve(const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R);
 
+/* pose graphs (ov2_oracle_pg.c): LeftSE3RelativePoseError on one edge (6 residuals, two 6x6 local jacobians, row-major;
+ * either jacobian may be NULL) and the LM solve of a whole graph (dense normal equations) */
+void ov2o_pg_eval_edge(const double *pose_i, const double *pose_j, const double *T_ij, double r[6], double Ji[36], double Jj[36]);
+int ov2o_pose_graph_solve(const ov2_pg_problem *P, const ov2_ba_options *o, ov2_pg_result *R);
+
 /* LevenbergMarquardtStrategy state updates used by the oracle's minimize() (levenberg_marquardt_strategy.cc:76-164) */
 void ov2o_lm_step_accepted(double *radius, double *decrease_factor, double step_quality, double max_radius);
 void ov2o_lm_step_rejected(double *radius, double *decrease_factor);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ov2_map_set_obs_stereo": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "ov2_map_remove_landmarks": (C.c_int, [vp, C.c_int, vp]),
     "ov2_map_remove_keyframe": (C.c_int, [vp, C.c_int]),
+    "ov2_pose_graph_solve": (C.c_int, [vp, vp, vp, vp]),
     "ov2_map_compact": (C.c_int, [vp, ip, ip]),
     "ov2_map_obs_rows": (C.c_int, [vp, ip, ip, ip]),
     "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -47,6 +47,39 @@ class BaResultC(C.Structure):
                 ("n_outliers_pass2", C.c_int32), ("log", BaIterC * MAX_LOG)]
 
 
+class PgProblemC(C.Structure):
+    _fields_ = [("n_pose", C.c_int32), ("pose", dp), ("pose_const", u8p), ("n_edge", C.c_int32), ("edge_i", i32p),
+                ("edge_j", i32p), ("T_ij", dp)]
+
+
+class PgResultC(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("termination", C.c_int32), ("n_log", C.c_int32),
+                ("log", BaIterC * MAX_LOG)]
+
+
+class PgProblem:
+    """a pose graph: poses (n x 7 Twc, solved in place), constness, edges (i, j) with the measured T_ij (7)"""
+
+    def __init__(self, pose, pose_const, edge_i, edge_j, T_ij):
+        c = np.ascontiguousarray
+        self.pose = c(pose, np.float64).reshape(-1, 7).copy()
+        self.pose_const = c(pose_const, np.uint8)
+        self.edge_i, self.edge_j = c(edge_i, np.int32), c(edge_j, np.int32)
+        self.T_ij = c(T_ij, np.float64).reshape(-1, 7)
+        assert len(self.pose) == len(self.pose_const) and len(self.edge_i) == len(self.edge_j) == len(self.T_ij)
+
+    def copy(self):
+        return PgProblem(self.pose, self.pose_const, self.edge_i, self.edge_j, self.T_ij)
+
+    def as_c(self):
+        p = PgProblemC()
+        p.n_pose, p.pose, p.pose_const = len(self.pose), self.pose.ctypes.data_as(dp), self.pose_const.ctypes.data_as(u8p)
+        p.n_edge = len(self.edge_i)
+        p.edge_i, p.edge_j = self.edge_i.ctypes.data_as(i32p), self.edge_j.ctypes.data_as(i32p)
+        p.T_ij = self.T_ij.ctypes.data_as(dp)
+        return p
+
+
 def _ptr(a, t):
     return None if a is None else a.ctypes.data_as(t)
 

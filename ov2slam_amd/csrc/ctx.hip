@@ -276,7 +276,7 @@ const char *ov2_kernel_names[OV2_K_MAX] = {"clahe_lut_kernel", "level0_kernel", 
                                            nullptr, nullptr, "detect_cell_kernels", "detect_mask_kernel", "subpix_kernel",
                                            "pnp_kernel", "klt_compact_kernel",
                                            "detect_list_kernels", "map_setup_kernels", "tri_kernel", "stereo_sad_kernel",
-                                           "stereo_gate_kernel", "brief_kernel", "match_kernels"};
+                                           "stereo_gate_kernel", "brief_kernel", "match_kernels", "pose_graph_kernel"};
 
 static hipEvent_t ktime_event(ov2_ctx *c)
 {

@@ -3,6 +3,7 @@
 #include "ov2_host.hpp"
 
 #include <climits>
+#include <map>
 #include <set>
 
 #include <algorithm>
@@ -1228,6 +1229,138 @@ ov2_status Optimizer::looseBA(int inikfid, const int nkfid, const bool buse_robu
         pc->setTwc(optTwnewkf * (iniTnewkfw * pc->getTwc()));
     }
     return OV2_OK;
+}
+
+// ---- pose graphs ------------------------------------------------------------------------------------------------
+bool Optimizer::localPoseGraph(Frame &newframe, int kfloop_id, const SE3 &newTwc, ov2_status *status)
+{
+    if (status) *status = OV2_OK;
+    const SE3 iniTcw = newframe.getTcw();
+    int nkfid_max = -1;
+    for (const auto &kv : pmap_->map_pkfs_) nkfid_max = std::max(nkfid_max, kv.first);
+    auto ploopkf = pmap_->getKeyframe(kfloop_id);
+    while (!ploopkf && kfloop_id < nkfid_max) ploopkf = pmap_->getKeyframe(++kfloop_id);   // :2368-2371
+    if (!ploopkf) return false;
+    std::vector<double> pose, Tij;
+    std::vector<uint8_t> cst;
+    std::vector<int32_t> ei, ej;
+    std::vector<int> kfids;
+    std::map<int, std::shared_ptr<Frame>> map_pkfs;
+    auto push_pose = [&](int kfid, const SE3 &T, bool c) {
+        kfids.push_back(kfid);
+        pose.insert(pose.end(), T.v.begin(), T.v.end());
+        cst.push_back(c ? 1 : 0);
+        return (int)kfids.size() - 1;
+    };
+    auto push_edge = [&](int a, int b, const SE3 &T) { ei.push_back(a); ej.push_back(b); Tij.insert(Tij.end(), T.v.begin(), T.v.end()); };
+    push_pose(kfloop_id, ploopkf->getTwc(), true);
+    SE3 Tciw = ploopkf->getTcw();
+    int ci = 0;
+    const SE3 Tloop_new = Tciw * newTwc;                         // :2387
+    for (int kfid = kfloop_id + 1; kfid <= newframe.kfid_; ++kfid) {   // :2389-2420
+        auto pkf = pmap_->getKeyframe(kfid);
+        if (!pkf) { if (kfid == newframe.kfid_) return false; continue; }
+        map_pkfs.emplace(kfid, pkf);
+        const SE3 Twcj = pkf->getTwc();
+        const int j = push_pose(kfid, Twcj, false);
+        push_edge(ci, j, Tciw * Twcj);
+        Tciw = Twcj.inverse();
+        ci = j;
+    }
+    if (kfids.size() < 2 || kfids.back() != newframe.kfid_) return false;
+    push_edge(0, (int)kfids.size() - 1, Tloop_new);              // :2422-2425
+    ov2_pg_problem P;
+    P.n_pose = (int)kfids.size(); P.pose = pose.data(); P.pose_const = cst.data();
+    P.n_edge = (int)ei.size(); P.edge_i = ei.data(); P.edge_j = ej.data(); P.T_ij = Tij.data();
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    o.max_iters = 10; o.function_tolerance = 1e-4;               // :2445-2446
+    const ov2_status s = ov2_pose_graph_solve(ctx_, &P, &o, &last_pg_);
+    if (status) *status = s;
+    if (s != OV2_OK) return false;
+    auto pose_of = [&](int idx) { SE3 T; for (int k = 0; k < 7; ++k) T.v[k] = pose[7 * (size_t)idx + k]; return T; };
+    const SE3 newoptTwc = pose_of((int)kfids.size() - 1);
+    {
+        const double dx = newTwc.v[0] - newoptTwc.v[0], dy = newTwc.v[1] - newoptTwc.v[1], dz = newTwc.v[2] - newoptTwc.v[2];
+        if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.3 && pslamstate_->stereo_) return false;   // :2468-2474: degenerate
+    }
+    // updated keyframes and the landmarks they anchor (:2487-2520)
+    std::unordered_set<int> processed_lmids;
+    std::vector<std::pair<int, Vec3>> vlm;
+    std::vector<std::pair<int, SE3>> vkf;
+    for (size_t i = 1; i < kfids.size(); ++i) {
+        const int kfid = kfids[i];
+        auto pkf = map_pkfs.at(kfid);
+        const SE3 T = pose_of((int)i);
+        vkf.emplace_back(kfid, T);
+        for (const auto &kp : pkf->getKeypoints3d()) {
+            const int lmid = kp.lmid_;
+            if (processed_lmids.count(lmid)) continue;
+            auto plm = pmap_->getMapPoint(lmid);
+            if (!plm) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+            if (plm->kfid_ == kfid) {
+                vlm.emplace_back(lmid, T * pkf->projWorldToCam(plm->getPoint()));
+                processed_lmids.insert(lmid);
+            }
+        }
+    }
+    // the correction of the new keyframe carried to the younger keyframes and their landmarks (:2527-2560)
+    for (int kfid = newframe.kfid_ + 1; kfid <= nkfid_max; ++kfid) {
+        auto pkf = pmap_->getKeyframe(kfid);
+        if (!pkf) continue;
+        const SE3 updTwkf = newoptTwc * (iniTcw * pkf->getTwc());
+        for (const auto &kp : pkf->getKeypoints3d()) {
+            const int lmid = kp.lmid_;
+            if (processed_lmids.count(lmid)) continue;
+            auto plm = pmap_->getMapPoint(lmid);
+            if (!plm) { pmap_->removeMapPointObs(lmid, kfid); continue; }
+            if (plm->kfid_ == kfid) {
+                pmap_->updateMapPoint(lmid, updTwkf * pkf->projWorldToCam(plm->getPoint()));
+                processed_lmids.insert(lmid);
+            }
+        }
+        pkf->setTwc(updTwkf);
+        pmap_->touchPose(kfid);
+    }
+    for (const auto &e : vlm) pmap_->updateMapPoint(e.first, e.second);   // :2563-2577
+    for (const auto &e : vkf) {
+        auto pkf = pmap_->getKeyframe(e.first);
+        if (pkf) { pkf->setTwc(e.second); pmap_->touchPose(e.first); }
+    }
+    if (pmap_->pcurframe_) {                                               // :2580-2583
+        auto pc = pmap_->pcurframe_;
+        pc->setTwc(newoptTwc * (iniTcw * pc->getTwc()));
+    }
+    return true;
+}
+
+bool Optimizer::fullPoseGraph(std::vector<SE3> &vTwc, const std::vector<SE3> &vTpc, const std::vector<bool> &viskf, ov2_status *status)
+{
+    if (status) *status = OV2_OK;
+    const size_t n = vTwc.size();
+    if (n == 0 || vTpc.size() != n || viskf.size() != n) return false;
+    std::vector<double> pose(7 * n), Tij;
+    std::vector<uint8_t> cst(n);
+    std::vector<int32_t> ei, ej;
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 7; ++k) pose[7 * i + k] = vTwc[i].v[k];
+        cst[i] = viskf[i] ? 1 : 0;
+        if (i == 0) continue;
+        ei.push_back((int32_t)i - 1); ej.push_back((int32_t)i);            // :2806-2809
+        Tij.insert(Tij.end(), vTpc[i].v.begin(), vTpc[i].v.end());
+    }
+    ov2_pg_problem P;
+    P.n_pose = (int)n; P.pose = pose.data(); P.pose_const = cst.data();
+    P.n_edge = (int)ei.size(); P.edge_i = ei.data(); P.edge_j = ej.data(); P.T_ij = Tij.data();
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    o.max_iters = 100; o.function_tolerance = 1e-6;                          // :2821-2824
+    const ov2_status s = ov2_pose_graph_solve(ctx_, &P, &o, &last_pg_);
+    if (status) *status = s;
+    if (s != OV2_OK) return false;
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 7; ++k) vTwc[i].v[k] = pose[7 * i + k];
+    return true;
 }
 
 ov2_status Optimizer::structureOnlyBA(const std::vector<int> &vlm2optids)

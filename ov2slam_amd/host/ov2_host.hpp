@@ -280,6 +280,15 @@ public:
     // constant), one robust solve of 5 iterations (function_tolerance 1e-4), then the corrections are propagated to the
     // younger keyframes, their own landmarks and the current frame
     ov2_status looseBA(int inikfid, const int nkfid, const bool buse_robust_cost);
+    // src/optimizer.cpp:2346-2592 (LoopCloser, src/loop_closer.cpp:320): keyframes kfloop_id .. newframe joined by their
+    // relative poses + the loop edge kfloop_id -> newframe from the P3P pose newTwc, loop keyframe constant; solved by
+    // ov2_pose_graph_solve (10 iterations, 1e-4); rejected when the optimised new pose lands > 0.3 m from newTwc (stereo);
+    // then keyframes, the landmarks they anchor, the younger keyframes and the current frame are moved
+    bool localPoseGraph(Frame &newframe, int kfloop_id, const SE3 &newTwc, ov2_status *status = nullptr);
+    // :2783-2870 (SlamManager::writeFullTrajectoryLC, src/ov2slam.cpp:702): every frame a pose (keyframes constant),
+    // consecutive frames joined by vTpc; vTwc receives the optimised trajectory (the reference writes it to a file)
+    bool fullPoseGraph(std::vector<SE3> &vTwc, const std::vector<SE3> &vTpc, const std::vector<bool> &viskf, ov2_status *status = nullptr);
+    ov2_pg_result last_pg_{};
     // problem assembly shared by the three: keyframes kf_lo .. kf_hi, observers above kf_obs_max ignored, landmarks with
     // fewer than min_obs observers set aside as bad
     void setupRangeBA(int kf_lo, int kf_hi, int kf_obs_max, size_t min_obs, LocalBAProblem &pb);

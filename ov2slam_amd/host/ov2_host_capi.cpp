@@ -343,6 +343,42 @@ int ov2h_loose_ba(void *p, void *ctx, int inikfid, int nkfid, int robust, int *n
     return s;
 }
 
+// Optimizer::localPoseGraph(newframe = keyframe newkf, kfloop_id, newTwc). returns 1 accepted, 0 rejected, < 0 error
+int ov2h_local_pose_graph(void *p, void *ctx, int newkf, int kfloop_id, const double *newTwc7, double *final_cost, int *n_log)
+{
+    HostMap *m = (HostMap *)p;
+    auto f = m->map->getKeyframe(newkf);
+    if (!f) return -1;
+    SE3 T;
+    for (int k = 0; k < 7; ++k) T.v[k] = newTwc7[k];
+    Optimizer opt((ov2_ctx *)ctx, m->st, m->map);
+    ov2_status s = OV2_OK;
+    const bool ok = opt.localPoseGraph(*f, kfloop_id, T, &s);
+    if (final_cost) *final_cost = opt.last_pg_.final_cost;
+    if (n_log) *n_log = opt.last_pg_.n_log;
+    return s != OV2_OK ? -2 : (ok ? 1 : 0);
+}
+
+// Optimizer::fullPoseGraph(vTwc, vTpc, viskf) on flat arrays (n x 7, n x 7, n); vTwc is overwritten
+int ov2h_full_pose_graph(void *p, void *ctx, int n, double *Twc7, const double *Tpc7, const unsigned char *iskf, double *final_cost)
+{
+    HostMap *m = (HostMap *)p;
+    std::vector<SE3> vTwc((size_t)n), vTpc((size_t)n);
+    std::vector<bool> viskf((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 7; ++k) { vTwc[i].v[k] = Twc7[7 * (size_t)i + k]; vTpc[i].v[k] = Tpc7[7 * (size_t)i + k]; }
+        viskf[i] = iskf[i] != 0;
+    }
+    Optimizer opt((ov2_ctx *)ctx, m->st, m->map);
+    ov2_status s = OV2_OK;
+    const bool ok = opt.fullPoseGraph(vTwc, vTpc, viskf, &s);
+    if (final_cost) *final_cost = opt.last_pg_.final_cost;
+    if (ok)
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 7; ++k) Twc7[7 * (size_t)i + k] = vTwc[i].v[k];
+    return s != OV2_OK ? -2 : (ok ? 1 : 0);
+}
+
 // VisualFrontEnd::computePose on keyframe `kfid` taken as the current frame, starting from pose Twc7_init
 int ov2h_compute_pose(void *p, void *ctx, int kfid, const double *Twc7_init, int *p3p_req)
 {

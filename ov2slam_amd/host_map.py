@@ -30,6 +30,8 @@ def lib():
         L.ov2h_map_device_rows.argtypes = [C.c_void_p, ip, ip, ip]
         L.ov2h_range_ba_setup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip]
         L.ov2h_full_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, C.POINTER(C.c_double), ip]
+        L.ov2h_local_pose_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, dp, C.POINTER(C.c_double), ip]
+        L.ov2h_full_pose_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, dp, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]
         L.ov2h_loose_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, ip, C.POINTER(C.c_double)]
         L.ov2h_map_remove_obs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ov2h_map_remove_landmark.argtypes = [C.c_void_p, C.c_int]
@@ -183,6 +185,26 @@ class HostMap:
         n1, fc = C.c_int(), C.c_double()
         st = lib().ov2h_loose_ba(self.h, ctx.h, int(inikfid), int(nkfid), int(robust), C.byref(n1), C.byref(fc))
         return st, n1.value, fc.value
+
+    def local_pose_graph(self, ctx, newkf, kfloop_id, newTwc):
+        """Optimizer::localPoseGraph. returns (1 accepted / 0 rejected, final cost, logged iterations)"""
+        fc, nl = C.c_double(), C.c_int()
+        T = np.ascontiguousarray(newTwc, np.float64)
+        rc = lib().ov2h_local_pose_graph(self.h, ctx.h, int(newkf), int(kfloop_id), _dp(T), C.byref(fc), C.byref(nl))
+        if rc < 0:
+            raise RuntimeError(f"localPoseGraph failed ({rc})")
+        return rc, fc.value, nl.value
+
+    def full_pose_graph(self, ctx, Twc, Tpc, iskf):
+        """Optimizer::fullPoseGraph on (n x 7) poses, (n x 7) relative poses prev -> cur, keyframe flags. returns (ok, Twc, cost)"""
+        Tw = np.ascontiguousarray(Twc, np.float64).copy()
+        Tp = np.ascontiguousarray(Tpc, np.float64)
+        kf = np.ascontiguousarray(iskf, np.uint8)
+        fc = C.c_double()
+        rc = lib().ov2h_full_pose_graph(self.h, ctx.h, len(Tw), _dp(Tw), _dp(Tp), kf.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(fc))
+        if rc < 0:
+            raise RuntimeError(f"fullPoseGraph failed ({rc})")
+        return rc == 1, Tw, fc.value
 
     def _read_problem(self, rc, npose, nlm, nres):
         L = lib()

@@ -255,3 +255,104 @@ def test_loose_ba_propagates_the_correction(ctx, oracle):
     # keyframe 11 doubles as MapManager::pcurframe_ in this test map (one Frame object), so it receives the keyframe update
     # AND the current-frame update (:1653-1656)
     assert np.allclose(mat(hm.pose(11)), D @ D @ mat(before[11]), atol=1e-9)
+
+
+def _mat(p7):
+    M = np.eye(4)
+    M[:3, :3] = synth_ba.quat_to_rot(np.asarray(p7[3:]) / np.linalg.norm(p7[3:]))
+    M[:3, 3] = p7[:3]
+    return M
+
+
+def _drifted_window(n_kf, n_lm, seed, drift):
+    """a window whose keyframes k >= 1 carry an accumulating pose error (what a loop closure finds)"""
+    P = synth_ba.make_window(n_kf, n_lm, inv_depth=False, seed=seed, max_obs=6)
+    rng = np.random.default_rng(seed)
+    E = np.eye(4)
+    for k in range(1, n_kf):
+        d = rng.normal(0, drift, 6)
+        dR, dt = synth_ba.se3_exp(d)
+        D = np.eye(4)
+        D[:3, :3], D[:3, 3] = dR, dt
+        E = E @ D
+        M = _mat(P.pose[k]) @ E
+        P.pose[k] = synth_ba.pose7(M[:3, :3], M[:3, 3])
+    return P
+
+
+@pytest.mark.gpu
+def test_local_pose_graph_through_the_host_mirror(ctx, oracle):
+    """Optimizer::localPoseGraph: chain + loop edge assembled from the map, solved on the GPU, keyframes / anchored
+    landmarks moved; against the oracle's solve of the same graph.  A loop pose that the chain cannot follow is refused."""
+    from ov2slam_amd import ba_types as BT
+    P0 = synth_ba.make_window(12, 400, inv_depth=False, seed=44, max_obs=6)
+    P = _drifted_window(12, 400, 44, 0.004)
+    hm = host_map.HostMap(P)
+    newTwc = P0.pose[11].copy()                       # the pose the loop detection found for the new keyframe (truth)
+    before = {k: hm.pose(k) for k in range(12)}
+    lm_before = {l: hm.landmark(l)[0] for l in range(0, 400, 9) if hm.landmark(l)[0] is not None}
+    # the same graph for the oracle
+    T = [_mat(before[k]) for k in range(12)]
+    ei, ej = list(range(11)) + [0], list(range(1, 12)) + [11]
+    Tij = [np.linalg.inv(T[k - 1]) @ T[k] for k in range(1, 12)] + [np.linalg.inv(T[0]) @ _mat(newTwc)]
+    const = np.zeros(12, np.uint8)
+    const[0] = 1
+    G = BT.PgProblem(np.stack([before[k] for k in range(12)]), const, ei, ej, np.stack([synth_ba.pose7(M[:3, :3], M[:3, 3]) for M in Tij]))
+    R = oracle.pose_graph_solve(G)
+    ok, fc, nlog = hm.local_pose_graph(ctx, 11, 0, newTwc)
+    assert ok == 1 and nlog == R.n_log
+    assert fc == pytest.approx(R.final_cost, rel=1e-8, abs=1e-16)
+    for k in range(11):
+        assert np.allclose(hm.pose(k), G.pose[k], atol=1e-8), k
+    # keyframe 11 doubles as MapManager::pcurframe_ in this test map (one Frame object): after the keyframe update it also
+    # receives the current-frame update newoptTwc * iniTcw * Twcur (:2580-2583)
+    Mopt = _mat(G.pose[11])
+    assert np.allclose(_mat(hm.pose(11)), Mopt @ np.linalg.inv(_mat(before[11])) @ Mopt, atol=1e-8)
+    assert np.linalg.norm(G.pose[11][:3] - newTwc[:3]) < 0.5 * np.linalg.norm(before[11][:3] - newTwc[:3])
+    moved = 0
+    for l, xyz in lm_before.items():                  # landmarks travel with the keyframe that anchors them
+        a = min(int(P.res_pose[i]) for i in range(P.n_res) if int(P.res_lm[i]) == l)
+        if a == 11:
+            continue
+        want = _mat(hm.pose(a)) @ np.linalg.inv(_mat(before[a])) @ np.append(xyz, 1.0)
+        assert np.allclose(hm.landmark(l)[0], want[:3], atol=1e-7), l
+        moved += a > 0
+    assert moved > 5
+    # degenerate loop pose: the optimised pose of the new keyframe stays > 0.3 m away from it -> refused, map untouched
+    h2 = host_map.HostMap(P)
+    far = newTwc.copy()
+    far[:3] += np.array([6.0, 0.0, 0.0])
+    ok2, _, _ = h2.local_pose_graph(ctx, 11, 0, far)
+    assert ok2 == 0
+    for k in range(12):
+        assert np.array_equal(h2.pose(k), before[k])
+
+
+@pytest.mark.gpu
+def test_full_pose_graph_through_the_host_mirror(ctx, oracle):
+    from ov2slam_amd import ba_types as BT
+    rng = np.random.default_rng(9)
+    n = 120
+    P0 = synth_ba.make_window(4, 40, inv_depth=False, seed=1)
+    hm = host_map.HostMap(P0)
+    gt = [np.eye(4)]
+    step = np.eye(4)
+    step[:3, :3], step[:3, 3] = synth_ba.se3_exp(np.array([0.1, 0.0, 0.01, 0.0, 0.02, 0.0]))
+    for k in range(1, n):
+        gt.append(gt[-1] @ step)
+    iskf = np.zeros(n, np.uint8)
+    iskf[::8] = 1
+    p7 = lambda M: synth_ba.pose7(M[:3, :3], M[:3, 3])
+
+    def noisy(M, s):
+        D = np.eye(4)
+        D[:3, :3], D[:3, 3] = synth_ba.se3_exp(rng.normal(0, s, 6))
+        return M @ D
+    Twc = np.stack([p7(gt[k]) if iskf[k] else p7(noisy(gt[k], 0.01)) for k in range(n)])
+    Tpc = np.stack([p7(np.eye(4))] + [p7(noisy(np.linalg.inv(gt[k - 1]) @ gt[k], 0.001)) for k in range(1, n)])
+    G = BT.PgProblem(Twc, iskf, np.arange(n - 1), np.arange(1, n), Tpc[1:])
+    R = oracle.pose_graph_solve(G, oracle.pg_default_options(100, 1e-6))
+    ok, out, fc = hm.full_pose_graph(ctx, Twc, Tpc, iskf)
+    assert ok and fc == pytest.approx(R.final_cost, rel=1e-8, abs=1e-16)
+    assert np.abs(out - G.pose).max() < 1e-8
+    assert np.array_equal(out[iskf != 0], Twc[iskf != 0])
