@@ -243,10 +243,71 @@ std::vector<Keypoint> Frame::getSurroundingKeypoints(const Keypoint &kp) const
     return vkps;
 }
 
+Point2f CameraCalibration::undistortImagePoint(const Point2f &pt) const
+{
+    if (D_.empty()) return pt;
+    const double u = pt.x, v = pt.y;
+    if (model_ == Pinhole) {
+        const double k1 = D_[0], k2 = D_.size() > 1 ? D_[1] : 0., p1 = D_.size() > 2 ? D_[2] : 0., p2 = D_.size() > 3 ? D_[3] : 0.,
+                     k3 = D_.size() > 4 ? D_[4] : 0.;
+        double x = (u - cx_) * (1. / fx_), y = (v - cy_) * (1. / fy_);
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {   // TermCriteria(COUNT, 5): no epsilon test
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1. + ((k3 * r2 + k2) * r2 + k1) * r2);
+            if (icdist < 0) { x = (u - cx_) * (1. / fx_); y = (v - cy_) * (1. / fy_); break; }
+            const double dX = 2. * p1 * x * y + p2 * (r2 + 2. * x * x), dY = p1 * (r2 + 2. * y * y) + 2. * p2 * x * y;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        return Point2f{(float)(fx_ * x + cx_), (float)(fy_ * y + cy_)};
+    }
+    const double k[4] = {D_[0], D_.size() > 1 ? D_[1] : 0., D_.size() > 2 ? D_[2] : 0., D_.size() > 3 ? D_[3] : 0.};
+    const double pwx = (u - cx_) / fx_, pwy = (v - cy_) / fy_;
+    double theta_d = std::sqrt(pwx * pwx + pwy * pwy);
+    theta_d = std::min(std::max(-M_PI / 2., theta_d), M_PI / 2.);
+    double scale = 1.0;
+    if (theta_d > 1e-8) {
+        double theta = theta_d;
+        for (int j = 0; j < 10; ++j) {
+            const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+            const double k0t2 = k[0] * t2, k1t4 = k[1] * t4, k2t6 = k[2] * t6, k3t8 = k[3] * t8;
+            const double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) / (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+            theta -= fix;
+            if (std::fabs(fix) < 1e-8) break;
+        }
+        scale = std::tan(theta) / theta_d;
+    }
+    return Point2f{(float)(fx_ * (pwx * scale) + cx_), (float)(fy_ * (pwy * scale) + cy_)};
+}
+
+Point2f CameraCalibration::projectCamToImageDist(const Vec3 &pc) const
+{
+    const double invz = 1. / pc.z, x = pc.x * invz, y = pc.y * invz;
+    if (D_.empty()) return Point2f{(float)(fx_ * x + cx_), (float)(fy_ * y + cy_)};
+    if (model_ == Pinhole) {
+        // the reference hands cv::projectPoints a Point3f(x, y, 1): the normalised coordinates pass through float
+        const double xf = (double)(float)x, yf = (double)(float)y;
+        const double k1 = D_[0], k2 = D_.size() > 1 ? D_[1] : 0., p1 = D_.size() > 2 ? D_[2] : 0., p2 = D_.size() > 3 ? D_[3] : 0.,
+                     k3 = D_.size() > 4 ? D_[4] : 0.;
+        const double r2 = xf * xf + yf * yf, r4 = r2 * r2, r6 = r4 * r2;
+        const double a1 = 2 * xf * yf, a2 = r2 + 2 * xf * xf, a3 = r2 + 2 * yf * yf;
+        const double cdist = 1 + k1 * r2 + k2 * r4 + k3 * r6;
+        const double xd = xf * cdist + p1 * a1 + p2 * a2, yd = yf * cdist + p1 * a3 + p2 * a1;
+        return Point2f{(float)(xd * fx_ + cx_), (float)(yd * fy_ + cy_)};
+    }
+    const double xf = (double)(float)x, yf = (double)(float)y;   // Point2f(x, y)
+    const double r = std::sqrt(xf * xf + yf * yf), theta = std::atan(r);
+    const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double theta_d = theta * (1 + D_[0] * t2 + (D_.size() > 1 ? D_[1] : 0.) * t4 + (D_.size() > 2 ? D_[2] : 0.) * t6 + (D_.size() > 3 ? D_[3] : 0.) * t8);
+    const double inv_r = r > 1e-8 ? 1.0 / r : 1.0, cdist = r > 1e-8 ? theta_d * inv_r : 1.0;
+    return Point2f{(float)(fx_ * (xf * cdist) + cx_), (float)(fy_ * (yf * cdist) + cy_)};
+}
+
 void Frame::computeKeypoint(const Point2f &pt, Keypoint &kp) const
-{   // src/frame.cpp:246-254; undistortImagePoint is the identity without distortion coefficients
+{   // src/frame.cpp:246-254
     kp.px_ = pt;
-    kp.unpx_ = pt;
+    kp.unpx_ = pcalib_leftcam_ ? pcalib_leftcam_->undistortImagePoint(pt) : pt;
     if (!pcalib_leftcam_) return;
     const CameraCalibration &cl = *pcalib_leftcam_;
     const double hx = (double)kp.unpx_.x, hy = (double)kp.unpx_.y;
@@ -261,8 +322,8 @@ void Frame::updateKeypointStereo(int lmid, const Point2f &pt)
     if (it == mapkps_.end()) return;
     Keypoint &kp = it->second;
     kp.rpx_ = pt;
-    kp.runpx_ = pt;   // undistortImagePoint: identity without distortion coefficients
     const CameraCalibration &cr = *pcalib_rightcam_;
+    kp.runpx_ = cr.undistortImagePoint(pt);
     Vec3 bv{((double)kp.runpx_.x - cr.cx_) / cr.fx_, ((double)kp.runpx_.y - cr.cy_) / cr.fy_, 1.0};
     const double nrm = std::sqrt(bv.x * bv.x + bv.y * bv.y + bv.z * bv.z);
     kp.rbv_ = Vec3{bv.x / nrm, bv.y / nrm, bv.z / nrm};
@@ -270,11 +331,9 @@ void Frame::updateKeypointStereo(int lmid, const Point2f &pt)
 }
 
 Point2f Frame::projCamToRightImageDist(const Vec3 &pt) const
-{   // src/frame.cpp:796-799 -> CameraCalibration::projectCamToImageDist (src/camera_calibration.cpp:254-264, Dcv_.empty())
+{   // src/frame.cpp:796-799 -> CameraCalibration::projectCamToImageDist (src/camera_calibration.cpp:254-282)
     const CameraCalibration &cr = *pcalib_rightcam_;
-    const Vec3 p = cr.Tc0ci_.inverse() * pt;
-    const double invz = 1. / p.z, x = p.x * invz, y = p.y * invz;
-    return Point2f{(float)(cr.fx_ * x + cr.cx_), (float)(cr.fy_ * y + cr.cy_)};
+    return cr.projectCamToImageDist(cr.Tc0ci_.inverse() * pt);
 }
 
 Point2f Frame::projWorldToRightImageDist(const Vec3 &wpt) const { return projCamToRightImageDist(projWorldToCam(wpt)); }

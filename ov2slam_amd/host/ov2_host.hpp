@@ -40,15 +40,23 @@ struct SE3 {
     static SE3 fromRt(const double R[9], const double t[3]);
 };
 
-struct CameraCalibration {   // pinhole part of src/camera_calibration.cpp that the path needs
+struct CameraCalibration {   // the part of src/camera_calibration.cpp that the path needs
+    enum Model { Pinhole, Fisheye };
     double fx_ = 1, fy_ = 1, cx_ = 0, cy_ = 0;
     int img_w_ = 0, img_h_ = 0;
     SE3 Tc0ci_;               // extrinsic: this camera in the left-camera frame (getExtrinsic(), T_left_right)
+    Model model_ = Pinhole;
+    std::vector<double> D_;   // Dcv_: empty = no distortion; Pinhole: k1 k2 p1 p2 [k3]; Fisheye: k1 k2 k3 k4
     Vec3 projectCamToImage(const Vec3 &pc) const
     {   // src/camera_calibration.cpp:243-252: invz first, then fx * x + cx
         const double invz = 1. / pc.z, x = pc.x * invz, y = pc.y * invz;
         return {fx_ * x + cx_, fy_ * y + cy_, pc.z};
     }
+    // :313-332 -> cv::undistortPoints(px, K, D, noArray(), K) (five fixed-point sweeps) / cv::fisheye::undistortPoints
+    // (Newton on theta, at most ten steps); OpenCV is not vendored by the reference: restated from its published algorithm
+    Point2f undistortImagePoint(const Point2f &pt) const;
+    // :254-282 -> cv::projectPoints with zero rvec / tvec (radial-tangential) / cv::fisheye::distortPoints
+    Point2f projectCamToImageDist(const Vec3 &pc) const;
 };
 
 struct Keypoint {   // include/frame.hpp:46-76

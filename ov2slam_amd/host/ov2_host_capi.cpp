@@ -182,6 +182,38 @@ int ov2h_project(void *p, int kfid, const double *xyz, int right, float *px)
     return 0;
 }
 
+// CameraCalibration::Dcv_ / model_ of the left (cam = 0) or right camera: model 0 = pinhole (k1 k2 p1 p2 [k3]), 1 = fisheye (k1..k4)
+int ov2h_set_distortion(void *p, int cam, int model, int n, const double *coeffs)
+{
+    HostMap *m = (HostMap *)p;
+    auto &c = cam ? m->cr : m->cl;
+    if (!c || n < 0 || n > 5) return -1;
+    c->model_ = model ? CameraCalibration::Fisheye : CameraCalibration::Pinhole;
+    c->D_.assign(coeffs, coeffs + n);
+    return 0;
+}
+
+// CameraCalibration::undistortImagePoint / projectCamToImageDist (test hooks)
+int ov2h_undistort(void *p, int cam, float x, float y, float *out)
+{
+    HostMap *m = (HostMap *)p;
+    const auto &c = cam ? m->cr : m->cl;
+    if (!c) return -1;
+    const Point2f q = c->undistortImagePoint(Point2f{x, y});
+    out[0] = q.x; out[1] = q.y;
+    return 0;
+}
+
+int ov2h_project_dist(void *p, int cam, const double *pc, float *out)
+{
+    HostMap *m = (HostMap *)p;
+    const auto &c = cam ? m->cr : m->cl;
+    if (!c) return -1;
+    const Point2f q = c->projectCamToImageDist(Vec3{pc[0], pc[1], pc[2]});
+    out[0] = q.x; out[1] = q.y;
+    return 0;
+}
+
 int ov2h_get_frl(void *p, int kfid, double *F9)
 {
     auto f = ((HostMap *)p)->map->getKeyframe(kfid);

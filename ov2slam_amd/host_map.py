@@ -28,6 +28,9 @@ def lib():
         L.ov2h_map_attach_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ov2h_local_ba_setup_dev.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_map_device_rows.argtypes = [C.c_void_p, ip, ip, ip]
+        L.ov2h_set_distortion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
+        L.ov2h_undistort.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.ov2h_project_dist.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_float)]
         L.ov2h_range_ba_setup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip]
         L.ov2h_full_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, C.POINTER(C.c_double), ip]
         L.ov2h_local_pose_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, dp, C.POINTER(C.c_double), ip]
@@ -135,6 +138,21 @@ class HostMap:
                                           max_obs or n_obs + 64)
         if rc != 0:
             raise RuntimeError(f"attachDevice failed (status {rc})")
+
+    def set_distortion(self, cam, model, coeffs):
+        """CameraCalibration::Dcv_ of the left (0) / right (1) camera: model 'pinhole' (k1 k2 p1 p2 [k3]) or 'fisheye' (k1..k4)"""
+        d = np.ascontiguousarray(coeffs, np.float64)
+        assert lib().ov2h_set_distortion(self.h, int(cam), 1 if model == "fisheye" else 0, len(d), _dp(d)) == 0
+
+    def undistort(self, cam, x, y):
+        out = (C.c_float * 2)()
+        assert lib().ov2h_undistort(self.h, int(cam), float(x), float(y), out) == 0
+        return np.array([out[0], out[1]], np.float32)
+
+    def project_dist(self, cam, pc):
+        out = (C.c_float * 2)()
+        assert lib().ov2h_project_dist(self.h, int(cam), _dp(np.ascontiguousarray(pc, np.float64)), out) == 0
+        return np.array([out[0], out[1]], np.float32)
 
     def device_rows(self):
         """(rows, capacity, compactions) of the device mirror's observation table"""

@@ -356,3 +356,50 @@ def test_full_pose_graph_through_the_host_mirror(ctx, oracle):
     assert ok and fc == pytest.approx(R.final_cost, rel=1e-8, abs=1e-16)
     assert np.abs(out - G.pose).max() < 1e-8
     assert np.array_equal(out[iskf != 0], Twc[iskf != 0])
+
+
+@pytest.mark.parametrize("model,D", [("pinhole", [-0.28, 0.074, 0.0002, 1.8e-5]), ("pinhole", [-0.3, 0.1, 0.001, -0.0005, -0.02]),
+                                     ("fisheye", [-0.01, 0.02, -0.005, 0.001])])
+def test_camera_distortion_models(model, D):
+    """CameraCalibration::undistortImagePoint / projectCamToImageDist (src/camera_calibration.cpp:254-332) = the OpenCV
+    radial-tangential and fisheye maps (restated; OpenCV is not vendored: parity unpinned).  Checked against numpy
+    restatements of the published formulas and by the round trip distort(undistort(px)) = px."""
+    P = synth_ba.make_window(4, 40, inv_depth=False, seed=1)
+    hm = host_map.HostMap(P)
+    hm.set_distortion(0, model, D)
+    fx, fy, cx, cy = P.calib_l
+    k = list(D) + [0.0] * (5 - len(D))
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        u, v = np.float32(rng.uniform(5, 747)), np.float32(rng.uniform(5, 475))
+        un = hm.undistort(0, u, v)
+        # numpy restatement
+        if model == "pinhole":
+            k1, k2, p1, p2, k3 = k
+            x0, y0 = (float(u) - cx) / fx, (float(v) - cy) / fy
+            x, y = x0, y0
+            for _i in range(5):
+                r2 = x * x + y * y
+                ic = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+                dx, dy = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+                x, y = (x0 - dx) * ic, (y0 - dy) * ic
+        else:
+            pw = np.array([(float(u) - cx) / fx, (float(v) - cy) / fy])
+            td = np.linalg.norm(pw)
+            th = td
+            for _i in range(10):
+                t2 = th * th
+                fix = (th * (1 + k[0] * t2 + k[1] * t2 ** 2 + k[2] * t2 ** 3 + k[3] * t2 ** 4) - td) / \
+                      (1 + 3 * k[0] * t2 + 5 * k[1] * t2 ** 2 + 7 * k[2] * t2 ** 3 + 9 * k[3] * t2 ** 4)
+                th -= fix
+                if abs(fix) < 1e-8:
+                    break
+            x, y = pw * (np.tan(th) / td if td > 1e-8 else 1.0)
+        assert np.allclose(un, [fx * x + cx, fy * y + cy], atol=2e-4)
+        # round trip through the forward model
+        back = hm.project_dist(0, np.array([(un[0] - cx) / fx, (un[1] - cy) / fy, 1.0]) * 2.5)
+        # five fixed-point sweeps (cv::undistortPoints' default) have not converged in the corners of a k1 = -0.28 lens
+        assert np.allclose(back, [u, v], atol=0.3 if model == "pinhole" else 2e-3)
+    # no coefficients: identity / plain pinhole
+    hm.set_distortion(0, "pinhole", [])
+    assert np.array_equal(hm.undistort(0, 100.25, 50.5), np.array([100.25, 50.5], np.float32))
