@@ -398,8 +398,18 @@ def test_camera_distortion_models(model, D):
         assert np.allclose(un, [fx * x + cx, fy * y + cy], atol=2e-4)
         # round trip through the forward model
         back = hm.project_dist(0, np.array([(un[0] - cx) / fx, (un[1] - cy) / fy, 1.0]) * 2.5)
-        # five fixed-point sweeps (cv::undistortPoints' default) have not converged in the corners of a k1 = -0.28 lens
-        assert np.allclose(back, [u, v], atol=0.3 if model == "pinhole" else 2e-3)
+        # five fixed-point sweeps (cv::undistortPoints' default) have not converged in the corners of a k1 = -0.3 lens: the
+        # round trip is exact to 0.02 px inside the central half of the image, and the forward map is checked on its own below
+        if model == "fisheye" or (abs(float(u) - cx) < 190 and abs(float(v) - cy) < 120):
+            assert np.allclose(back, [u, v], atol=2e-2 if model == "pinhole" else 2e-3)
+        xn, yn = (un[0] - cx) / fx, (un[1] - cy) / fy
+        if model == "pinhole":
+            k1, k2, p1, p2, k3 = k
+            xf, yf = float(np.float32(xn)), float(np.float32(yn))
+            r2 = xf * xf + yf * yf
+            cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+            want = [fx * (xf * cd + 2 * p1 * xf * yf + p2 * (r2 + 2 * xf * xf)) + cx, fy * (yf * cd + p1 * (r2 + 2 * yf * yf) + 2 * p2 * xf * yf) + cy]
+            assert np.allclose(back, want, atol=2e-4)
     # no coefficients: identity / plain pinhole
     hm.set_distortion(0, "pinhole", [])
     assert np.array_equal(hm.undistort(0, 100.25, 50.5), np.array([100.25, 50.5], np.float32))
