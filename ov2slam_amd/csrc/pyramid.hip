@@ -161,6 +161,121 @@ __global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__r
 }
 
 // ---------------------------------------------------------------------------------------------------
+// CLAHE LUT, one WAVE per tile (four tiles per workgroup, no workgroup barrier anywhere): the tile's ~2.6 k pixels are
+// 12 dwords per lane, the histogram lives in four interleaved LDS copies private to the wave, lane l owns bins
+// 4l .. 4l+3 for the clip / redistribute / scan steps (wave shuffles), and writes its four LUT bytes as one dword.
+// The 256-thread kernel above is a chain of barrier-separated phases with eight workgroups resident per CU (4.2 rounds
+// for 64 images x 135 tiles); here every tile of the batch is resident at once.  Same integers, same float product.
+#ifndef CLW_COPIES
+#define CLW_COPIES 4
+#endif
+__global__ __launch_bounds__(256) void clahe_lut_wave_kernel(const unsigned char *__restrict__ src, int w, int h,
+                                                             int sstride, size_t sbstride, int tiles_x, int tiles_y,
+                                                             int tw, int th, int clip_limit, float lut_scale,
+                                                             unsigned char *__restrict__ lut)
+{
+    __shared__ int hist_all[4][256 * CLW_COPIES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv, b = blockIdx.y;
+    if (tile >= tiles_x * tiles_y) return;           // wave-uniform
+    int *hist = hist_all[wv];
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const unsigned char *img = src + sbstride * b;
+#pragma unroll
+    for (int k = 0; k < 256 * CLW_COPIES / 64 / 4; ++k)
+        *reinterpret_cast<int4 *>(&hist[(k * 64 + lane) * 4]) = make_int4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    const int x0 = tx * tw, y0 = ty * th, copy = lane & (CLW_COPIES - 1);
+    if (x0 + tw <= w && y0 + th <= h) {
+        // rows as aligned dwords, pixels of the first / last dword outside [x0, x0 + tw) masked
+        const int xa = x0 & ~3, ndw = (x0 + tw - xa + 3) >> 2;
+        const int total = ndw * th;
+        const unsigned char *base = img + (size_t)y0 * sstride + xa;
+        constexpr int CH = 6;
+        for (int i0 = 0; i0 < total; i0 += 64 * CH) {
+            unsigned v[CH];
+            int xs[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = i0 + k * 64 + lane;
+                xs[k] = -1000;
+                v[k] = 0;
+                if (i < total) {
+                    const int yy = i / ndw, dd = i - yy * ndw;
+                    v[k] = *reinterpret_cast<const unsigned *>(base + (size_t)yy * sstride + 4 * dd);
+                    xs[k] = xa + 4 * dd - x0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(xs[k] + j) < (unsigned)tw) atomicAdd(&hist[((v[k] >> (8 * j)) & 255) * CLW_COPIES + copy], 1);
+        }
+    } else {
+        // tiles reaching into the REFLECT_101 extension (last tile row / column)
+        const int npx = tw * th;
+        for (int i0 = 0; i0 < npx; i0 += 64 * 8) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 64 + lane;
+                v[k] = -1;
+                if (i < npx) {
+                    const int yy = i / tw, xx = i - yy * tw;
+                    v[k] = img[(size_t)reflect101(y0 + yy, h) * sstride + reflect101(x0 + xx, w)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k] >= 0) atomicAdd(&hist[v[k] * CLW_COPIES + copy], 1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane l: bins 4l .. 4l+3
+    int hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int sum = 0;
+#pragma unroll
+        for (int q = 0; q < CLW_COPIES / 4; ++q) {
+            const int4 c = *reinterpret_cast<const int4 *>(&hist[(4 * lane + k) * CLW_COPIES + 4 * q]);
+            sum += (c.x + c.y) + (c.z + c.w);
+        }
+        hv[k] = sum;
+    }
+    if (clip_limit > 0) {
+        int over = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (hv[k] > clip_limit) { over += hv[k] - clip_limit; hv[k] = clip_limit; }
+        for (int o = 32; o > 0; o >>= 1) over += __shfl_xor(over, o);
+        const int clipped = over;
+        const int batch = clipped / 256, residual = clipped - batch * 256;
+        int step = residual ? 256 / residual : 1;
+        if (step < 1) step = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bin = 4 * lane + k;
+            hv[k] += batch;
+            if (residual != 0 && bin % step == 0 && bin / step < residual) hv[k] += 1;
+        }
+    }
+    // inclusive scan over the 256 bins
+    hv[1] += hv[0]; hv[2] += hv[1]; hv[3] += hv[2];
+    int tot = hv[3];
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(tot, o);
+        if (lane >= o) tot += t;
+    }
+    const int below = tot - hv[3];
+    unsigned outw = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) outw |= (unsigned)sat_u8_rn((float)(hv[k] + below) * lut_scale) << (8 * k);
+    reinterpret_cast<unsigned *>(lut + ((size_t)b * tiles_x * tiles_y + tile) * 256)[lane] = outw;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // level 0: CLAHE interpolation (use_clahe) or copy, 4 px per thread, into the padded plane + reflect border.
 // grid (ceil(w/256), h, batch), 64 threads.
 __global__ __launch_bounds__(64) void level0_kernel(const unsigned char *__restrict__ src, int w, int h, int sstride,
@@ -628,7 +743,7 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
         }
         inv_tw = 1.0f / (float)tw;
         inv_th = 1.0f / (float)th;
-        OV2_LAUNCH_ON(c, OV2_K_CLAHE_LUT, sp, clahe_lut_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, sp, im->base, im->w,
+        OV2_LAUNCH_ON(c, OV2_K_CLAHE_LUT, sp, clahe_lut_wave_kernel, dim3((tiles_x * tiles_y + 3) / 4, B), dim3(256), 0, sp, im->base, im->w,
                            im->h, im->stride, im->bstride, tiles_x, tiles_y, tw, th, clip_limit, lut_scale, buf->lut);
     }
     int ncx_max = 0, ncy_max = 0;
