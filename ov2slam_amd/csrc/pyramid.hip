@@ -11,7 +11,7 @@
 // padding = 0 (zeroed once when the pooled buffer is created; kernels never write it).
 //
 // Kernels (all HBM-streaming, byte/int16 work -- no MFMA on purpose):
-//   clahe_lut_kernel      one workgroup per (tile, image): LDS histogram -> clip/redistribute -> scan -> LUT
+//   clahe_lut_wave_kernel one wave per (tile, image): LDS histogram -> clip/redistribute -> scan -> LUT
 //   level0_kernel         CLAHE bilinear LUT interpolation (or plain copy) -> padded level-0 plane
 //   level_kernel          one pass over level l staged in LDS (64x16 tile + 2-px halo):
 //                         writes Scharr(l) as 16-byte stores and pyrDown(l) -> level l+1 (+ its reflect border)
@@ -52,120 +52,11 @@ __device__ __forceinline__ void store_reflections(unsigned char *plane, int istr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// CLAHE LUT: grid (tiles_x*tiles_y, batch), 256 threads.
-__global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char *__restrict__ src, int w, int h,
-                                                        int sstride, size_t sbstride, int tiles_x, int tiles_y,
-                                                        int tw, int th, int clip_limit, float lut_scale,
-                                                        unsigned char *__restrict__ lut)
-{
-    // 16 interleaved copies of the histogram (copy = lane & 15, fastest index): neighbouring pixels of a natural image
-    // share grey levels, and same-address LDS atomics serialise -- with the copies at most 4 lanes of a wave can meet
-    __shared__ int hist[256][16];
-    __shared__ int wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const unsigned char *img = src + sbstride * b;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hist[tid][k] = 0;
-    __syncthreads();
-    const int x0 = tx * tw, y0 = ty * th;
-    if (x0 + tw <= w && y0 + th <= h) {
-        // tile inside the image (all but the last tile row / column, which reach into the REFLECT_101 extension): walk the
-        // tile's rows as ALIGNED dwords -- one 4-byte load per 4 pixels instead of four byte gathers, no reflection, and
-        // a thread's loads are all issued before its atomics.  Pixels of the first / last dword outside [x0, x0 + tw)
-        // are masked.
-        const int xa = x0 & ~3, ndw = (x0 + tw - xa + 3) >> 2;      // dwords per tile row
-        const int total = ndw * th, copy = lane & 15;
-        const int q = 256 / ndw, r = 256 - q * ndw;
-        int yy = tid / ndw, dd = tid - yy * ndw;
-        const unsigned char *base = img + (size_t)y0 * sstride + xa;
-        constexpr int CH = 4;   // 4 dwords = 16 pixels per thread cover a 51 x 54 tile in one chunk
-        for (int i0 = tid; i0 < total; i0 += 256 * CH) {
-            unsigned v[CH];
-            int xs[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                xs[k] = -1000;
-                v[k] = 0;
-                if (yy < th) {
-                    v[k] = *reinterpret_cast<const unsigned *>(base + (size_t)yy * sstride + 4 * dd);
-                    xs[k] = xa + 4 * dd - x0;     // tile-relative x of the dword's first byte
-                }
-                yy += q; dd += r;
-                if (dd >= ndw) { dd -= ndw; ++yy; }
-            }
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((unsigned)(xs[k] + j) < (unsigned)tw) atomicAdd(&hist[(v[k] >> (8 * j)) & 255][copy], 1);
-        }
-    } else {
-        // pixel i = tid, tid + 256, ... of the tile in row-major order, kept as (yy, xx) without per-pixel divisions
-        const int q = 256 / tw, r = 256 - q * tw;
-        int yy = tid / tw, xx = tid - yy * tw;
-        const int copy = lane & 15;
-        // chunks of 8 pixels per thread: all loads of a chunk are issued before its atomics, so a thread pays the
-        // memory latency once per chunk instead of once per pixel (measured: the kernel was a chain of ~10 round trips)
-        while (yy < th) {
-            int v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[k] = -1;
-                if (yy < th) {
-                    const int y = reflect101(ty * th + yy, h), x = reflect101(tx * tw + xx, w);
-                    v[k] = img[(size_t)y * sstride + x];
-                }
-                yy += q; xx += r;
-                if (xx >= tw) { xx -= tw; ++yy; }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (v[k] >= 0) atomicAdd(&hist[v[k]][copy], 1);
-        }
-    }
-    __syncthreads();
-    int hv = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hv += hist[tid][(k + tid) & 15];   // rotated start: conflict-free banks
-    if (clip_limit > 0) {
-        int over = hv > clip_limit ? hv - clip_limit : 0;
-        if (over) hv = clip_limit;
-        // block sum of `over`
-        int s = over;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) wsum[wv] = s;
-        __syncthreads();
-        const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        const int batch = clipped / 256;
-        const int residual = clipped - batch * 256;
-        hv += batch;
-        if (residual != 0) {
-            int step = 256 / residual;
-            if (step < 1) step = 1;
-            if (tid % step == 0 && tid / step < residual) hv += 1;
-        }
-        __syncthreads();
-    }
-    // inclusive scan over the 256 bins: in-wave shuffle scan, then the totals of the lower waves
-    int v = hv;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    if (lane == 63) wsum[wv] = v;
-    __syncthreads();
-    for (int k = 0; k < wv; ++k) v += wsum[k];
-    lut[((size_t)b * tiles_x * tiles_y + tile) * 256 + tid] = sat_u8_rn((float)v * lut_scale);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // CLAHE LUT, one WAVE per tile (four tiles per workgroup, no workgroup barrier anywhere): the tile's ~2.6 k pixels are
 // 12 dwords per lane, the histogram lives in four interleaved LDS copies private to the wave, lane l owns bins
 // 4l .. 4l+3 for the clip / redistribute / scan steps (wave shuffles), and writes its four LUT bytes as one dword.
-// The 256-thread kernel above is a chain of barrier-separated phases with eight workgroups resident per CU (4.2 rounds
-// for 64 images x 135 tiles); here every tile of the batch is resident at once.  Same integers, same float product.
+// A workgroup per tile (the first version) is a chain of barrier-separated phases with eight workgroups resident per CU
+// (4.2 rounds for 64 images x 135 tiles); here every tile of the batch is resident at once.
 #ifndef CLW_COPIES
 #define CLW_COPIES 4
 #endif
