@@ -42,7 +42,9 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+    # gpurun merges every call's outputs into gpurun_out/: only the NEWEST file of a pass belongs to the current state
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]
+    ks = newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
     if ks:
         with open(ks[0]) as f, open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as g:
             r, w = csv.reader(f), csv.writer(g)
@@ -53,7 +55,7 @@ def main():
     pmc = {}
     for ctr, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = defaultdict(lambda: [0.0, 0])
-        for fn in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for fn in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             with open(fn) as f:
                 for row in csv.DictReader(f):
                     if row["Counter_Name"] != ctr:
