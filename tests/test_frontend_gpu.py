@@ -351,3 +351,30 @@ def test_klt_every_lane_mapping_matches_the_oracle(ctx, oracle, stream, lanes):
             assert np.array_equal(out.view(np.uint32), eout.view(np.uint32))
     finally:
         ctx.set_klt_lanes(0)
+
+
+@pytest.mark.parametrize("w,h", [(101, 67), (64, 40), (233, 121)])
+def test_klt_three_lane_path_on_small_odd_images(ctx, oracle, w, h):
+    """the three-lane kernels address the planes with clamped 48-byte region rows and 12-byte template rows: small and
+    odd geometries (rows shorter than a region, levels smaller than a window) against the oracle, keypoints everywhere
+    incl. outside the image"""
+    rng = np.random.default_rng(w)
+    tex = synth.base_texture(h + 40, w + 40, seed=w)
+    I0 = np.ascontiguousarray(tex[10:10 + h, 10:10 + w]).astype(np.uint8)
+    I1 = np.ascontiguousarray(tex[11:11 + h, 12:12 + w]).astype(np.uint8)
+    g0, g1 = fe.preprocess_image(ctx, I0, use_clahe=False), fe.preprocess_image(ctx, I1, use_clahe=False)
+    o0, o1 = oracle.Pyramid(I0), oracle.Pyramid(I1)
+    n = 4500
+    kps = np.stack([rng.uniform(-6, w + 6, n), rng.uniform(-6, h + 6, n)], 1).astype(np.float32)
+    pri = kps + rng.normal(0, 1.5, kps.shape).astype(np.float32)
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    ctx.set_klt_lanes(3)
+    try:
+        for nl in (0, 2, 3):
+            out, st = trk.fbKltTracking(g0, g1, 9, nl, 30.0, 0.5, kps, pri)
+            eout, est, _ = oracle.fb_klt_tracking(o0, o1, kps, pri, 9, nl, 30.0, 0.5, 30, 0.01)
+            assert np.array_equal(st, est.astype(bool)), nl
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), nl
+        assert st.mean() > 0.3
+    finally:
+        ctx.set_klt_lanes(0)
