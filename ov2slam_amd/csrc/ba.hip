@@ -91,7 +91,7 @@ struct ba_dev {
     const int *row_ptr;            // n_e + 1
     const int *lm_of_e, *pose_of_f;
     // jacobian storage
-    double *res, *Je, *Jf;
+    double *res, *Je, *U;   // per row: residual, landmark block, pose block (2 x 6) of the robustified, UNSCALED jacobian
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
     double *rhs, *iete, *ieg;
@@ -183,7 +183,7 @@ __device__ inline void se3_plus(const double *x, const double *d, double *out)
 // one residual block: r, local jacobians, chi2, depth sign  (src/ceres_parametrization.cpp, 5 functors)
 
 struct row_eval {
-    double r[2], Jk[12], Ja[12], Jl[6], chi2;
+    double r[2], Jk[12], Jl[6], chi2;   // the anchor-pose block of an anchored row is -Jk: not formed
     bool depth_pos;
 };
 
@@ -247,7 +247,7 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
     double JR[6];
     for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c) JR[3 * r + c] = Jc[3 * r] * M[c] + Jc[3 * r + 1] * M[3 + c] + Jc[3 * r + 2] * M[6 + c];
-    for (int i = 0; i < 12; ++i) { o.Jk[i] = 0.0; o.Ja[i] = 0.0; }
+    for (int i = 0; i < 12; ++i) o.Jk[i] = 0.0;
     for (int i = 0; i < 6; ++i) o.Jl[i] = 0.0;
     if (type != OV2_BA_RANCH_INV) {
         for (int r = 0; r < 2; ++r) {
@@ -255,10 +255,6 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
             const double h0 = b * wpt[2] - c * wpt[1], h1 = c * wpt[0] - a * wpt[2], h2 = a * wpt[1] - b * wpt[0];
             o.Jk[6 * r + 0] = -inv_sigma * a; o.Jk[6 * r + 1] = -inv_sigma * b; o.Jk[6 * r + 2] = -inv_sigma * c;
             o.Jk[6 * r + 3] = inv_sigma * h0; o.Jk[6 * r + 4] = inv_sigma * h1; o.Jk[6 * r + 5] = inv_sigma * h2;
-            if (inv) {
-                o.Ja[6 * r + 0] = inv_sigma * a; o.Ja[6 * r + 1] = inv_sigma * b; o.Ja[6 * r + 2] = inv_sigma * c;
-                o.Ja[6 * r + 3] = -inv_sigma * h0; o.Ja[6 * r + 4] = -inv_sigma * h1; o.Ja[6 * r + 5] = -inv_sigma * h2;
-            }
         }
     }
     if (inv) {
@@ -325,19 +321,18 @@ __device__ __forceinline__ int win_of_vblock(const int *__restrict__ vb_start, i
 // which windows a launch works for
 enum { EV_ZERO = 0,   // iteration zero: every window of the program
        EV_CAND = 1,   // candidate evaluation: windows whose round produced a valid step
-       EV_ACC = 2,    // jacobian at the new x: windows whose step was accepted
-       EV_ZERO_SCALED = 3 };  // iteration zero, second pass: the same jacobian with the Jacobi scaling applied
+       EV_ACC = 2 };  // jacobian at the new x: windows whose step was accepted
 
 __device__ __forceinline__ bool win_runs(const ba_win &W, int mode)
 {
-    return (mode == EV_ZERO || mode == EV_ZERO_SCALED) ? !W.skip : (mode == EV_CAND ? (W.active && W.valid) : W.accepted != 0);
+    return mode == EV_ZERO ? !W.skip : (mode == EV_CAND ? (W.active && W.valid) : W.accepted != 0);
 }
 
 // workgroup b covers 256 rows of ONE window (virtual blocks: a window with r rows owns ceil(r / 256) of them), so the
 // cost partial part[b] belongs to one window and a window's partials are summed in the order a lone solve would use
 template <bool JAC, int E>
 __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
-                                                      const double *__restrict__ lms, int mode, double huber_a, int jacobi,
+                                                      const double *__restrict__ lms, int mode, double huber_a,
                                                       double *__restrict__ part)
 {
     BA_WAVE_PRIO();
@@ -350,7 +345,6 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
     if (!win_runs(W, mode)) return;   // workgroup-uniform
     const int row = W.row0 + ((int)blockIdx.x - W.vb0) * 256 + (int)threadIdx.x;
     const int use_loss = W.use_loss;
-    const int apply_scale = (mode == EV_ACC || mode == EV_ZERO_SCALED) ? jacobi : 0;   // iteration zero: the scale comes from its first pass
     double c = 0.0;
     if (row < W.row1) {
         row_eval ev;
@@ -372,16 +366,13 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
             constexpr int e = E;   // compile-time: the Jl accesses below must not become scratch-backed dynamic indexing
             if (use_loss) {
                 if (asn == 0.0) {
-                    for (int i = 0; i < 12; ++i) { ev.Jk[i] *= sqrt_rho1; ev.Ja[i] *= sqrt_rho1; }
+                    for (int i = 0; i < 12; ++i) ev.Jk[i] *= sqrt_rho1;
                     for (int i = 0; i < 2 * e; ++i) ev.Jl[i] *= sqrt_rho1;
                 } else {
                     for (int cc = 0; cc < 6; ++cc) {
-                        double rtj = ev.Jk[cc] * ev.r[0] + ev.Jk[6 + cc] * ev.r[1];
+                        const double rtj = ev.Jk[cc] * ev.r[0] + ev.Jk[6 + cc] * ev.r[1];
                         ev.Jk[cc] = sqrt_rho1 * (ev.Jk[cc] - asn * ev.r[0] * rtj);
                         ev.Jk[6 + cc] = sqrt_rho1 * (ev.Jk[6 + cc] - asn * ev.r[1] * rtj);
-                        rtj = ev.Ja[cc] * ev.r[0] + ev.Ja[6 + cc] * ev.r[1];
-                        ev.Ja[cc] = sqrt_rho1 * (ev.Ja[cc] - asn * ev.r[0] * rtj);
-                        ev.Ja[6 + cc] = sqrt_rho1 * (ev.Ja[6 + cc] - asn * ev.r[1] * rtj);
                     }
                     for (int cc = 0; cc < e; ++cc) {
                         const double rtj = ev.Jl[cc] * ev.r[0] + ev.Jl[e + cc] * ev.r[1];
@@ -393,24 +384,14 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
             }
             d.res[2 * row] = ev.r[0];
             d.res[2 * row + 1] = ev.r[1];
-            const int eb = d.eb[row], fk = d.fk[row], fa = d.fa[row];
-            const int ne = d.n_e * e;
-            for (int cc = 0; cc < e; ++cc) {
-                const double s = apply_scale ? d.scale[eb * e + cc] : 1.0;
-                d.Je[(size_t)row * 2 * e + cc] = ev.Jl[cc] * s;
-                d.Je[(size_t)row * 2 * e + e + cc] = ev.Jl[e + cc] * s;
-            }
-            double out[24];
+            // Stored UNSCALED: the consumers apply the Jacobi scaling of the column as they read (the same product the
+            // scaled store made, so nothing changes numerically).  The anchor-pose block of an anchored inverse-depth row
+            // is exactly -Jk (ceres_parametrization.cpp: the two blocks differ by sign only) and zero for every other
+            // type, so ONE 2 x 6 block per row is kept: 96 bytes instead of 192.
+            for (int cc = 0; cc < 2 * e; ++cc) d.Je[(size_t)row * 2 * e + cc] = ev.Jl[cc];
+            double2 *U2 = reinterpret_cast<double2 *>(d.U + (size_t)row * 12);   // 96-byte rows: six 16-byte stores
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                const double sk = (apply_scale && fk >= 0) ? d.scale[ne + fk * 6 + cc] : 1.0;
-                const double sa = (apply_scale && fa >= 0) ? d.scale[ne + fa * 6 + cc] : 1.0;
-                out[cc] = ev.Jk[cc] * sk; out[6 + cc] = ev.Jk[6 + cc] * sk;
-                out[12 + cc] = ev.Ja[cc] * sa; out[18 + cc] = ev.Ja[6 + cc] * sa;
-            }
-            double2 *Jf2 = reinterpret_cast<double2 *>(d.Jf + (size_t)row * 24);   // 192-byte rows: twelve 16-byte stores
-#pragma unroll
-            for (int cc = 0; cc < 12; ++cc) Jf2[cc] = make_double2(out[2 * cc], out[2 * cc + 1]);
+            for (int cc = 0; cc < 6; ++cc) U2[cc] = make_double2(ev.Jk[2 * cc], ev.Jk[2 * cc + 1]);
         }
     }
     const double tot = block_sum_256(c, sh);
@@ -635,22 +616,6 @@ __global__ void ba_make_scale_kernel(ba_dev d)
     if (i < d.nc) d.scale[i] = 1.0 / (1.0 + sqrt(d.sqn[i]));
 }
 
-__global__ __launch_bounds__(256) void ba_scale_rows_kernel(ba_dev d)
-{
-    BA_WAVE_PRIO();
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= d.n_rows) return;
-    const int e = d.e, ne = d.n_e * e, eb = d.eb[row], fk = d.fk[row], fa = d.fa[row];
-    for (int c = 0; c < e; ++c) {
-        const double s = d.scale[eb * e + c];
-        d.Je[(size_t)row * 2 * e + c] *= s;
-        d.Je[(size_t)row * 2 * e + e + c] *= s;
-    }
-    double *Jf = d.Jf + (size_t)row * 24;
-    if (fk >= 0) for (int c = 0; c < 6; ++c) { const double s = d.scale[ne + fk * 6 + c]; Jf[c] *= s; Jf[6 + c] *= s; }
-    if (fa >= 0) for (int c = 0; c < 6; ++c) { const double s = d.scale[ne + fa * 6 + c]; Jf[12 + c] *= s; Jf[18 + c] *= s; }
-}
-
 // LevenbergMarquardtStrategy::ComputeStep :76-89, per window (blockIdx.y)
 // LM diagonal of the window's columns (refreshed from the column norms after an accepted step) and, in the same launch,
 // S_w = diag(D_f^2), rhs_w = 0.  The S part recomputes the few D_f it needs instead of reading what other threads of
@@ -747,13 +712,17 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
     const bool live = l < d.n_e && win_runs(d.W[d.win_of_e[l]], mode);
     const int e = d.e;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
-    double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
+    double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
+    if (live) for (int c = 0; c < e; ++c) sc[c] = d.scale[l * e + c];
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
             const double *Je = d.Je + (size_t)r * 2 * e;
             const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
-            for (int c = 0; c < e; ++c) { se[c] += Je[c] * Je[c] + Je[e + c] * Je[e + c]; ge[c] += Je[c] * b0 + Je[e + c] * b1; }
+            for (int c = 0; c < e; ++c) {
+                const double j0 = Je[c] * sc[c], j1 = Je[e + c] * sc[c];
+                se[c] += j0 * j0 + j1 * j1; ge[c] += j0 * b0 + j1 * b1;
+            }
         }
     }
     for (int c = 0; c < e; ++c) { se[c] = row_sum(se[c]); ge[c] = row_sum(ge[c]); }
@@ -778,14 +747,22 @@ __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int
     __shared__ double sh[4][27];
     const int f = blockIdx.x, tid = threadIdx.x;
     if (!win_runs(d.W[d.win_of_f[f]], mode)) return;
-    double acc[27];
+    double acc[27], sf[6];
 #pragma unroll
     for (int c = 0; c < 27; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sf[c] = d.scale[d.n_e * d.e + f * 6 + c];
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
         const int ent = pose_ent[k], r = ent >> 1;
         double J[12], bb[2];
-        load_d2<12>(d.Jf + (size_t)r * 24 + (ent & 1) * 12, J);
+        load_d2<12>(d.U + (size_t)r * 12, J);
         load_d2<2>(d.res + 2 * (size_t)r, bb);
+        // the pose's block of this row, Jacobi-scaled; as the row's anchor pose (entry bit 0) the block is -U
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            J[c] *= sf[c]; J[6 + c] *= sf[c];
+            if (ent & 1) { J[c] = -J[c]; J[6 + c] = -J[6 + c]; }
+        }
         const double b0 = bb[0], b1 = bb[1];
 #pragma unroll
         for (int t = 0; t < 21; ++t) acc[t] += J[c_tri_i[t]] * J[c_tri_j[t]] + J[6 + c_tri_i[t]] * J[6 + c_tri_j[t]];
@@ -822,17 +799,20 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
     const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
-    double acc[E];
-    for (int i = 0; i < E; ++i) acc[i] = 0.0;
+    const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
+    double acc[E], se[E];
+    for (int i = 0; i < E; ++i) { acc[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+            const double *Je = d.Je + (size_t)r * 2 * E;
+            double Uu[12];
+            load_d2<12>(d.U + (size_t)r * 12, Uu);
             double sj0 = d.res[2 * r], sj1 = d.res[2 * r + 1];
             const int fk = d.fk[r], fa = d.fa[r];
-            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; sj0 -= Jf[c] * z; sj1 -= Jf[6 + c] * z; }
-            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; sj0 -= Jf[12 + c] * z; sj1 -= Jf[18 + c] * z; }
-            for (int i = 0; i < E; ++i) acc[i] += Je[i] * sj0 + Je[E + i] * sj1;
+            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; sj0 -= (Uu[c] * sk) * z; sj1 -= (Uu[6 + c] * sk) * z; }
+            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c], sa = sf[fa * 6 + c]; sj0 += (Uu[c] * sa) * z; sj1 += (Uu[6 + c] * sa) * z; }
+            for (int i = 0; i < E; ++i) acc[i] += (Je[i] * se[i]) * sj0 + (Je[E + i] * se[i]) * sj1;
         }
     }
     double y[E];
@@ -846,12 +826,14 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+            const double *Je = d.Je + (size_t)r * 2 * E;
+            double Uu[12];
+            load_d2<12>(d.U + (size_t)r * 12, Uu);
             double m0 = 0.0, m1 = 0.0;
-            for (int i = 0; i < E; ++i) { m0 -= Je[i] * y[i]; m1 -= Je[E + i] * y[i]; }
+            for (int i = 0; i < E; ++i) { m0 -= (Je[i] * se[i]) * y[i]; m1 -= (Je[E + i] * se[i]) * y[i]; }
             const int fk = d.fk[r], fa = d.fa[r];
-            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c]; m0 -= Jf[c] * z; m1 -= Jf[6 + c] * z; }
-            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c]; m0 -= Jf[12 + c] * z; m1 -= Jf[18 + c] * z; }
+            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; m0 -= (Uu[c] * sk) * z; m1 -= (Uu[6 + c] * sk) * z; }
+            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c], sa = sf[fa * 6 + c]; m0 += (Uu[c] * sa) * z; m1 += (Uu[6 + c] * sa) * z; }
             mc += m0 * (d.res[2 * r] + m0 / 2.0) + m1 * (d.res[2 * r + 1] + m1 / 2.0);
         }
     }
@@ -1541,9 +1523,9 @@ struct ba_cells {
     const int *cell_row;      // first row of its run, -1 = anchor cell (always the last cell of its landmark)
     const int *cell_lm;       // landmark block of the cell
     const int *cell_rank;     // position of the cell in the pose-major order (cells of a pose are contiguous there)
-    // per cell, stored at its pose-major position: W = F'E (6E), W (E'E + D)^-1 (6E), W (E'E + D)^-1 E'b (6) and, for the
-    // observing cells of a landmark that has an anchor cell, F'Fa (36)
-    double *Wm, *Wie, *Wg, *FFa;
+    // per cell, stored at its pose-major position: W = F'E (6E), W (E'E + D)^-1 (6E), W (E'E + D)^-1 E'b (6)
+    double *Wm, *Wie, *Wg;
+    const int2 *qrow;         // pose-major position of an observing cell -> (first row, rows) of its run in the sorted rows
 };
 
 __global__ __launch_bounds__(256) void bs_count_kernel(ba_dev d, int *__restrict__ ncell, int *__restrict__ npair)
@@ -1631,6 +1613,22 @@ __global__ __launch_bounds__(256) void bs_rank_kernel(const int *__restrict__ pc
     if (j < n) cell_rank[pcell_ent[j]] = j;
 }
 
+// observing cell -> its run of rows, stored at the cell's pose-major position (what the gather walks to form F'Fa)
+__global__ __launch_bounds__(256) void bs_qrow_kernel(ba_dev d, const int *__restrict__ cell_f, const int *__restrict__ cell_row,
+                                                      const int *__restrict__ cell_lm, const int *__restrict__ cell_rank, int n,
+                                                      int2 *__restrict__ qrow)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int r0 = cell_row[c];
+    int cnt = 0;
+    if (r0 >= 0) {
+        const int r1 = d.row_ptr[cell_lm[c] + 1], fk = cell_f[c];
+        while (r0 + cnt < r1 && d.fk[r0 + cnt] == fk) ++cnt;
+    }
+    qrow[cell_rank[c]] = make_int2(r0, cnt);
+}
+
 // pair entries: cell ids -> pose-major positions, bit 31 = "this cell is the landmark's anchor cell"
 __global__ __launch_bounds__(256) void bs_pent_kernel(int *__restrict__ pent, size_t n2, const int *__restrict__ cell_rank,
                                                       const int *__restrict__ cell_row)
@@ -1663,13 +1661,16 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const int l = blockIdx.x * 16 + grp;
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
-    double ete[E * E], g[E];
+    const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
+    double ete[E * E], g[E], se[E];
     for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
-    for (int i = 0; i < E; ++i) g[i] = 0.0;
+    for (int i = 0; i < E; ++i) { g[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E;
+            double Je[2 * E];
+            load_d2<2 * E>(d.Je + (size_t)r * 2 * E, Je);
+            for (int i = 0; i < E; ++i) { Je[i] *= se[i]; Je[E + i] *= se[i]; }
             const double b0 = d.res[2 * r], b1 = d.res[2 * r + 1];
             for (int i = 0; i < E; ++i) {
                 for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
@@ -1696,9 +1697,6 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const int c0 = C.cell_ptr[l], nc = C.cell_ptr[l + 1] - c0;
     const bool has_anchor = nc > 0 && C.cell_row[c0 + nc - 1] < 0;
     const int nobs = has_anchor ? nc - 1 : nc;
-    // F'Fa only changes with the jacobian: recomputed in the first round after an evaluation (the round that also
-    // refreshes the LM diagonal), reused by the rounds that follow a rejected step
-    const bool do_ffa = has_anchor && d.W[d.win_of_e[l]].refresh_diag != 0;
     // writes W, W ie, W ieg of one cell at its pose-major position
     auto store_cell = [&](int cell, const double *Wk) {
         const size_t q = (size_t)C.cell_rank[cell];
@@ -1722,47 +1720,45 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
 #pragma unroll
         for (int i = 0; i < 6; ++i) C.Wg[q * 6 + i] = wg[i];
     };
-    // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once
+    // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once.  (F'Fa, the coupling of
+    // an observing pose with the landmark's anchor pose, is not materialised: the gather forms it from the same rows.)
     for (int c = sub; c < nobs; c += 16) {
         const int fk = C.cell_f[c0 + c];
-        double Wk[6 * E], ffa[36];
+        double Wk[6 * E], sk[6];
 #pragma unroll
         for (int i = 0; i < 6 * E; ++i) Wk[i] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) ffa[i] = 0.0;
+        for (int i = 0; i < 6; ++i) sk[i] = sf[fk * 6 + i];
         for (int r2 = C.cell_row[c0 + c]; r2 < r1 && d.fk[r2] == fk; ++r2) {
             double J2[12], Je2[2 * E];
-            load_d2<12>(d.Jf + (size_t)r2 * 24, J2);
+            load_d2<12>(d.U + (size_t)r2 * 12, J2);
             load_d2<2 * E>(d.Je + (size_t)r2 * 2 * E, Je2);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { J2[i] *= sk[i]; J2[6 + i] *= sk[i]; }
+#pragma unroll
+            for (int k = 0; k < E; ++k) { Je2[k] *= se[k]; Je2[E + k] *= se[k]; }
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int k = 0; k < E; ++k) Wk[i * E + k] += J2[i] * Je2[k] + J2[6 + i] * Je2[E + k];
-            if (do_ffa && d.fa[r2] >= 0) {
-                double Ja[12];
-                load_d2<12>(d.Jf + (size_t)r2 * 24 + 12, Ja);
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) ffa[i * 6 + j] += J2[i] * Ja[j] + J2[6 + i] * Ja[6 + j];
-            }
         }
         store_cell(c0 + c, Wk);
-        if (do_ffa) {
-            const size_t q = (size_t)C.cell_rank[c0 + c];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) C.FFa[q * 36 + i] = ffa[i];
-        }
     }
-    if (has_anchor) {   // W of the anchor cell: summed over all rows by the group
-        double Wa[6 * E];
+    if (has_anchor) {   // W of the anchor cell: summed over all rows by the group (anchor block of a row = -U)
+        const int fa = C.cell_f[c0 + nc - 1];
+        double Wa[6 * E], sa[6];
         for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
+        for (int i = 0; i < 6; ++i) sa[i] = sf[fa * 6 + i];
         for (int base = r0; base < r1; base += 16) {
             const int r = base + sub;
             if (r < r1 && d.fa[r] >= 0) {
-                const double *Je = d.Je + (size_t)r * 2 * E, *Jf = d.Jf + (size_t)r * 24;
+                double Ja[12], Je[2 * E];
+                load_d2<12>(d.U + (size_t)r * 12, Ja);
+                load_d2<2 * E>(d.Je + (size_t)r * 2 * E, Je);
+                for (int i = 0; i < 6; ++i) { Ja[i] = -(Ja[i] * sa[i]); Ja[6 + i] = -(Ja[6 + i] * sa[i]); }
+                for (int k = 0; k < E; ++k) { Je[k] *= se[k]; Je[E + k] *= se[k]; }
                 for (int i = 0; i < 6; ++i)
-                    for (int k = 0; k < E; ++k) Wa[i * E + k] += Jf[12 + i] * Je[k] + Jf[18 + i] * Je[E + k];
+                    for (int k = 0; k < E; ++k) Wa[i * E + k] += Ja[i] * Je[k] + Ja[6 + i] * Je[E + k];
             }
         }
         for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
@@ -1837,7 +1833,10 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
 #pragma unroll
     for (int t = 0; t < 36; ++t) acc[t] = 0.0;
     const int s0 = seg_start[pidx], s1 = seg_start[pidx + 1];
-    double mine_ffa = 0.0;   // element `lane` of the block (i = lane % 6 of hi, j = lane / 6 of lo), anchor terms only
+    const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;
+    double s_hi[6], s_lo[6];   // Jacobi scales of the two poses' columns (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s_hi[i] = sf[hi * 6 + i]; s_lo[i] = sf[lo * 6 + i]; }
     for (int q0 = s0; q0 < s1; q0 += 64) {
         const int q = q0 + lane;
         const bool in = q < s1;
@@ -1860,27 +1859,28 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
                     for (int cc = 0; cc < E; ++cc) w += T[i * E + cc] * Wl[j * E + cc];
                     acc[i + 6 * j] -= w;
                 }
-        }
-        // entries in which one of the two cells is the landmark's anchor cell add F'Fa (36 doubles of the observing cell's
-        // record): walked one entry at a time, lane t < 36 fetching element t -- one coalesced 288-byte read per entry
-        // instead of 36 scattered loads per lane (which made this kernel 3x slower)
-        unsigned long long am = (dbg & 4) ? 0ull : __ballot(in && (eh < 0 || el < 0));
-        const int li = lane % 6, lj = lane / 6;
-        while (am) {   // four entries per trip: their loads are in flight together, the adds keep the entry order
-            double v[4];
+            // an entry in which one of the two cells is the landmark's anchor cell adds F'Fa = sum over the observing cell's
+            // rows of (its pose block)' (the anchor's block); the anchor block of a row is -U, so whichever of hi / lo
+            // observes, element (i of hi, j of lo) is -((U s_hi)_i (U s_lo)_j) summed over the two residual components.
+            // Formed here from the one or two 96-byte rows of the run, lane-parallel like the rest of the entry (nothing
+            // materialised per cell: the 288-byte F'Fa records were the largest store of the whole Schur complement).
+            if (!(dbg & 4) && (eh < 0 || el < 0)) {
+                const int2 rr = C.qrow[el < 0 ? qh : ql];
+                const double *Ur = d.U + (size_t)rr.x * 12;
+                for (int k = 0; k < rr.y; ++k, Ur += 12) {
+                    double Uu[12], H[12], L[12];
+                    load_d2<12>(Ur, Uu);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = 0.0;
-                if (am) {
-                    const int b = __builtin_ctzll(am);
-                    am &= am - 1;
-                    const int ehb = __builtin_amdgcn_readlane(eh, b), elb = __builtin_amdgcn_readlane(el, b);
-                    // lo cell is the anchor: hi observes, F'Fa stored (i of hi, j of anchor) row-major; else transposed
-                    if (lane < 36)
-                        v[u] = (elb < 0) ? C.FFa[(size_t)(ehb & 0x7fffffff) * 36 + li * 6 + lj] : C.FFa[(size_t)(elb & 0x7fffffff) * 36 + lj * 6 + li];
+                    for (int i = 0; i < 6; ++i) {
+                        H[i] = Uu[i] * s_hi[i]; H[6 + i] = Uu[6 + i] * s_hi[i];
+                        L[i] = Uu[i] * s_lo[i]; L[6 + i] = Uu[6 + i] * s_lo[i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) acc[i + 6 * j] -= H[i] * L[j] + H[6 + i] * L[6 + j];
                 }
             }
-            mine_ffa += v[0]; mine_ffa += v[1]; mine_ffa += v[2]; mine_ffa += v[3];
         }
     }
     // the 36 totals are wave-uniform: lane t keeps total t, then 36 lanes write the block with one store.  An
@@ -1897,7 +1897,6 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
         if (lane == t) mine = v;
     }
     }
-    mine += mine_ffa;
     if (lane < 36) {
         const int i = lane % 6, j = lane / 6;
         double *dst = d.Spool + Wn.S_off + (size_t)((lo - Wn.f0) * 6 + j) * Wn.m + (hi - Wn.f0) * 6 + i;
@@ -2212,7 +2211,7 @@ ov2_status build_program(ba_solver &S)
     const int nr = d.n_rows;
 #undef AL
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
-    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(Jf, 24 * (size_t)nr);
+    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(U, 12 * (size_t)nr);
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
     AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e); AL(FFp, (size_t)d.n_f * 21);
     AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);
@@ -2258,7 +2257,7 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
         size_t tbytes = std::max(std::max(t1, t2), t4);
         {   // the structure lives in its own block, sized now that the counts are known and kept across solves
-            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + (size_t)(12 * e + 42) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
+            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + 8 + (size_t)(12 * e + 6) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
                                  (size_t)pair_cap * 12 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
             if (need2 > c->ba_arena2_cap) {
                 OV2_HIP(c, hipStreamSynchronize(st));
@@ -2272,7 +2271,9 @@ ov2_status build_program(ba_solver &S)
         }
         size_t off2 = 0;
         AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot); AL3(cell_rank, C_tot);
-        AL3(Cc.Wm, (size_t)C_tot * 6 * e); AL3(Cc.Wie, (size_t)C_tot * 6 * e); AL3(Cc.Wg, (size_t)C_tot * 6); AL3(Cc.FFa, (size_t)C_tot * 36);
+        AL3(Cc.Wm, (size_t)C_tot * 6 * e); AL3(Cc.Wie, (size_t)C_tot * 6 * e); AL3(Cc.Wg, (size_t)C_tot * 6);
+        int2 *qrow;
+        AL3(qrow, C_tot);
         AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
         AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(pent, 2 * (size_t)P_tot); AL3(pent_sorted, P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
         AL3(ukey, pair_cap + 1); AL3(seg_start, pair_cap + 2);
@@ -2280,13 +2281,14 @@ ov2_status build_program(ba_solver &S)
         AL3(tsort, tbytes + 256);
 #undef AL3
 #undef AL2
-        Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm; Cc.cell_rank = cell_rank;
+        Cc.cell_ptr = cell_ptr; Cc.cell_f = cell_f; Cc.cell_row = cell_row; Cc.cell_lm = cell_lm; Cc.cell_rank = cell_rank; Cc.qrow = qrow;
         BA_LAUNCH(S, K_MISC, bs_cells_kernel, dim3((d.n_e + 255) / 256), dim3(256), 0, st, d, cell_ptr, pair_off, cell_f, cell_row,
                   cell_lm, pkey, pent, ckey, fb, pb);
         if (C_tot > 0) {
             OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tsort, tbytes, ckey, ckey2, C_tot, 32, 32 + fb, st));
             BA_LAUNCH(S, K_MISC, bs_posecells_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, ckey2, C_tot, d.n_f, pcell_ptr, pcell_ent);
             BA_LAUNCH(S, K_MISC, bs_rank_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, pcell_ent, C_tot, cell_rank);
+            BA_LAUNCH(S, K_MISC, bs_qrow_kernel, dim3((C_tot + 255) / 256), dim3(256), 0, st, d, cell_f, cell_row, cell_lm, cell_rank, C_tot, qrow);
         }
         if (P_tot > 0) {
             BA_LAUNCH(S, K_MISC, bs_pent_kernel, dim3((unsigned)((2 * (size_t)P_tot + 255) / 256)), dim3(256), 0, st, pent, 2 * (size_t)P_tot,
@@ -2356,11 +2358,11 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     auto eval = [&](bool jac, const double *xp, const double *xl, int mode) {
         double *pc = d.part + 3 * (size_t)(d.n_e + d.n_f);
         if (jac) {
-            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
-            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
         } else {
-            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
-            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, lo.jacobi, pc);
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
         }
     };
     auto colnorm = [&](int mode) {
@@ -2370,19 +2372,16 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     const int nb = d.n_e + d.n_f;
     double *part_step = d.part, *part_norm = d.part + nb, *part_model = d.part + 2 * (size_t)nb;
     double *part_cost = d.part + 3 * (size_t)nb;
-    // ---- IterationZero: EvaluateGradientAndJacobian at x
+    // ---- IterationZero: EvaluateGradientAndJacobian at x.  The rows hold the unscaled jacobian; the Jacobi scaling
+    // (trust_region_minimizer.cc:185-199: 1 / (1 + column norm) of the FIRST jacobian) is a vector the consumers apply.
+    BA_LAUNCH(S, K_SCALE, ba_fill_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d.scale, (size_t)d.nc, 1.0);
     eval(true, S.xp, S.xl, EV_ZERO);
     colnorm(EV_ZERO);
     if (lo.jacobi) {
         BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
-        // the scaled jacobian is written by a second evaluation (same products as scaling the stored rows, without reading
-        // them back: 1.0 ms instead of 1.66 ms at 8.2 M rows)
-        eval(true, S.xp, S.xl, EV_ZERO_SCALED);
-        // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): recompute the norms on
-        // it; its gradient is the scaled one, the tolerance test unscales it on the fly
+        // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): the norms again, now
+        // with the scale in place; the gradient is the scaled one, the tolerance test unscales it on the fly
         colnorm(EV_ZERO);
-    } else {
-        BA_LAUNCH(S, K_SCALE, ba_fill_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d.scale, (size_t)d.nc, 1.0);
     }
     BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm, part_model,
               1, o->initial_radius, 0);
