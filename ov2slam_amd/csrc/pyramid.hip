@@ -19,6 +19,8 @@
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int reflect101(int i, int n)
 {
     // one reflection is enough for |overshoot| < n (callers guarantee it)
@@ -77,34 +79,60 @@ __global__ __launch_bounds__(256) void clahe_lut_wave_kernel(const unsigned char
         *reinterpret_cast<int4 *>(&hist[(k * 64 + lane) * 4]) = make_int4(0, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
     const int x0 = tx * tw, y0 = ty * th, copy = lane & (CLW_COPIES - 1);
-    if (x0 + tw <= w && y0 + th <= h) {
-        // rows as aligned dwords, pixels of the first / last dword outside [x0, x0 + tw) masked
-        const int xa = x0 & ~3, ndw = (x0 + tw - xa + 3) >> 2;
-        const int total = ndw * th;
+    // Tiles of the last tile row / column reach into the REFLECT_101 extension (CLAHE_Impl::apply pads the image to a
+    // multiple of the tile grid): an extension pixel is the mirror image of an in-image pixel, so when all mirror sources
+    // lie inside this tile's own in-image part (every usual geometry) the tile is histogrammed from that part alone, the
+    // mirrored columns / rows counting twice (weights 1, 2, 4) -- the same dword loads as any other tile.
+    const int xe = min(x0 + tw, w), ye = min(y0 + th, h);
+    const int xm_lo = 2 * w - 1 - x0 - tw, ym_lo = 2 * h - 1 - y0 - th;   // first mirrored column / row (when there is an extension)
+    const bool ext_x = x0 + tw > w, ext_y = y0 + th > h;
+    if ((!ext_x || (x0 < w - 1 && xm_lo >= x0)) && (!ext_y || (y0 < h - 1 && ym_lo >= y0))) {
+        // rows as aligned dwords, pixels of the first / last dword outside [x0, xe) masked
+        const int xa = x0 & ~3, ndw = (xe - xa + 3) >> 2;
+        const int total = ndw * (ye - y0);
         const unsigned char *base = img + (size_t)y0 * sstride + xa;
         constexpr int CH = 6;
+        // the lane's index advances by 64 per load: (row, dword) tracked incrementally instead of divided out
+        const int a64 = 64 / ndw, r64 = 64 - a64 * ndw;
+        int yy = lane / ndw, dd = lane - yy * ndw;
         for (int i0 = 0; i0 < total; i0 += 64 * CH) {
             unsigned v[CH];
-            int xs[CH];
+            int xs[CH], ys[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int i = i0 + k * 64 + lane;
                 xs[k] = -1000;
+                ys[k] = 0;
                 v[k] = 0;
                 if (i < total) {
-                    const int yy = i / ndw, dd = i - yy * ndw;
-                    v[k] = *reinterpret_cast<const unsigned *>(base + (size_t)yy * sstride + 4 * dd);
+                    v[k] = *reinterpret_cast<const unsigned *>(base + (unsigned)(yy * sstride + 4 * dd));
                     xs[k] = xa + 4 * dd - x0;
+                    ys[k] = y0 + yy;
+                }
+                dd += r64; yy += a64;
+                if (dd >= ndw) { dd -= ndw; ++yy; }
+            }
+            if (!ext_x && !ext_y) {   // wave-uniform
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((unsigned)(xs[k] + j) < (unsigned)tw) atomicAdd(&hist[((v[k] >> (8 * j)) & 255) * CLW_COPIES + copy], 1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int wy = (ext_y && ys[k] >= ym_lo && ys[k] <= h - 2) ? 2 : 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = x0 + xs[k] + j;
+                        if (x >= x0 && x < xe)
+                            atomicAdd(&hist[((v[k] >> (8 * j)) & 255) * CLW_COPIES + copy], (ext_x && x >= xm_lo && x <= w - 2) ? 2 * wy : wy);
+                    }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((unsigned)(xs[k] + j) < (unsigned)tw) atomicAdd(&hist[((v[k] >> (8 * j)) & 255) * CLW_COPIES + copy], 1);
         }
     } else {
-        // tiles reaching into the REFLECT_101 extension (last tile row / column)
+        // exotic geometries (an extension wider than the in-image part of its tile): pixel by pixel through the reflection
         const int npx = tw * th;
         for (int i0 = 0; i0 < npx; i0 += 64 * 8) {
             int v[8];
@@ -501,6 +529,187 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(ov2_pyr_view pv, int l)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// level 0 (CLAHE path) AND the first pyrDown in one pass: the workgroup forms the CLAHE output of a 128 x 32 px tile
+// plus the 2-px ring the 5 x 5 binomial reaches into (36 rows x 36 dwords, columns x0-4 .. x0+139), keeps it in LDS,
+// writes the tile's own pixels to the level-0 plane (128-byte rows: whole lines) and then runs pyrdown_kernel's
+// arithmetic from LDS -- level 0 is not read back, one launch tail less.  Ring positions outside the image take the value
+// of their REFLECT_101 source pixel, which is what the padded plane holds there.
+// The interpolation makes ONE LDS read per pixel: for every interpolation cell the tile touches (the rectangle between
+// four neighbouring tile centres; <= 3 x 2 for EuRoC geometry) the four surrounding LUTs are interleaved into a
+// 256-entry table of byte quads, so a pixel value fetches all four taps with one dword read (v_cvt_f32_ubyte0..3 unpack
+// them); the per-pixel arithmetic is the expression of level0_kernel evaluated two taps at a time by the packed fp32
+// instructions (each product and sum rounded separately), so the bytes are the same.  The kernel is bound by vector
+// instruction issue, so tiles whose staged region lies inside the image and away from the plane's reflected border
+// (workgroup-uniform test) take a path without any reflect / clamp / edge-store logic, and every address is a uniform
+// base plus a 32-bit lane offset.
+template <bool INTERIOR>
+__device__ __forceinline__ void l0pd_stage(const unsigned char *__restrict__ sb, int w, int h, int sstride,
+                                           unsigned char *__restrict__ plane, int istride, int pad, float inv_tw, float inv_th,
+                                           int txA, int tyA, int ncellx, int ncelly, int x0, int y0,
+                                           unsigned int (*tile)[PD_DW], const unsigned int *quad)
+{
+    const int tid = threadIdx.x;
+    const int c = tid % PD_DW, g = tid / PD_DW;   // dword column of the staged region (252 threads busy), rows g, g + 7, ...
+    if (g >= 7) return;
+    const int x = x0 - 4 + 4 * c;
+    const bool col_live = INTERIOR || x < w + 4;          // columns further right feed no output
+    const bool col_in = INTERIOR || (x >= 0 && x + 3 < w);   // the four pixels are four consecutive source bytes
+    int xr[4];
+    unsigned cellx[4];   // byte offset of the pixel's cell column in the quad tables
+    float xa[4], xa1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xr[i] = INTERIOR ? x + i : min(max(reflect101(x + i, w), 0), w - 1);
+        const float txf = (float)xr[i] * inv_tw - 0.5f;
+        const float fl = floorf(txf);
+        xa[i] = txf - fl;
+        xa1[i] = 1.0f - xa[i];
+        cellx[i] = (unsigned)min(max((int)fl - txA, 0), ncellx - 1) * 1024u;
+    }
+    unsigned int raw[6];
+    {   // the source loads of all rows are in flight together
+        const int yfirst = y0 - 2 + g;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int r = g + 7 * k, y = yfirst + 7 * k;
+            raw[k] = 0;
+            if (INTERIOR) {
+                if (r < PD_ROWS) raw[k] = *reinterpret_cast<const unsigned int *>(sb + (unsigned)(y * sstride + x));
+            } else if (col_live && r < PD_ROWS && y < h + 2) {
+                const unsigned ro = (unsigned)(min(max(reflect101(y, h), 0), h - 1) * sstride);
+                if (col_in) raw[k] = *reinterpret_cast<const unsigned int *>(sb + (ro + (unsigned)x));
+                else
+                    for (int i = 0; i < 4; ++i) raw[k] |= (unsigned int)sb[ro + (unsigned)xr[i]] << (8 * i);
+            }
+        }
+    }
+    __syncthreads();   // quad tables complete
+    const bool own_col = c >= 1 && c <= PD_TW / 4 && (INTERIOR || x < w);
+    const unsigned char *qb = reinterpret_cast<const unsigned char *>(quad);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int r = g + 7 * k, y = y0 - 2 + r;
+        if (r >= PD_ROWS) break;
+        unsigned int packed = 0;
+        if (INTERIOR || (col_live && y < h + 2)) {
+            const int yr = INTERIOR ? y : min(max(reflect101(y, h), 0), h - 1);
+            const float tyf = (float)yr * inv_th - 0.5f;
+            const float fl = floorf(tyf);
+            const float ya = tyf - fl;
+            const v2f yw = {1.0f - ya, ya};
+            const unsigned celly = (unsigned)(min(max((int)fl - tyA, 0), ncelly - 1) * ncellx) * 1024u;
+            unsigned int rb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // ((tl xa1 + tr xa) ya1 + (bl xa1 + br xa) ya), every product and sum rounded on its own, two at a time
+                // (v_pk_mul_f32 / v_pk_add_f32); the result lies in [0, 255], so adding 2^23 leaves cvRound(res) in the
+                // low mantissa byte (round-to-nearest-even, like v_rndne)
+                const unsigned q = *reinterpret_cast<const unsigned int *>(qb + (celly + cellx[i] + 4u * ((raw[k] >> (8 * i)) & 255u)));
+                const v2f left = {(float)(q & 255u), (float)((q >> 16) & 255u)}, right = {(float)((q >> 8) & 255u), (float)(q >> 24)};
+                const v2f xl = {xa1[i], xa1[i]}, xr2 = {xa[i], xa[i]};
+                const v2f tb = (left * xl + right * xr2) * yw;
+                rb[i] = __float_as_uint((tb.x + tb.y) + 8388608.0f);
+            }
+            packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(rb[3], rb[2], 0x0c0c0400u),
+                                           __builtin_amdgcn_perm(rb[1], rb[0], 0x0c0c0400u), 0x05040100u);
+            // the tile's own pixels go to the level-0 plane
+            if (own_col && r >= 2 && r < PD_TH + 2 && (INTERIOR || y < h)) {
+                const unsigned po = (unsigned)((y + pad) * istride + OV2_LM + x);
+                if (INTERIOR) {
+                    *reinterpret_cast<unsigned int *>(plane + po) = packed;
+                } else {
+                    const int nvalid = min(4, w - x);
+                    if (nvalid == 4) *reinterpret_cast<unsigned int *>(plane + po) = packed;
+                    else for (int i = 0; i < nvalid; ++i) plane[po + i] = (unsigned char)(packed >> (8 * i));
+                    const bool yedge = (y <= pad) || (y >= h - 1 - pad);
+                    const bool xedge = (x <= pad) || (x + 3 >= w - 1 - pad);
+                    if (yedge || xedge)
+                        for (int i = 0; i < nvalid; ++i)
+                            store_reflections(plane, istride, pad, w, h, x + i, y, (unsigned char)(packed >> (8 * i)), false);
+                }
+            }
+        }
+        tile[r][c] = packed;
+    }
+}
+
+__global__ __launch_bounds__(256) void level0_clahe_pyrdown_kernel(const unsigned char *__restrict__ src, int w, int h,
+                                                                   int sstride, size_t sbstride,
+                                                                   const unsigned char *__restrict__ lut, int tiles_x,
+                                                                   int tiles_y, float inv_tw, float inv_th, ov2_pyr_view pv)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned int fl[];
+    unsigned int (*tile)[PD_DW] = reinterpret_cast<unsigned int (*)[PD_DW]>(fl);   // PD_ROWS x PD_DW
+    unsigned int *quad = fl + PD_ROWS * PD_DW;                                     // cells x 256 byte quads
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
+    const int pad = pv.pad;
+    const int xmin = max(x0 - 4, 0), xmax = min(x0 + PD_TW + 11, w - 1);
+    const int ymin = max(y0 - 2, 0), ymax = min(y0 + PD_TH + 1, h - 1);
+    const int txA = (int)floorf((float)xmin * inv_tw - 0.5f), txB = (int)floorf((float)xmax * inv_tw - 0.5f);
+    const int tyA = (int)floorf((float)ymin * inv_th - 0.5f), tyB = (int)floorf((float)ymax * inv_th - 0.5f);
+    const int ncellx = txB - txA + 1, ncelly = tyB - tyA + 1;
+    // ---- byte-quad tables of the cells: item = (cell, group of four values); value v -> (tl | tr << 8 | bl << 16 | br << 24)
+    const unsigned char *lb = lut + (size_t)b * tiles_x * tiles_y * 256;
+    for (int i = tid; i < ncellx * ncelly * 64; i += 256) {
+        const int cell = i >> 6, v4 = i & 63;
+        const int jy = cell / ncellx, jx = cell - jy * ncellx;
+        const int c1 = min(max(txA + jx, 0), tiles_x - 1), c2 = min(max(txA + jx + 1, 0), tiles_x - 1);
+        const int r1 = min(max(tyA + jy, 0), tiles_y - 1), r2 = min(max(tyA + jy + 1, 0), tiles_y - 1);
+        const unsigned A = reinterpret_cast<const unsigned int *>(lb + (unsigned)((r1 * tiles_x + c1) * 256))[v4];
+        const unsigned Bq = reinterpret_cast<const unsigned int *>(lb + (unsigned)((r1 * tiles_x + c2) * 256))[v4];
+        const unsigned Cq = reinterpret_cast<const unsigned int *>(lb + (unsigned)((r2 * tiles_x + c1) * 256))[v4];
+        const unsigned D = reinterpret_cast<const unsigned int *>(lb + (unsigned)((r2 * tiles_x + c2) * 256))[v4];
+        // 4 x 4 byte transpose: AB = (A0 B0 A1 B1 | A2 B2 A3 B3), CD alike, then the halves are paired
+        const unsigned ab_lo = __builtin_amdgcn_perm(Bq, A, 0x05010400u), ab_hi = __builtin_amdgcn_perm(Bq, A, 0x07030602u);
+        const unsigned cd_lo = __builtin_amdgcn_perm(D, Cq, 0x05010400u), cd_hi = __builtin_amdgcn_perm(D, Cq, 0x07030602u);
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); o.y = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+        o.z = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); o.w = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+        *reinterpret_cast<uint4 *>(quad + cell * 256 + 4 * v4) = o;
+    }
+    const ov2_level_desc L = pv.lv[0];
+    const unsigned char *sb = src + sbstride * b;
+    unsigned char *plane = pv.base + L.img_off + L.img_bstride * b;
+    // staged region inside the image, own pixels clear of the rows / columns whose reflections the padded plane holds
+    const bool interior = x0 - 4 >= 0 && x0 + PD_TW + 11 < w && y0 - 2 >= 0 && y0 + PD_TH + 1 < h &&
+                          x0 > pad && x0 + PD_TW - 1 < w - 1 - pad && y0 > pad && y0 + PD_TH - 1 < h - 1 - pad;
+    if (interior) l0pd_stage<true>(sb, w, h, sstride, plane, L.istride, pad, inv_tw, inv_th, txA, tyA, ncellx, ncelly, x0, y0, tile, quad);
+    else l0pd_stage<false>(sb, w, h, sstride, plane, L.istride, pad, inv_tw, inv_th, txA, tyA, ncellx, ncelly, x0, y0, tile, quad);
+    __syncthreads();
+    // ---- pyrDown of the staged tile (pyrdown_kernel's second half, l = 0)
+    const ov2_level_desc N = pv.lv[1];
+    const int gx = tid & 15, ly = tid >> 4;
+    const int xo = (x0 >> 1) + 4 * gx, yo = (y0 >> 1) + ly;
+    if (yo >= N.h || xo >= N.w) return;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(&tile[2 * ly + j][2 * gx]);
+        const unsigned d0 = __builtin_amdgcn_alignbyte(q.y, q.x, 2), d2 = __builtin_amdgcn_alignbyte(q.z, q.y, 2);
+        const unsigned wts = 0x04060401u;
+        int rr[4];
+        rr[0] = (int)__builtin_amdgcn_udot4(d0, wts, (q.y >> 16) & 255u, false);
+        rr[1] = (int)__builtin_amdgcn_udot4(q.y, wts, q.z & 255u, false);
+        rr[2] = (int)__builtin_amdgcn_udot4(d2, wts, (q.z >> 16) & 255u, false);
+        rr[3] = (int)__builtin_amdgcn_udot4(q.z, wts, q.w & 255u, false);
+        const int kj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] += kj * rr[o];
+    }
+    const unsigned outp = (unsigned)((acc[0] + 128) >> 8) | ((unsigned)((acc[1] + 128) >> 8) << 8) |
+                          ((unsigned)((acc[2] + 128) >> 8) << 16) | ((unsigned)((acc[3] + 128) >> 8) << 24);
+    unsigned char *nplane = pv.base + N.img_off + N.img_bstride * b;
+    const unsigned no = (unsigned)((yo + pad) * N.istride + OV2_LM + xo);
+    const int nv = min(4, N.w - xo);
+    if (nv == 4) *reinterpret_cast<unsigned int *>(nplane + no) = outp;
+    else for (int o = 0; o < nv; ++o) nplane[no + o] = (unsigned char)(outp >> (8 * o));
+    const bool edge = (xo <= pad) || (xo + 3 >= N.w - 1 - pad) || (yo <= pad) || (yo >= N.h - 1 - pad);
+    if (edge)
+        for (int o = 0; o < nv; ++o) store_reflections(nplane, N.istride, pad, N.w, N.h, xo + o, yo, (unsigned char)(outp >> (8 * o)), false);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 
 ov2_status acquire_buf(ov2_ctx *c, int w, int h, int pad, int max_level, int batch, ov2_pyr_buf **out)
@@ -646,16 +855,31 @@ extern "C" ov2_status ov2_pyramid_build_images(ov2_ctx *c, const ov2_images *im,
         ncy_max = (int)(64.0f / th) + 3;
         l0_lds = (size_t)ncx_max * ncy_max * 256;
     }
-    if (use_clahe && l0_lds <= 48 * 1024)
+    // fused level 0 + first pyrDown: LDS = the staged tile + one 1-KB quad table per interpolation cell it can touch
+    int first_down = 0;
+    size_t fused_lds = 0;
+    if (use_clahe && v.nlevels >= 2) {
+        const float tw = 1.0f / inv_tw, th = 1.0f / inv_th;
+        const int cells = ((int)((float)(PD_TW + 16) / tw) + 2) * ((int)((float)(PD_TH + 4) / th) + 2);
+        fused_lds = ((size_t)PD_ROWS * PD_DW + (size_t)cells * 256) * 4;
+    }
+    static const bool no_fused = getenv("OV2_PYR_NO_FUSED") != nullptr;   // experiments: the two-kernel path
+    if (use_clahe && v.nlevels >= 2 && fused_lds <= 64 * 1024 && im->w >= 8 && im->h >= 8 && !no_fused) {
+        OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_clahe_pyrdown_kernel, dim3((im->w + PD_TW - 1) / PD_TW, (im->h + PD_TH - 1) / PD_TH, B),
+                      dim3(256), fused_lds, sp, im->base, im->w, im->h, im->stride, im->bstride, buf->lut, tiles_x, tiles_y, inv_tw,
+                      inv_th, v);
+        first_down = 1;
+    } else if (use_clahe && l0_lds <= 48 * 1024)
         OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_clahe_tiled_kernel, dim3((im->w + 63) / 64, (im->h + 63) / 64, B), dim3(256), l0_lds,
                    sp, im->base, im->w, im->h, im->stride, im->bstride, buf->lut, tiles_x, tiles_y, inv_tw, inv_th,
                    ncx_max, v);
-    else
-    OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, sp, im->base, im->w,
-                       im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
+    else {
+        OV2_LAUNCH_ON(c, OV2_K_LEVEL0, sp, level0_kernel, dim3((im->w + 255) / 256, im->h, B), dim3(64), 0, sp, im->base, im->w,
+                      im->h, im->stride, im->bstride, use_clahe, buf->lut, tiles_x, tiles_y, inv_tw, inv_th, v);
+    }
     // pyrDown chain only: the gradient planes are written when a consumer asks for them (ov2_pyr_need_grad)
     { std::lock_guard<std::mutex> g(c->mu); buf->grad_built = false; }
-    for (int l = 0; l + 1 < v.nlevels; ++l) {
+    for (int l = first_down; l + 1 < v.nlevels; ++l) {
         const ov2_level_desc &L = v.lv[l];
         OV2_LAUNCH_ON(c, OV2_K_LEVEL, sp, pyrdown_kernel, dim3((L.w + PD_TW - 1) / PD_TW, (L.h + PD_TH - 1) / PD_TH, B), dim3(256), 0, sp,
                       v, l);

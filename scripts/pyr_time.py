@@ -8,12 +8,13 @@ from ov2slam_amd import frontend as fe, synth
 ctx = fe.Context(0)
 S = synth.StereoStream()
 img = S.left(0)
-for B in (1, 16, 64):
+Bs = [int(a) for a in sys.argv[1:]]   # with arguments: only those batch sizes, full pyramid only (profiling)
+for B in (Bs or (1, 16, 64)):
     ims = fe.Images(ctx, B, 752, 480)
     for b in range(B):
         ims.upload(b, img)
     prev = {}
-    for nl in (0, 1, 2, 3):
+    for nl in ((3,) if Bs else (0, 1, 2, 3)):
         for _ in range(3):
             fe.preprocess_images(ctx, ims, True, 3.0, 9, nl).release()
         ctx.synchronize()
