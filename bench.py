@@ -67,6 +67,9 @@ def parse():
                     help="HIP stream priority of the local-BA workers: high = a pending batch takes the device as soon as it has "
                          "work (the reference's Estimator thread never waits for the front-end), normal = equal sharing")
     ap.add_argument("--ba-batch", type=int, default=64, help="most windows one ov2_ba_solve_batch call of a worker takes")
+    ap.add_argument("--ba-host-windows", action="store_true",
+                    help="the local-BA windows cross PCIe on every solve (ov2_ba_solve_batch on host arrays) instead of being "
+                         "resident in HBM like every other input of the timed region (ov2_ba_solve_batch_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnp", action="store_true",
                     help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
@@ -243,12 +246,13 @@ class BaWorker:
     newest).  The loop is a NATIVE thread of libov2host.so (ov2slam_amd/host/ov2_host_capi.cpp): a Python thread here
     fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
-    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64, high_priority=True):
+    def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64, high_priority=True, device_resident=True):
         from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
         workers = max(1, min(workers, seqs))
         share = [seqs // workers + (1 if k < seqs % workers else 0) for k in range(workers)]
-        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k], max_batch=max_batch, high_priority=high_priority)
+        self.ws = [host_map.EstimatorWorker(device, self.P0, share[k], max_batch=max_batch, high_priority=high_priority,
+                                            device_resident=device_resident)
                    for k in range(workers)]
         for w in self.ws:
             w.submit_all()                        # warm-up (allocations, code objects); not counted
@@ -256,8 +260,9 @@ class BaWorker:
         self.busy_s = 0.0
         self.batches = 0
         self.mode = (f"{workers} native worker thread(s), each on its own {'high' if high_priority else 'normal'}-priority HIP stream, concurrent with the front-end; a "
-                     f"worker solves the windows of all its sequences that have a keyframe pending in ONE ov2_ba_solve_batch "
-                     f"call (<= {max_batch} windows; reference: one Estimator thread per SLAM instance, src/estimator.cpp:32-98); "
+                     f"worker solves the windows of all its sequences that have a keyframe pending in ONE "
+                     f"{'ov2_ba_solve_batch_dev call on windows resident in HBM' if device_resident else 'ov2_ba_solve_batch call on host windows (PCIe-inclusive)'} "
+                     f"(<= {max_batch} windows; reference: one Estimator thread per SLAM instance, src/estimator.cpp:32-98); "
                      "robust solve (<=5 it) + L2 (<=10 it); a newer keyframe of a sequence replaces its pending one")
 
     def submit_all(self):
@@ -354,7 +359,7 @@ def main():
     ba = None
     if not a.no_ba:
         ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers, max_batch=a.ba_batch,
-                      high_priority=a.ba_priority == "high")
+                      high_priority=a.ba_priority == "high", device_resident=not a.ba_host_windows)
     def run_step():
         """one bench step = a.chunk frame-batches; returns the number of keyframe batches it held"""
         k = 0

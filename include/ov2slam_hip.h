@@ -307,6 +307,17 @@ ov2_status ov2_ba_solve(ov2_ctx *ctx, const ov2_ba_problem *p, const ov2_ba_opti
  * All windows of a batch share one landmark parametrisation (inv_depth); calibrations / extrinsics may differ. */
 ov2_status ov2_ba_solve_batch(ov2_ctx *ctx, int B, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
 
+/* The same solve for DEVICE-RESIDENT windows: every array pointer inside p[w] (pose, pose_const, lm, lm_anchor_pose,
+ * lm_anchor_uv, res_type, res_pose, res_lm, res_uv, res_sigma) and the per-residual outputs of r[w] (chi2, depth_positive,
+ * outlier; NULL = not wanted) are device pointers on ctx's device (ov2_dev_alloc, or arrays a device-side producer such as
+ * the map mirror left there); p[] / r[] themselves and the scalar fields / iteration logs of r[] are host memory.  One kernel
+ * lays the windows end to end, one hands the solved states and the outputs back; what crosses PCIe is a table of B
+ * pointers in and the window records out (a batch of 64 50-keyframe windows is 205 MB of arrays in the host form: ~5 ms
+ * of link time plus the host staging).  Replaces the same reference code as ov2_ba_solve_batch
+ * (src/optimizer.cpp:439-735 per window, src/estimator.cpp:32-98 per instance); results are bitwise those of the host form.
+ * The arrays must not be written by other streams during the call; it returns after one synchronisation. */
+ov2_status ov2_ba_solve_batch_dev(ov2_ctx *ctx, int B, const ov2_ba_problem *p, const ov2_ba_options *o, ov2_ba_result *r);
+
 /* ---------------------------------------------------------------------------------------------------
  * Motion-only BA (pose refinement on fixed 3D points).
  * Replaces MultiViewGeometry::ceresPnP(vunkps, vwpts, vscales, Twc, nmaxiter, chi2th, buse_robust,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ov2_ba_default_options": (None, [vp, C.c_float]),
     "ov2_ba_solve": (C.c_int, [vp, vp, vp, vp]),
     "ov2_ba_solve_batch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "ov2_ba_solve_batch_dev": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "ov2_pnp_solve_batch_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                           vp, vp, vp, vp]),
     "ov2_map_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -1315,6 +1315,69 @@ struct ba_raw {   // the B flat problems laid end to end; indices inside a windo
     int B, n_res, n_lm, n_pose, inv_depth;                                        // batch totals
 };
 
+// One window of a DEVICE-RESIDENT batch (ov2_ba_solve_batch_dev): where its arrays live and where they go in the
+// batch-wide arrays; the per-window outputs are device pointers as well.
+struct ba_gsrc {
+    const unsigned char *type, *pose_const;
+    const int *pose, *lm, *anch;
+    const double *uv, *sigma, *auv, *xp, *xl;
+    double *out_pose, *out_lm, *out_chi2;
+    unsigned char *out_depth, *out_outlier;
+    int n_res, n_lm, n_pose, r0, l0, p0;
+};
+
+struct ba_gdst {
+    unsigned char *type, *pose_const;
+    int *pose, *lm, *anch;
+    double *uv, *sigma, *auv, *xp, *xl;
+    int e, inv_depth;
+};
+
+template <typename T>
+__device__ __forceinline__ void gcopy(T *__restrict__ dst, const T *__restrict__ src, size_t n, size_t tid, size_t nthr)
+{
+    for (size_t i = tid; i < n; i += nthr) dst[i] = src[i];
+}
+
+// lays the windows' device arrays end to end (what upload_batch's host staging + H2D copy does for host problems);
+// grid (G, B): the G workgroups of a window stride over each of its arrays
+__global__ __launch_bounds__(256) void bb_gather_kernel(const ba_gsrc *__restrict__ T, ba_gdst D)
+{
+    const ba_gsrc g = T[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+    const size_t nr = (size_t)g.n_res, nl = (size_t)g.n_lm, np = (size_t)g.n_pose, r0 = (size_t)g.r0, l0 = (size_t)g.l0, p0 = (size_t)g.p0;
+    gcopy(D.type + r0, g.type, nr, tid, nthr);
+    gcopy(D.pose + r0, g.pose, nr, tid, nthr);
+    gcopy(D.lm + r0, g.lm, nr, tid, nthr);
+    gcopy(D.uv + 2 * r0, g.uv, 2 * nr, tid, nthr);
+    if (D.sigma) {
+        if (g.sigma) gcopy(D.sigma + r0, g.sigma, nr, tid, nthr);
+        else for (size_t i = tid; i < nr; i += nthr) D.sigma[r0 + i] = 1.0;
+    }
+    if (D.inv_depth) {
+        gcopy(D.anch + l0, g.anch, nl, tid, nthr);
+        gcopy(D.auv + 2 * l0, g.auv, 2 * nl, tid, nthr);
+    }
+    gcopy(D.xl + (size_t)D.e * l0, g.xl, (size_t)D.e * nl, tid, nthr);
+    gcopy(D.pose_const + p0, g.pose_const, np, tid, nthr);
+    gcopy(D.xp + 7 * p0, g.xp, 7 * np, tid, nthr);
+}
+
+// ... and hands the solved states and the per-residual outputs back to the windows' own device arrays
+__global__ __launch_bounds__(256) void bb_scatter_kernel(const ba_gsrc *__restrict__ T, const double *__restrict__ xp,
+                                                         const double *__restrict__ xl, int e, const double *__restrict__ chi2,
+                                                         const unsigned char *__restrict__ depth,
+                                                         const unsigned char *__restrict__ outlier)
+{
+    const ba_gsrc g = T[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+    gcopy(g.out_pose, xp + 7 * (size_t)g.p0, 7 * (size_t)g.n_pose, tid, nthr);
+    gcopy(g.out_lm, xl + (size_t)e * g.l0, (size_t)e * g.n_lm, tid, nthr);
+    if (g.out_chi2) gcopy(g.out_chi2, chi2 + g.r0, (size_t)g.n_res, tid, nthr);
+    if (g.out_depth) gcopy(g.out_depth, depth + g.r0, (size_t)g.n_res, tid, nthr);
+    if (g.out_outlier) gcopy(g.out_outlier, outlier + g.r0, (size_t)g.n_res, tid, nthr);
+}
+
 typedef unsigned long long u64;
 enum { BH_ROWS = 0, BH_NE, BH_NF, BH_ERR, BH_ENT, BH_VB, BH_MMAX, BH_STOT, BH_PAIRCAP, BH_N = 12 };
 // sort keys of inactive residual blocks carry one bit above the live key bits: they sort behind every live key
@@ -2015,6 +2078,10 @@ struct ba_solver {
     const int *pose_ptr = nullptr, *pose_ent = nullptr;   // pose -> (row*2 + cell) CSR
     int n_res = 0, n_lm = 0, n_pose = 0, e = 1;           // batch totals
     bool any_sigma = false;
+    bool on_device = false;      // ov2_ba_solve_batch_dev: the problems' arrays and the per-residual outputs are device memory
+    const ov2_ba_result *Rdev = nullptr;   // ... the results (for their output pointers)
+    const ba_gsrc *gtab = nullptr;         // ... device table of the windows' arrays
+    bool meas_pending = false;   // the measurement upload is still travelling on the copy stream (first program build waits for it)
 };
 
 #define BA_LAUNCH(S, id, ...) OV2_LAUNCH((S).c, id, __VA_ARGS__)
@@ -2036,12 +2103,52 @@ ov2_status upload_batch(ba_solver &S)
     R.B = B; R.n_res = S.n_res; R.n_lm = S.n_lm; R.n_pose = S.n_pose; R.inv_depth = S.e == 1 ? 1 : 0;
     const double *d_xp, *d_xl; const ba_win *d_W; const ba_wconst *d_wc;
 #define HC(devp, hostp, count) if ((s = hcarve(c, S.arena_off, &hostp, &devp, (size_t)(count))) != OV2_OK) return s
-    HC(R.type, h_type, n); HC(R.pose, h_pose, n); HC(R.lm, h_lm, n); HC(R.uv, h_uv, 2 * n);
-    if (S.any_sigma) { HC(R.sigma, h_sig, n); } else { R.sigma = nullptr; h_sig = nullptr; }
+    // the measurements (two thirds of the bytes) come last: they travel on a second stream while the program build
+    // already numbers and sorts the residual blocks, which only needs the index arrays of the head
+    HC(R.type, h_type, n); HC(R.pose, h_pose, n); HC(R.lm, h_lm, n);
     HC(R.lm_anch, h_anch, L); HC(R.lm_auv, h_auv, 2 * L); HC(R.pose_const, h_pc, NP);
     HC(R.res_off, h_ro, B + 1); HC(R.lm_off, h_lo, B + 1); HC(R.pose_off, h_po, B + 1);
     HC(d_xp, h_xp, 7 * NP); HC(d_xl, h_xl, e * L); HC(d_W, h_W, B); HC(d_wc, h_wc, B);
+    const size_t head_end = S.arena_off;
+    HC(R.uv, h_uv, 2 * n);
+    if (S.any_sigma) { HC(R.sigma, h_sig, n); } else { R.sigma = nullptr; h_sig = nullptr; }
+    ba_gsrc *h_tab = nullptr; const ba_gsrc *d_tab = nullptr;
+    if (S.on_device) HC(d_tab, h_tab, B);
 #undef HC
+    if (S.on_device) {
+        // the arrays stay where they are: only the window table, the offsets and the window records cross the link, one
+        // kernel lays the windows end to end
+        for (int w = 0; w < B; ++w) {
+            const ov2_ba_problem &P = S.P[w];
+            ba_gsrc &g = h_tab[w];
+            g.type = P.res_type; g.pose_const = P.pose_const; g.pose = P.res_pose; g.lm = P.res_lm; g.anch = P.lm_anchor_pose;
+            g.uv = P.res_uv; g.sigma = P.res_sigma; g.auv = P.lm_anchor_uv; g.xp = P.pose; g.xl = P.lm;
+            g.out_pose = P.pose; g.out_lm = P.lm;
+            g.out_chi2 = S.Rdev[w].chi2; g.out_depth = S.Rdev[w].depth_positive; g.out_outlier = S.Rdev[w].outlier;
+            g.n_res = P.n_res; g.n_lm = P.n_lm; g.n_pose = P.n_pose;
+            g.r0 = S.res_off[w]; g.l0 = S.lm_off[w]; g.p0 = S.pose_off[w];
+            ba_wconst &K = h_wc[w];
+            for (int i = 0; i < 4; ++i) { K.Kl[i] = P.calib_l[i]; K.Kr[i] = P.calib_r[i]; }
+            pose_Rt(P.T_rl, K.Rrl, K.trl);
+        }
+        memcpy(h_ro, S.res_off.data(), sizeof(int) * (B + 1));
+        memcpy(h_lo, S.lm_off.data(), sizeof(int) * (B + 1));
+        memcpy(h_po, S.pose_off.data(), sizeof(int) * (B + 1));
+        memcpy(h_W, S.hW.data(), sizeof(ba_win) * B);
+        auto h2d = [&](const void *dev, const void *host, size_t bytes) {
+            return hipMemcpyAsync(const_cast<void *>(dev), host, bytes, hipMemcpyHostToDevice, c->stream);
+        };
+        OV2_HIP(c, h2d(R.res_off, h_ro, (size_t)((const char *)d_xp - (const char *)R.res_off)));           // the three offset arrays
+        OV2_HIP(c, h2d(d_W, h_W, head_end - (size_t)((const char *)d_W - (const char *)c->ba_arena)));     // window records + constants
+        OV2_HIP(c, h2d(d_tab, h_tab, sizeof(ba_gsrc) * B));
+        ba_gdst D;
+        D.type = const_cast<unsigned char *>(R.type); D.pose_const = const_cast<unsigned char *>(R.pose_const);
+        D.pose = const_cast<int *>(R.pose); D.lm = const_cast<int *>(R.lm); D.anch = const_cast<int *>(R.lm_anch);
+        D.uv = const_cast<double *>(R.uv); D.sigma = const_cast<double *>(R.sigma); D.auv = const_cast<double *>(R.lm_auv);
+        D.xp = const_cast<double *>(d_xp); D.xl = const_cast<double *>(d_xl); D.e = S.e; D.inv_depth = R.inv_depth;
+        BA_LAUNCH(S, K_MISC, bb_gather_kernel, dim3(64, B), dim3(256), 0, c->stream, d_tab, D);
+        S.gtab = d_tab;
+    } else {
     auto stage_window = [&](int w) {
         const ov2_ba_problem &P = S.P[w];
         const size_t r0 = (size_t)S.res_off[w], l0 = (size_t)S.lm_off[w], p0 = (size_t)S.pose_off[w];
@@ -2086,7 +2193,19 @@ ov2_status upload_batch(ba_solver &S)
     memcpy(h_lo, S.lm_off.data(), sizeof(int) * (B + 1));
     memcpy(h_po, S.pose_off.data(), sizeof(int) * (B + 1));
     memcpy(h_W, S.hW.data(), sizeof(ba_win) * B);
-    OV2_HIP(c, hipMemcpyAsync(c->ba_arena, c->ba_host, S.arena_off, hipMemcpyHostToDevice, c->stream));
+    if (!c->ba_copy_stream) {
+        OV2_HIP(c, hipStreamCreateWithFlags(&c->ba_copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) OV2_HIP(c, hipEventCreateWithFlags(&c->ba_copy_ev[i], hipEventDisableTiming));
+    }
+    OV2_HIP(c, hipMemcpyAsync(c->ba_arena, c->ba_host, head_end, hipMemcpyHostToDevice, c->stream));
+    // the two copies share the link: the second starts when the first is through, the kernels of the build run beside it
+    OV2_HIP(c, hipEventRecord(c->ba_copy_ev[0], c->stream));
+    OV2_HIP(c, hipStreamWaitEvent(c->ba_copy_stream, c->ba_copy_ev[0], 0));
+    OV2_HIP(c, hipMemcpyAsync((char *)c->ba_arena + head_end, (char *)c->ba_host + head_end, S.arena_off - head_end, hipMemcpyHostToDevice,
+                              c->ba_copy_stream));
+    OV2_HIP(c, hipEventRecord(c->ba_copy_ev[1], c->ba_copy_stream));
+    S.meas_pending = true;
+    }
     S.xp = const_cast<double *>(d_xp); S.xl = const_cast<double *>(d_xl);
     S.W = const_cast<ba_win *>(d_W); S.wc = const_cast<ba_wconst *>(d_wc);
     // device-only arrays that live for the whole batch
@@ -2170,6 +2289,10 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipMemcpyAsync(hdr + BH_NF, fscan + NP, sizeof(int), hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(S, K_MISC, bb_keys_kernel, gn, dim3(256), 0, st, R, S.W, eidx, fidx, keys, hdr, nbits, fb, dead_bit);
         OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys2, n, nbits, dead_bit + 1, st));
+        if (S.meas_pending) {   // the sorted rows take their measurements along: the second half of the upload must be in
+            OV2_HIP(c, hipStreamWaitEvent(st, c->ba_copy_ev[1], 0));
+            S.meas_pending = false;
+        }
         BA_LAUNCH(S, K_MISC, bb_fill_kernel, gn, dim3(256), 0, st, R, keys2, eidx, fidx, hdr, O, nbits);
         BA_LAUNCH(S, K_MISC, bb_rowptr_kernel, gn, dim3(256), 0, st, O.eb, hdr, row_ptr);
         BA_LAUNCH(S, K_MISC, bb_posekeys_kernel, gn, dim3(256), 0, st, O.fk, O.fa, hdr, n, pk, fb);
@@ -2507,13 +2630,25 @@ extern "C" ov2_status ov2_ba_solve(ov2_ctx *c, const ov2_ba_problem *P, const ov
     return ov2_ba_solve_batch(c, 1, P, o, R);
 }
 
+static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R, bool on_device);
+
 extern "C" ov2_status ov2_ba_solve_batch(ov2_ctx *c, int B, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R)
+{
+    return ba_solve_batch_impl(c, B, P, o, R, false);
+}
+
+extern "C" ov2_status ov2_ba_solve_batch_dev(ov2_ctx *c, int B, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R)
+{
+    return ba_solve_batch_impl(c, B, P, o, R, true);
+}
+
+static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P, const ov2_ba_options *o, ov2_ba_result *R, bool on_device)
 {
     if (!c) return OV2_ERR_INVALID;
     if (B == 0) return OV2_OK;
     if (B < 0 || !P || !o || !R) return ov2_set_err(c, OV2_ERR_INVALID, "null problem/options/result");
     ba_solver S;
-    S.c = c; S.B = B; S.P = P; S.o = o;
+    S.c = c; S.B = B; S.P = P; S.o = o; S.on_device = on_device; S.Rdev = R;
     S.e = P[0].inv_depth ? 1 : 3;
     S.res_off.assign(B + 1, 0); S.lm_off.assign(B + 1, 0); S.pose_off.assign(B + 1, 0);
     long long tn = 0, tl = 0, tp = 0;
@@ -2548,7 +2683,7 @@ extern "C" ov2_status ov2_ba_solve_batch(ov2_ctx *c, int B, const ov2_ba_problem
         Rw.n_log = 0; Rw.n_log_robust = 0; Rw.l2_done = 0; Rw.n_outliers_pass1 = Rw.n_outliers_pass2 = 0;
         Rw.initial_cost = Rw.final_cost = Rw.l2_initial_cost = Rw.l2_final_cost = 0.0;
         Rw.termination = Rw.l2_termination = OV2_BA_TERM_SKIPPED;
-        if (Rw.outlier) memset(Rw.outlier, 0, (size_t)P[w].n_res);
+        if (Rw.outlier && !on_device) memset(Rw.outlier, 0, (size_t)P[w].n_res);
     }
     // arena: upper bound of everything upload_batch + build_program carve for the full batch
     {
@@ -2639,12 +2774,19 @@ extern "C" ov2_status ov2_ba_solve_batch(ov2_ctx *c, int B, const ov2_ba_problem
         double *h_chi2 = want_chi2 ? (double *)carve(n * 8) : nullptr;
         unsigned char *h_depth = want_depth ? (unsigned char *)carve(n) : nullptr, *h_out = want_out ? (unsigned char *)carve(n) : nullptr;
         if (off > c->ba_host_cap) return ov2_set_err(c, OV2_ERR_NOMEM, "BA pinned mirror too small for the results");
+        if (S.meas_pending) { OV2_HIP(c, hipStreamWaitEvent(c->stream, c->ba_copy_ev[1], 0)); S.meas_pending = false; }   // a batch without residual blocks
         if (n_l2 > 0) OV2_HIP(c, hipMemcpyAsync(h_W, S.W, sizeof(ba_win) * B, hipMemcpyDeviceToHost, c->stream));
-        if (NP) OV2_HIP(c, hipMemcpyAsync(h_xp, S.xp, 7 * NP * 8, hipMemcpyDeviceToHost, c->stream));
-        if (L) OV2_HIP(c, hipMemcpyAsync(h_xl, S.xl, e * L * 8, hipMemcpyDeviceToHost, c->stream));
-        if (h_chi2 && n) OV2_HIP(c, hipMemcpyAsync(h_chi2, S.chi2_dev, n * 8, hipMemcpyDeviceToHost, c->stream));
-        if (h_depth && n) OV2_HIP(c, hipMemcpyAsync(h_depth, S.depth_dev, n, hipMemcpyDeviceToHost, c->stream));
-        if (h_out && n) OV2_HIP(c, hipMemcpyAsync(h_out, S.outlier_dev, n, hipMemcpyDeviceToHost, c->stream));
+        if (S.on_device) {
+            // states and per-residual outputs go back to the windows' own device arrays; only the window records travel
+            BA_LAUNCH(S, K_MISC, bb_scatter_kernel, dim3(32, B), dim3(256), 0, c->stream, S.gtab, S.xp, S.xl, S.e, S.chi2_dev, S.depth_dev,
+                      S.outlier_dev);
+        } else {
+            if (NP) OV2_HIP(c, hipMemcpyAsync(h_xp, S.xp, 7 * NP * 8, hipMemcpyDeviceToHost, c->stream));
+            if (L) OV2_HIP(c, hipMemcpyAsync(h_xl, S.xl, e * L * 8, hipMemcpyDeviceToHost, c->stream));
+            if (h_chi2 && n) OV2_HIP(c, hipMemcpyAsync(h_chi2, S.chi2_dev, n * 8, hipMemcpyDeviceToHost, c->stream));
+            if (h_depth && n) OV2_HIP(c, hipMemcpyAsync(h_depth, S.depth_dev, n, hipMemcpyDeviceToHost, c->stream));
+            if (h_out && n) OV2_HIP(c, hipMemcpyAsync(h_out, S.outlier_dev, n, hipMemcpyDeviceToHost, c->stream));
+        }
         OV2_HIP(c, hipStreamSynchronize(c->stream));
         t5 = now();
         for (int w = 0; w < B; ++w) {
@@ -2659,6 +2801,7 @@ extern "C" ov2_status ov2_ba_solve_batch(ov2_ctx *c, int B, const ov2_ba_problem
             }
             Rw.n_log = std::min<int>(X.n_log, OV2_BA_MAX_LOG);
             memcpy(Rw.log, X.log, sizeof(ov2_ba_iter) * (size_t)Rw.n_log);
+            if (S.on_device) continue;
             const size_t r0 = (size_t)S.res_off[w], l0 = (size_t)S.lm_off[w], p0 = (size_t)S.pose_off[w];
             // write back the non-constant blocks ("parameters_"; constant ones come back unchanged)
             if (Q.n_pose) memcpy(Q.pose, h_xp + 7 * p0, sizeof(double) * 7 * (size_t)Q.n_pose);

@@ -87,6 +87,8 @@ struct ov2_ctx {
     size_t ba_arena2_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
     size_t ba_host_cap;
+    hipStream_t ba_copy_stream;          // second half of a batch upload (measurements) travels here while the program build sorts
+    hipEvent_t ba_copy_ev[2];            // [0] head uploaded (main stream), [1] measurements uploaded (copy stream)
     int klt_lanes;                       // ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = forced lanes per keypoint
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
     bool ktime_on;

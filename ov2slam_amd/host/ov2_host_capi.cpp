@@ -476,9 +476,57 @@ struct BaWorkerNative {
     double busy_s = 0.0;
     int last_status = 0;
 
+    // device-resident windows (ov2_ba_solve_batch_dev): the window's arrays are uploaded once, every job solves its own
+    // device copy of the state -- what a device-side producer of the problems (the map mirror) hands over
+    bool device_resident = false;
+    ov2_ba_problem Pd{};                       // P with device pointers
+    void *pose0_d = nullptr, *lm0_d = nullptr;
+    std::vector<void *> pose_d, lm_d, owned_d;
+
+    bool dev_setup()
+    {
+        auto up = [&](const void *h, size_t bytes) -> void * {
+            if (!h || !bytes) return nullptr;
+            void *d = nullptr;
+            if (ov2_dev_alloc(ctx, bytes, &d) != OV2_OK) return nullptr;
+            owned_d.push_back(d);
+            if (ov2_memcpy_h2d(ctx, d, h, bytes) != OV2_OK) return nullptr;
+            return d;
+        };
+        const size_t e = P.inv_depth ? 1 : 3, np = (size_t)P.n_pose, nl = (size_t)P.n_lm, nr = (size_t)P.n_res;
+        Pd = P;
+        pose0_d = up(pose0.data(), 7 * np * 8); lm0_d = up(lm0.data(), e * nl * 8);
+        Pd.pose_const = (const uint8_t *)up(P.pose_const, np);
+        Pd.lm_anchor_pose = (const int32_t *)up(P.lm_anchor_pose, nl * 4);
+        Pd.lm_anchor_uv = (const double *)up(P.lm_anchor_uv, 2 * nl * 8);
+        Pd.res_type = (const uint8_t *)up(P.res_type, nr);
+        Pd.res_pose = (const int32_t *)up(P.res_pose, nr * 4);
+        Pd.res_lm = (const int32_t *)up(P.res_lm, nr * 4);
+        Pd.res_uv = (const double *)up(P.res_uv, 2 * nr * 8);
+        Pd.res_sigma = (const double *)up(P.res_sigma, nr * 8);
+        return (pose0_d || !np) && (lm0_d || !nl) && (Pd.res_uv || !nr);
+    }
+
+    bool dev_job_state(size_t nb)
+    {
+        const size_t e = P.inv_depth ? 1 : 3, pb = 7 * (size_t)P.n_pose * 8, lb = e * (size_t)P.n_lm * 8;
+        while (pose_d.size() < nb) {
+            void *a = nullptr, *b = nullptr;
+            if (ov2_dev_alloc(ctx, pb ? pb : 8, &a) != OV2_OK || ov2_dev_alloc(ctx, lb ? lb : 8, &b) != OV2_OK) return false;
+            owned_d.push_back(a); owned_d.push_back(b);
+            pose_d.push_back(a); lm_d.push_back(b);
+        }
+        for (size_t k = 0; k < nb; ++k) {   // a fresh copy of the window per job, on the solver's stream
+            if (pb && ov2_memcpy_d2d(ctx, pose_d[k], pose0_d, pb) != OV2_OK) return false;
+            if (lb && ov2_memcpy_d2d(ctx, lm_d[k], lm0_d, lb) != OV2_OK) return false;
+        }
+        return true;
+    }
+
     void loop()
     {
         size_t rr = 0;
+        bool dev_ready = false;
         std::vector<int> jobs;
         std::vector<std::vector<double>> poses, lms;   // per job: the window's own state (solved in place)
         std::vector<ov2_ba_problem> Ps;
@@ -504,12 +552,25 @@ struct BaWorkerNative {
             Ps.assign(nb, P);
             Rs.resize(nb);
             for (size_t k = 0; k < nb; ++k) {
-                poses[k] = pose0; lms[k] = lm0;
-                Ps[k].pose = poses[k].data(); Ps[k].lm = lms[k].data();
+                if (!device_resident) {
+                    poses[k] = pose0; lms[k] = lm0;
+                    Ps[k].pose = poses[k].data(); Ps[k].lm = lms[k].data();
+                }
                 std::memset(&Rs[k], 0, sizeof(ov2_ba_result));
             }
+            if (device_resident && !dev_ready) dev_ready = dev_setup();
             const auto t0 = std::chrono::steady_clock::now();
-            const ov2_status s = ov2_ba_solve_batch(ctx, (int)nb, Ps.data(), &opt, Rs.data());
+            ov2_status s;
+            if (device_resident) {
+                s = OV2_ERR_NOMEM;
+                if (dev_ready && dev_job_state(nb)) {
+                    Ps.assign(nb, Pd);
+                    for (size_t k = 0; k < nb; ++k) { Ps[k].pose = (double *)pose_d[k]; Ps[k].lm = (double *)lm_d[k]; }
+                    s = ov2_ba_solve_batch_dev(ctx, (int)nb, Ps.data(), &opt, Rs.data());
+                }
+            } else {
+                s = ov2_ba_solve_batch(ctx, (int)nb, Ps.data(), &opt, Rs.data());
+            }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);
             last_status = s;
@@ -556,6 +617,14 @@ void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mo
     return w;
 }
 
+// before the first submission: the worker keeps its windows in device memory and solves them with ov2_ba_solve_batch_dev
+void ov2h_ba_worker_set_device_resident(void *p, int on)
+{
+    BaWorkerNative *w = (BaWorkerNative *)p;
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->device_resident = on != 0;
+}
+
 // Mapper::run -> Estimator::addNewKf for every sequence of the batch
 void ov2h_ba_worker_submit_all(void *p)
 {
@@ -596,6 +665,7 @@ void ov2h_ba_worker_destroy(void *p)
     }
     w->cv.notify_all();
     if (w->th.joinable()) w->th.join();
+    for (void *d : w->owned_d) ov2_dev_free(w->ctx, d);
     ov2_ctx_destroy(w->ctx);
     delete w;
 }

@@ -44,6 +44,8 @@ def lib():
         L.ov2h_apply_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, ip, ip, dp]
         L.ov2h_ba_worker_create.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int]
         L.ov2h_ba_worker_create.restype = C.c_void_p
+        L.ov2h_ba_worker_set_device_resident.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_ba_worker_set_device_resident.restype = None
         L.ov2h_ba_worker_submit_all.argtypes = [C.c_void_p]
         L.ov2h_ba_worker_submit_all.restype = None
         L.ov2h_ba_worker_set_counting.argtypes = [C.c_void_p, C.c_int]
@@ -280,12 +282,14 @@ class EstimatorWorker:
     ov2_ba_solve_batch call (at most max_batch).  Python only submits keyframes and reads the counters, so the worker never
     competes for the interpreter lock."""
 
-    def __init__(self, device, problem, nseq, robust_mono_th=5.9915, max_batch=64, high_priority=True):
+    def __init__(self, device, problem, nseq, robust_mono_th=5.9915, max_batch=64, high_priority=True, device_resident=False):
         self.problem = problem              # keeps the arrays alive during the deep copy
         pc = problem.as_c()
         self.h = lib().ov2h_ba_worker_create(device, C.addressof(pc), robust_mono_th, nseq, max_batch, int(bool(high_priority)))
         if not self.h:
             raise RuntimeError("ov2h_ba_worker_create failed (no GPU?)")
+        if device_resident:   # windows kept in HBM, solved by ov2_ba_solve_batch_dev (before the first submission)
+            lib().ov2h_ba_worker_set_device_resident(self.h, 1)
 
     def submit_all(self):
         lib().ov2h_ba_worker_submit_all(self.h)

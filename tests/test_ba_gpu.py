@@ -165,3 +165,44 @@ def test_local_ba_long_tracks(ctx, oracle):
     Rg = local_ba.Optimizer(ctx).localBA(P)
     Rc = oracle.ba_solve(Pc)
     _compare(P, Rg, Pc, Rc, flags_exact=False)
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_local_ba_batch_device_resident_is_bitwise_the_host_form(ctx, inv_depth):
+    """ov2_ba_solve_batch_dev (arrays + per-residual outputs in device memory, gathered / scattered by kernels) against
+    ov2_ba_solve_batch on the same ragged windows (one empty, one without outliers, one with per-residual sigmas):
+    states, costs, logs, chi2 and flags bitwise equal -- the host form is what the oracle tests pin."""
+    Ps = [synth_ba.make_window(6, 80, inv_depth=inv_depth, seed=23),
+          synth_ba.make_window(20, 2000, inv_depth=inv_depth, seed=37),
+          synth_ba.make_window(12, 600, inv_depth=inv_depth, seed=3, outlier_frac=0.0, px_noise=0.05),
+          synth_ba.make_window(31, 3000, inv_depth=inv_depth, seed=43, max_obs=9)]
+    Ps[1].res_sigma = (2.0 ** np.random.default_rng(5).integers(0, 3, Ps[1].n_res)).astype(np.float64)
+    E = synth_ba.make_window(4, 20, inv_depth=inv_depth, seed=1)     # empty window
+    E.res_type, E.res_pose, E.res_lm, E.res_uv = E.res_type[:0], E.res_pose[:0], E.res_lm[:0], E.res_uv[:0]
+    Ps.insert(1, E)
+    opt = local_ba.Optimizer(ctx)
+    Ds = [local_ba.DeviceBaProblem(ctx, p) for p in Ps]
+    Rd = opt.localBA_batch_dev(Ds)
+    Rh = opt.localBA_batch(Ps)          # solves Ps in place (the device copies were taken before)
+    for k, (D, P) in enumerate(zip(Ds, Ps)):
+        pose, lm, chi2, depth, outl = D.download()
+        assert np.array_equal(pose.view(np.uint64), P.pose.view(np.uint64)), k
+        assert np.array_equal(lm.view(np.uint64), P.lm.view(np.uint64)), k
+        a, b = Rd[k], Rh[k].c
+        assert (a.n_log, a.n_log_robust, a.termination, a.l2_termination, a.l2_done) == \
+               (b.n_log, b.n_log_robust, b.termination, b.l2_termination, b.l2_done), k
+        assert (a.initial_cost, a.final_cost, a.l2_initial_cost, a.l2_final_cost) == \
+               (b.initial_cost, b.final_cost, b.l2_initial_cost, b.l2_final_cost), k
+        assert (a.n_outliers_pass1, a.n_outliers_pass2) == (b.n_outliers_pass1, b.n_outliers_pass2), k
+        for i in range(a.n_log):
+            assert a.log[i].cost == b.log[i].cost and a.log[i].radius == b.log[i].radius
+        if P.n_res:
+            assert np.array_equal(chi2.view(np.uint64), Rh[k].chi2.view(np.uint64)), k
+            assert np.array_equal(depth, Rh[k].depth_positive) and np.array_equal(outl, Rh[k].outlier), k
+    # a second solve from the re-set state gives the same answer (nothing of the first call survives in the arena)
+    first = [D.download()[0] for D in Ds]
+    for D in Ds:
+        D.reset()
+    opt.localBA_batch_dev(Ds)
+    for k, D in enumerate(Ds):
+        assert np.array_equal(D.download()[0].view(np.uint64), first[k].view(np.uint64)), k
