@@ -454,6 +454,12 @@ ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_covscore, int 
                                   const double *calib_l /* fx fy cx cy: anchor depth needs no intrinsics; reserved */,
                                   ov2_local_ba_setup *out);
 
+/* The flat problem of the last set-up where the kernels left it ON THE DEVICE: `dev` = `host` with every array pointer
+ * translated (same validity: until the next set-up call of this map).  These are the pointers ov2_ba_solve_batch_dev
+ * takes, so set-up -> solve runs without the measurement arrays crossing PCIe in either direction; the solved pose / lm
+ * arrays are then the device copies (ov2_memcpy_d2h what the host-side update stage, src/optimizer.cpp:741-882, needs). */
+ov2_status ov2_map_setup_device_view(const ov2_map *m, const ov2_local_ba_setup *host, ov2_local_ba_setup *dev);
+
 /* ---------------------------------------------------------------------------------------------------
  * Two-view triangulation of keypoint pairs + the mapper's acceptance gates (second half).
  * Replaces the per-keypoint bodies of Mapper::triangulateStereo (src/mapper.cpp:346-461) and

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ov2_map_compact": (C.c_int, [vp, ip, ip]),
     "ov2_map_obs_rows": (C.c_int, [vp, ip, ip, ip]),
     "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ov2_map_setup_device_view": (C.c_int, [vp, vp, vp]),
     "ov2_triangulate_pairs": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
                                         vp, vp, vp, vp]),
     "ov2_triangulate_pairs_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,

@@ -912,3 +912,24 @@ extern "C" ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_cov
     out->bad_lmid = (const int32_t *)at(Hh, o_bl);
     return squeeze ? compact_obs(m) : OV2_OK;
 }
+
+// The same flat problem, where the set-up left it on the device (ov2_ba_solve_batch_dev takes these pointers as they are)
+extern "C" ov2_status ov2_map_setup_device_view(const ov2_map *m, const ov2_local_ba_setup *host, ov2_local_ba_setup *dev)
+{
+    if (!m || !host || !dev) return OV2_ERR_INVALID;
+    *dev = *host;
+    if (host->aborted) return OV2_OK;
+    const unsigned char *H = m->out_host, *D = m->out_dev;
+    auto tr = [&](const void *p) -> const unsigned char * {
+        const unsigned char *q = (const unsigned char *)p;
+        return (q && H && q >= H && q < H + m->out_cap) ? D + (q - H) : nullptr;
+    };
+    if (host->n_pose && !tr(host->pose)) return OV2_ERR_INVALID;   // not the arrays of this map's last set-up
+    dev->pose_kfid = (const int32_t *)tr(host->pose_kfid); dev->pose_const = tr(host->pose_const); dev->pose = (double *)tr(host->pose);
+    dev->lm_lmid = (const int32_t *)tr(host->lm_lmid); dev->lm = (double *)tr(host->lm);
+    dev->lm_anchor_pose = (const int32_t *)tr(host->lm_anchor_pose); dev->lm_anchor_uv = (const double *)tr(host->lm_anchor_uv);
+    dev->res_type = tr(host->res_type); dev->res_pose = (const int32_t *)tr(host->res_pose); dev->res_lm = (const int32_t *)tr(host->res_lm);
+    dev->res_uv = (const double *)tr(host->res_uv); dev->res_sigma = (const double *)tr(host->res_sigma);
+    dev->bad_lmid = (const int32_t *)tr(host->bad_lmid);
+    return OV2_OK;
+}

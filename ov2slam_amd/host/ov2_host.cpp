@@ -972,6 +972,7 @@ ov2_status Optimizer::setupLocalBADevice(Frame &newframe, LocalBAProblem &pb)
         pb.lmid_to_lm.emplace(lmid, (int)i);
         pb.map_local_plms.emplace(lmid, pmap_->getMapPoint(lmid));
     }
+    pb.has_dev = ov2_map_setup_device_view(pmap_->dev_, &f, &pb.dev_view) == OV2_OK;
     for (int i = 0; i < f.n_bad; ++i) {   // MapPoint::isBad() also clears is3d_ (src/map_point.cpp:219,227)
         pb.set_badlmids.insert(f.bad_lmid[i]);
         auto plm = pmap_->getMapPoint(f.bad_lmid[i]);
@@ -1066,7 +1067,36 @@ ov2_status Optimizer::localBA(Frame &newframe, const bool buse_robust_cost)
     std::vector<uint8_t> depth(p.n_res), outlier(p.n_res);
     std::memset(&last_result_, 0, sizeof(last_result_));
     last_result_.chi2 = chi2.data(); last_result_.depth_positive = depth.data(); last_result_.outlier = outlier.data();
-    const ov2_status s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    ov2_status s;
+    if (pb.has_dev) {
+        // the set-up kernels left the flat problem in HBM: solve it there (ov2_ba_solve_batch_dev); only the solved states
+        // and the flags the update stage walks come back
+        const size_t R = (size_t)p.n_res, e = p.inv_depth ? 1 : 3;
+        const size_t need = R * 8 + 2 * ((R + 15) & ~(size_t)15) + 64;
+        if (need > dev_out_cap_) {
+            if (dev_out_) ov2_dev_free(ctx_, dev_out_);
+            dev_out_ = nullptr; dev_out_cap_ = 0;
+            if ((s = ov2_dev_alloc(ctx_, need + need / 2, &dev_out_)) != OV2_OK) return s;
+            dev_out_cap_ = need + need / 2;
+        }
+        unsigned char *d = (unsigned char *)dev_out_;
+        ov2_ba_problem pd = p;
+        const ov2_local_ba_setup &v = pb.dev_view;
+        pd.pose = v.pose; pd.pose_const = v.pose_const; pd.lm = v.lm; pd.lm_anchor_pose = v.lm_anchor_pose; pd.lm_anchor_uv = v.lm_anchor_uv;
+        pd.res_type = v.res_type; pd.res_pose = v.res_pose; pd.res_lm = v.res_lm; pd.res_uv = v.res_uv; pd.res_sigma = v.res_sigma;
+        ov2_ba_result rd = last_result_;
+        rd.chi2 = (double *)d; rd.depth_positive = d + R * 8; rd.outlier = d + R * 8 + ((R + 15) & ~(size_t)15);
+        s = ov2_ba_solve_batch_dev(ctx_, 1, &pd, &o, &rd);
+        if (s == OV2_OK) s = ov2_memcpy_d2h(ctx_, pb.pose.data(), v.pose, 7 * (size_t)p.n_pose * 8);
+        if (s == OV2_OK) s = ov2_memcpy_d2h(ctx_, pb.lm.data(), v.lm, e * (size_t)p.n_lm * 8);
+        if (s == OV2_OK && R) s = ov2_memcpy_d2h(ctx_, chi2.data(), rd.chi2, R * 8);
+        if (s == OV2_OK && R) s = ov2_memcpy_d2h(ctx_, depth.data(), rd.depth_positive, R);
+        if (s == OV2_OK && R) s = ov2_memcpy_d2h(ctx_, outlier.data(), rd.outlier, R);
+        rd.chi2 = chi2.data(); rd.depth_positive = depth.data(); rd.outlier = outlier.data();
+        last_result_ = rd;
+    } else {
+        s = ov2_ba_solve(ctx_, &p, &o, &last_result_);
+    }
     if (s == OV2_OK) updateAfterLocalBA(newframe, pb, last_result_);
     last_result_.chi2 = nullptr; last_result_.depth_positive = nullptr; last_result_.outlier = nullptr;
     return s;

@@ -271,6 +271,8 @@ struct LocalBAProblem {
     std::unordered_map<int, std::shared_ptr<MapPoint>> map_local_plms;
     size_t nbmono = 0, nbstereo = 0;
     bool aborted = false;                                // early return of :61-63
+    ov2_local_ba_setup dev_view{};   // set by setupLocalBADevice: the same arrays where the set-up kernels left them (has_dev)
+    bool has_dev = false;
     ov2_ba_problem view(const SlamParams &st, const Frame &newframe);
 };
 
@@ -308,6 +310,9 @@ public:
     bool stopLocalBA() const { return bstop_localba_; }
     void signalStopLocalBA() { bstop_localba_ = true; }
     ov2_ba_result last_result_{};
+    void *dev_out_ = nullptr;        // device scratch of the per-residual outputs when the solve runs on the set-up's device arrays
+    size_t dev_out_cap_ = 0;
+    ~Optimizer() { if (dev_out_) ov2_dev_free(ctx_, dev_out_); }
     ov2_ctx *ctx_;
     std::shared_ptr<SlamParams> pslamstate_;
     std::shared_ptr<MapManager> pmap_;
