@@ -97,6 +97,12 @@ struct ba_dev {
     double *rhs, *iete, *ieg;
     double *FFp;         // per pose block: lower triangle (21) of F'F over all its rows, refreshed with the jacobian
     double *part;        // partial sums (max(n_rows blocks, n_e, n_f + n_e))
+    // L2 re-solve on the SAME program: rows flagged by the robust pass are dead (zero residual and jacobian), blocks whose
+    // rows all died stay out of the parameter norms (Ceres' reduced program would not contain them)
+    int masked;
+    unsigned char *dead;       // per sorted row
+    unsigned char *e_dead;     // per landmark block: no live row left
+    unsigned char *f_live;     // per pose block: some live row refers to it
 };
 
 struct ba_lmopt {   // the solver options the device-side state machine needs
@@ -346,7 +352,17 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__
     const int row = W.row0 + ((int)blockIdx.x - W.vb0) * 256 + (int)threadIdx.x;
     const int use_loss = W.use_loss;
     double c = 0.0;
-    if (row < W.row1) {
+    const bool dead = d.masked && row < W.row1 && d.dead[row];
+    if (dead) {
+        if (JAC) {
+            constexpr int e = E;
+            d.res[2 * row] = 0.0; d.res[2 * row + 1] = 0.0;
+            for (int cc = 0; cc < 2 * e; ++cc) d.Je[(size_t)row * 2 * e + cc] = 0.0;
+            double2 *U2 = reinterpret_cast<double2 *>(d.U + (size_t)row * 12);
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) U2[cc] = make_double2(0.0, 0.0);
+        }
+    } else if (row < W.row1) {
         row_eval ev;
         eval_row<JAC>(d, d.wc[w], poses, lms, row, ev);
         double rho[3] = {ev.chi2, 1.0, 0.0};
@@ -1220,6 +1236,10 @@ __global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__r
         const ba_win &W = d.W[i < d.n_e ? d.win_of_e[i] : d.win_of_f[i - d.n_e]];
         if (!(W.active && W.valid)) return;
     }
+    if (d.masked && i < d.n_e + d.n_f && (i < d.n_e ? d.e_dead[i] != 0 : d.f_live[i - d.n_e] == 0)) {
+        part_step[i] = 0.0; part_norm[i] = 0.0;   // not a block of the reduced program: its step is zero, the candidate keeps x
+        return;
+    }
     if (i < d.n_e) {
         const int l = d.lm_of_e[i];
         double s2 = 0, n2 = 0;
@@ -1250,8 +1270,8 @@ __global__ __launch_bounds__(64) void ba_plus_kernel(ba_dev d, const double *__r
 // the cost functors' cached chi2err_ / isdepthpositive_ (src/optimizer.cpp:500-592; src/ceres_parametrization.cpp:136-146),
 // i.e. the values of the LAST Evaluate() call, and Ceres does not re-evaluate after Solve: after an accepted last step that
 // is the final x, after a FTOL / PTOL exit or a rejected last step it is the candidate (trust_region_minimizer.cc:108-131).
-// Rows that fail the test leave the device-side active set (the L2 program is rebuilt from it without the host); the
-// per-window tallies drive the decision for the L2 refinement (src/optimizer.cpp:603-608).
+// Rows that fail the test leave the device-side active set and are marked dead in the program (the L2 re-solve runs the
+// same program with them masked); the per-window tallies drive the decision for the L2 refinement (src/optimizer.cpp:603-608).
 __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__restrict__ xp, const double *__restrict__ xl,
                                                       const double *__restrict__ cp, const double *__restrict__ cl,
                                                       const int *__restrict__ rows, double chi2_th, int pass,
@@ -1264,7 +1284,7 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
     const int w = d.row_win[in ? row : d.n_rows - 1];
     ba_win &W = d.W[w];
     bool bad = false, left = false, right = false;
-    if (in) {
+    if (in && !(pass == 2 && (W.skip || d.dead[row]))) {   // second pass: the rows of the L2 program only
         const bool at_cand = W.eval_at_cand != 0;
         row_eval ev;
         eval_row<false>(d, d.wc[w], at_cand ? cp : xp, at_cand ? cl : xl, row, ev);
@@ -1274,6 +1294,7 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
         if (ev.chi2 > chi2_th || !ev.depth_pos) {
             active[i] = 0;
             outlier[i] = (unsigned char)pass;
+            d.dead[row] = 1;
             bad = true;
         } else {
             const int t = d.type[row];
@@ -1296,6 +1317,23 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
         if (left) atomicAdd(&W.n_left, 1);
         if (right) atomicAdd(&W.n_right, 1);
     }
+}
+
+// which blocks still have a live row after the robust pass (thread per landmark block)
+__global__ __launch_bounds__(256) void ba_live_kernel(ba_dev d)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.n_e) return;
+    if (d.W[d.win_of_e[l]].skip) { d.e_dead[l] = 0; return; }
+    bool any = false;
+    for (int r = d.row_ptr[l]; r < d.row_ptr[l + 1]; ++r) {
+        if (d.dead[r]) continue;
+        any = true;
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fk >= 0) d.f_live[fk] = 1;
+        if (fa >= 0) d.f_live[fa] = 1;
+    }
+    d.e_dead[l] = any ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2339,6 +2377,9 @@ ov2_status build_program(ba_solver &S)
     AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e); AL(FFp, (size_t)d.n_f * 21);
     AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);
     AL(n_active, 64);   // |step|^2, |x+|^2, model change per block | cost partials per virtual block
+    AL(dead, (size_t)nr + 1); AL(e_dead, (size_t)d.n_e + 1); AL(f_live, (size_t)d.n_f + 1);
+    OV2_HIP(c, hipMemsetAsync(d.dead, 0, (size_t)nr + 1, st));
+    d.masked = 0;
 #undef AL
     S.chold_stride = (size_t)(S.mmax / CHOL_NB + 1) * CHOL_NB * CHOL_NB;
     if ((s = dalloc(c, S.arena_off, &S.chold, S.chold_stride * B)) != OV2_OK) return s;
@@ -2746,6 +2787,11 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
             did_l2[w] = 1;
             X.use_loss = !(X.n_left > 0 && X.n_right > 0);   // src/optimizer.cpp:606-608
             X.max_iters = o->l2_max_iters;
+            if (X.nbad >= X.row1 - X.row0) {   // every residual block was flagged: nothing left to minimise
+                X.skip = 2; X.done = 1; X.termination = OV2_BA_TERM_SKIPPED;
+                X.initial_cost = X.minimum_cost = X.x_cost = 0.0;
+                X.active = X.valid = X.accepted = 0; X.eval_at_cand = 0;
+            }
             X.nbad = X.n_left = X.n_right = 0;
         }
     }
@@ -2755,7 +2801,12 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
         ba_win *h_W = (ba_win *)c->ba_host;
         memcpy(h_W, S.hW.data(), sizeof(ba_win) * B);
         OV2_HIP(c, hipMemcpyAsync(S.W, h_W, sizeof(ba_win) * B, hipMemcpyHostToDevice, c->stream));
-        if ((s = build_program(S)) != OV2_OK) return s;
+        // the program (row order, Schur structure, work arrays) is the robust pass's: nothing is rebuilt or re-sorted
+        if (S.d.n_rows > 0 && S.d.n_e > 0) {
+            S.d.masked = 1;
+            OV2_HIP(c, hipMemsetAsync(S.d.f_live, 0, (size_t)S.d.n_f + 1, c->stream));
+            BA_LAUNCH(S, K_MISC, ba_live_kernel, dim3((S.d.n_e + 255) / 256), dim3(256), 0, c->stream, S.d);
+        }
         t3 = now();
         if ((s = enqueue_minimize(S, o->l2_max_iters)) != OV2_OK) return s;
         if ((s = enqueue_flags(S, 2)) != OV2_OK) return s;
