@@ -206,3 +206,33 @@ def test_local_ba_batch_device_resident_is_bitwise_the_host_form(ctx, inv_depth)
     opt.localBA_batch_dev(Ds)
     for k, D in enumerate(Ds):
         assert np.array_equal(D.download()[0].view(np.uint64), first[k].view(np.uint64)), k
+
+
+def test_local_ba_l2_on_a_nearly_empty_program(ctx, oracle):
+    """the L2 re-solve runs the robust pass's program with the flagged rows masked: (a) 566 of 573 residual blocks flagged --
+    most landmark and pose blocks are left without a row, Ceres' reduced program would not contain them and the solve ends
+    on the PARAMETER tolerance, whose norms must not see them; (b) every block flagged -- nothing to minimise, skipped."""
+    P = synth_ba.make_window(6, 60, inv_depth=True, seed=5, outlier_frac=1.0)
+    Pc = P.copy()
+    Rg, Rc = local_ba.Optimizer(ctx).localBA(P), oracle.ba_solve(Pc)
+    assert Rc.summary()["l2_termination"] == "parameter_tolerance" and Rc.c.n_outliers_pass1 > 0.9 * P.n_res
+    _compare(P, Rg, Pc, Rc)
+    assert Rg.summary()["l2_termination"] == "parameter_tolerance"
+    assert Rg.c.l2_initial_cost == pytest.approx(Rc.c.l2_initial_cost, rel=1e-9)
+    Q = synth_ba.make_window(6, 60, inv_depth=True, seed=5)
+    Q.res_uv = Q.res_uv + 500.0
+    Qc = Q.copy()
+    Rg, Rc = local_ba.Optimizer(ctx).localBA(Q), oracle.ba_solve(Qc)
+    assert Rc.c.n_outliers_pass1 == Q.n_res and Rc.summary()["l2_termination"] == "skipped"
+    # (measurements 500 px off: the robust pass takes wild, rejected steps whose costs agree to 1e-8 only -- not the subject here)
+    assert Rg.summary()["iterations"] == Rc.summary()["iterations"] and Rg.c.n_log == Rc.c.n_log
+    assert Rg.c.final_cost == pytest.approx(Rc.c.final_cost, rel=1e-6) and Rg.c.n_outliers_pass1 == Q.n_res
+    assert np.array_equal(Rg.outlier, Rc.outlier) and np.abs(Q.pose - Qc.pose).max() < 1e-4
+    assert Rg.summary()["l2_termination"] == "skipped" and Rg.c.l2_done == Rc.c.l2_done
+    assert (Rg.c.l2_initial_cost, Rg.c.l2_final_cost) == (0.0, 0.0)
+    # and inside a batch, beside an ordinary window
+    Ps = [synth_ba.make_window(6, 60, inv_depth=True, seed=5, outlier_frac=1.0), synth_ba.make_window(9, 300, inv_depth=True, seed=41)]
+    Pcs = [p.copy() for p in Ps]
+    Rb = local_ba.Optimizer(ctx).localBA_batch(Ps)
+    for k in range(2):
+        _compare(Ps[k], Rb[k], Pcs[k], oracle.ba_solve(Pcs[k]))
