@@ -16,19 +16,22 @@
 //
 // HBM layout (one workspace per batch, reused across calls through the ctx):
 //   rows (= residual blocks) sorted by (landmark, observing pose), SoA: type / pose / landmark / F-block ids /
-//   measurement; per row storage of the robustified, Jacobi-scaled jacobian: res[2], Je[2e], Jf[2 cells][2x6]
+//   measurement; per row storage of the robustified, UNSCALED jacobian: res[2], Je[2e], U[2x6] (ONE pose block: the
+//   anchor-pose block of an anchored row is -U; the consumers apply the Jacobi scale of the column as they read)
 //   landmark CSR row_ptr[n_e+1]; S (reduced camera system) dense column-major m x m (m = 6 * free poses), lower
-//   triangle authoritative; all reductions that decide accept/reject (cost, model change, norms) are two-stage and
-//   order-fixed => bitwise reproducible; S / rhs / pose column norms are accumulated with f64 atomics after a
-//   per-(landmark,pose) pre-aggregation in registers (order-dependent at the 1e-16 level only).
+//   triangle authoritative; every reduction (cost, model change, norms, S, rhs, column norms) has one writer per element
+//   and a fixed summation order => bitwise reproducible, independent of the batch a window shares.
 //
-// Kernels:  ba_eval (residual + analytic jacobian + Huber corrector + Jacobi scaling)  -> rows
-//           ba_colnorm (per landmark: E column norms/gradient direct, F side aggregated + atomics)
-//           ba_schur (per landmark: E'E, inverse, rhs, F'F and (E'F)'(E'E)^-1(E'F) blocks -> S)
-//           ba_chol (one workgroup, left-looking blocked Cholesky in LDS, rhs carried as an extra row; back solve)
-//           ba_backsub (per landmark: y_e, then J*step and the model cost change)
-//           ba_plus (SE3 left update / additive), ba_flag (chi2 + depth flags), ba_reduce (ordered sums)
-// No MFMA: the dense contractions are 6x6 / 6x1 / 6x3 blocks (latency- and atomics-bound).
+// Kernels:  ba_eval (residual + analytic jacobian + Huber corrector)  -> rows
+//           ba_colnorm16 / ba_pose_normal (column norms, gradient, F'F per pose: whatever only changes with the jacobian)
+//           bs_landmark + bs_gather (per landmark: (E'E + D)^-1 and the Schur cells; per pose / pose pair: the blocks of S)
+//           ba_chol (one workgroup per window, left-looking blocked Cholesky in LDS, rhs carried as an extra row; back solve)
+//           ba_backsub16 (per landmark: y_e, then J*step and the model cost change)
+//           ba_plus (SE3 left update / additive), ba_flag (chi2 + depth flags), ba_winreduce (ordered sums + the
+//           per-window trust-region state machine); bb_* / bs_* structure kernels build the program on the device;
+//           bb_gather / bb_scatter serve device-resident callers (ov2_ba_solve_batch_dev)
+// MFMA only in the multi-workgroup Cholesky's SYRK (v_mfma_f64_16x16x4_f64): the other contractions are 6x6 / 6x1 / 6x3
+// blocks and every kernel of an LM round waits on memory (SQ counters: 52-82 % of the wave cycles, scripts/profile_ba_sq.sh).
 #include "ov2_internal.h"
 
 #include <hipcub/hipcub.hpp>
@@ -306,7 +309,7 @@ __device__ inline double block_sum_256(double v, double *sh)
 // ------------------------------------------------------------------------------------------------------
 // K_EVAL: residual (+ jacobian), loss, corrector, Jacobi scaling; cost partial per workgroup
 
-// The solver's kernels are few, short waves on a high-priority stream that share their CUs with the front-end's long
+// The solver's kernels are few, short waves that share their CUs with the front-end's long
 // KLT waves: raising the wave priority lets them win the SIMD issue arbitration instead of taking turns
 // (s_setprio is per wave and costs one scalar instruction; measured: 467 -> 475 LM it/s concurrent, front-end unchanged).
 #ifndef BA_WAVE_PRIO
