@@ -340,7 +340,7 @@ __device__ __forceinline__ bool win_runs(const ba_win &W, int mode)
 // workgroup b covers 256 rows of ONE window (virtual blocks: a window with r rows owns ceil(r / 256) of them), so the
 // cost partial part[b] belongs to one window and a window's partials are summed in the order a lone solve would use
 template <bool JAC, int E>
-__global__ __launch_bounds__(256) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
                                                       const double *__restrict__ lms, int mode, double huber_a,
                                                       double *__restrict__ part)
 {
