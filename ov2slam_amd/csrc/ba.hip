@@ -1621,14 +1621,19 @@ __global__ __launch_bounds__(256) void bb_winranges_kernel(ba_raw R, const int *
 // bitwise reproducible, and the 10 M f64 atomics per iteration of the previous form (its bound: atomic request rate)
 // are gone.
 
+template <int E> struct cell_rec { static constexpr int STRIDE = (E == 1) ? 8 : 22; };   // doubles per cell record (16-byte multiples)
+
 struct ba_cells {
     const int *cell_ptr;      // n_e + 1
     const int *cell_f;        // pose block of the cell
     const int *cell_row;      // first row of its run, -1 = anchor cell (always the last cell of its landmark)
     const int *cell_lm;       // landmark block of the cell
     const int *cell_rank;     // position of the cell in the pose-major order (cells of a pose are contiguous there)
-    // per cell, stored at its pose-major position: W = F'E (6E), W (E'E + D)^-1 (6E), W (E'E + D)^-1 E'b (6)
-    double *Wm, *Wie, *Wg;
+    // per cell, one record at its pose-major position: V = W L (6E doubles) with W = F'E and (E'E + D)^-1 = L L' (a scalar
+    // root for inverse depths, a 3 x 3 Cholesky factor for XYZ), then h = L' E'b (E doubles).  The Schur complement is
+    // symmetric in V: S[hi, lo] -= V_hi V_lo', rhs -= V h -- one 64-byte (E = 1) / 176-byte (E = 3) record per cell
+    // instead of W, W (E'E + D)^-1 and W (E'E + D)^-1 E'b (144 / 336 bytes), and both sides of a pair read the same array.
+    double *V;
     const int2 *qrow;         // pose-major position of an observing cell -> (first row, rows) of its run in the sorted rows
 };
 
@@ -1801,28 +1806,42 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const int c0 = C.cell_ptr[l], nc = C.cell_ptr[l + 1] - c0;
     const bool has_anchor = nc > 0 && C.cell_row[c0 + nc - 1] < 0;
     const int nobs = has_anchor ? nc - 1 : nc;
-    // writes W, W ie, W ieg of one cell at its pose-major position
+    // L with (E'E + D)^-1 = L L' and h = L' E'b (the same for every cell of the landmark)
+    double Lf[E * E], hv[E];
+    if (E == 1) {
+        Lf[0] = sqrt(ie[0]);
+        hv[0] = Lf[0] * g[0];
+    } else {
+        const double l00 = sqrt(ie[0]), l10 = ie[3] / l00, l20 = ie[6] / l00;
+        const double l11 = sqrt(ie[4] - l10 * l10), l21 = (ie[7] - l20 * l10) / l11;
+        const double l22 = sqrt(ie[8] - l20 * l20 - l21 * l21);
+        Lf[0] = l00; Lf[1] = 0.0; Lf[2] = 0.0; Lf[3] = l10; Lf[4] = l11; Lf[5] = 0.0; Lf[6] = l20; Lf[7] = l21; Lf[8] = l22;
+        for (int cc = 0; cc < E; ++cc) {
+            double sacc = 0.0;
+            for (int k = cc; k < E; ++k) sacc += Lf[k * E + cc] * g[k];
+            hv[cc] = sacc;
+        }
+    }
+    // writes the record (V = W L | h) of one cell at its pose-major position
     auto store_cell = [&](int cell, const double *Wk) {
-        const size_t q = (size_t)C.cell_rank[cell];
-        double T[6 * E], wg[6];
+        constexpr int CS = cell_rec<E>::STRIDE;
+        double rec[CS];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double sg = 0.0;
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int cc = 0; cc < E; ++cc) {
                 double w = 0.0;
 #pragma unroll
-                for (int k = 0; k < E; ++k) w += Wk[i * E + k] * ie[k * E + cc];
-                T[i * E + cc] = w;
+                for (int k = cc; k < E; ++k) w += Wk[i * E + k] * Lf[k * E + cc];
+                rec[i * E + cc] = w;
             }
 #pragma unroll
-            for (int k = 0; k < E; ++k) sg += Wk[i * E + k] * ieg[k];
-            wg[i] = sg;
-        }
+        for (int cc = 0; cc < E; ++cc) rec[6 * E + cc] = hv[cc];
 #pragma unroll
-        for (int i = 0; i < 6 * E; ++i) { C.Wm[q * 6 * E + i] = Wk[i]; C.Wie[q * 6 * E + i] = T[i]; }
+        for (int i = 7 * E; i < CS; ++i) rec[i] = 0.0;
+        double2 *dst = reinterpret_cast<double2 *>(C.V + (size_t)C.cell_rank[cell] * CS);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) C.Wg[q * 6 + i] = wg[i];
+        for (int i = 0; i < CS / 2; ++i) dst[i] = make_double2(rec[2 * i], rec[2 * i + 1]);
     };
     // observing cells: ONE LANE PER CELL -- the lane walks the (one or two) rows of its run once.  (F'Fa, the coupling of
     // an observing pose with the landmark's anchor pose, is not materialised: the gather forms it from the same rows.)
@@ -1890,20 +1909,24 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = 0.0;
     for (int q = pcell_ptr[f] + tid; q < pcell_ptr[f + 1]; q += 256) {
-        const double *W = C.Wm + (size_t)q * 6 * E, *T = C.Wie + (size_t)q * 6 * E;
-        double w[6 * E], t6[6 * E];
-#pragma unroll
-        for (int i = 0; i < 6 * E; ++i) { w[i] = W[i]; t6[i] = T[i]; }
+        constexpr int CS = cell_rec<E>::STRIDE;
+        double v[CS];
+        load_d2<CS>(C.V + (size_t)q * CS, v);
 #pragma unroll
         for (int t = 0; t < 21; ++t) {
             const int i = c_tri_i[t], j = c_tri_j[t];
             double p = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < E; ++cc) p += t6[i * E + cc] * w[j * E + cc];
+            for (int cc = 0; cc < E; ++cc) p += v[i * E + cc] * v[j * E + cc];
             acc[t] -= p;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] -= C.Wg[(size_t)q * 6 + i];
+        for (int i = 0; i < 6; ++i) {
+            double p = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < E; ++cc) p += v[i * E + cc] * v[6 * E + cc];
+            acc[21 + i] -= p;
+        }
     }
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
@@ -1949,8 +1972,9 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
         if (in) {
             const size_t qh = (size_t)(eh & 0x7fffffff), ql = (size_t)(el & 0x7fffffff);
             double T[6 * E], Wl[6 * E];
-            {   // 16-byte loads: the records are 48 E bytes, 16-byte aligned
-                const double2 *th = reinterpret_cast<const double2 *>(C.Wie + qh * 6 * E), *wl = reinterpret_cast<const double2 *>(C.Wm + ql * 6 * E);
+            {   // the V part of the two records (16-byte loads)
+                constexpr int CS = cell_rec<E>::STRIDE;
+                const double2 *th = reinterpret_cast<const double2 *>(C.V + qh * CS), *wl = reinterpret_cast<const double2 *>(C.V + ql * CS);
 #pragma unroll
                 for (int i = 0; i < 3 * E; ++i) { const double2 a = th[i], b = wl[i]; T[2 * i] = a.x; T[2 * i + 1] = a.y; Wl[2 * i] = b.x; Wl[2 * i + 1] = b.y; }
             }
@@ -2424,7 +2448,7 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
         size_t tbytes = std::max(std::max(t1, t2), t4);
         {   // the structure lives in its own block, sized now that the counts are known and kept across solves
-            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + 8 + (size_t)(12 * e + 6) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
+            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + 8 + (size_t)(e == 1 ? cell_rec<1>::STRIDE : cell_rec<3>::STRIDE) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
                                  (size_t)pair_cap * 12 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
             if (need2 > c->ba_arena2_cap) {
                 OV2_HIP(c, hipStreamSynchronize(st));
@@ -2438,7 +2462,7 @@ ov2_status build_program(ba_solver &S)
         }
         size_t off2 = 0;
         AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot); AL3(cell_rank, C_tot);
-        AL3(Cc.Wm, (size_t)C_tot * 6 * e); AL3(Cc.Wie, (size_t)C_tot * 6 * e); AL3(Cc.Wg, (size_t)C_tot * 6);
+        AL3(Cc.V, (size_t)C_tot * (e == 1 ? cell_rec<1>::STRIDE : cell_rec<3>::STRIDE));
         int2 *qrow;
         AL3(qrow, C_tot);
         AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
