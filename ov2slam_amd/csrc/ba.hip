@@ -629,10 +629,30 @@ __global__ __launch_bounds__(256) void ba_accept_kernel(ba_dev d, const int *__r
 // ------------------------------------------------------------------------------------------------------
 // K_COLNORM helpers / scaling
 
+// lower-triangle element order of a symmetric 6x6 block
+__constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+__constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+__constant__ signed char c_tri_diag[6] = {0, 6, 11, 15, 18, 20};
+
+// Jacobi scale of every column from the norms of the FIRST jacobian, and in the same pass what the unscaled norms /
+// gradient / F'F become under it (column i scales by s_i: squared norm by s_i^2, gradient entry by s_i, F'F entry (i, j) by
+// s_i s_j) -- the column-norm kernels are not run a second time over the rows at iteration zero.
 __global__ void ba_make_scale_kernel(ba_dev d)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d.nc) d.scale[i] = 1.0 / (1.0 + sqrt(d.sqn[i]));
+    if (i >= d.nc) return;
+    const double s = 1.0 / (1.0 + sqrt(d.sqn[i]));
+    d.scale[i] = s;
+    d.sqn[i] = d.sqn[i] * s * s;
+    d.grad[i] = d.grad[i] * s;
+    const int ne = d.n_e * d.e;
+    if (i >= ne && (i - ne) % 6 == 0) {   // first column of a pose block also rescales the block's F'F; the six scales are
+        const int f = (i - ne) / 6;       // re-derived from its diagonal (= the unscaled squared norms, touched by this thread only)
+        double *FF = d.FFp + (size_t)f * 21;
+        double sf[6];
+        for (int c = 0; c < 6; ++c) sf[c] = 1.0 / (1.0 + sqrt(FF[c_tri_diag[c]]));
+        for (int t = 0; t < 21; ++t) FF[t] = FF[t] * sf[c_tri_i[t]] * sf[c_tri_j[t]];
+    }
 }
 
 // LevenbergMarquardtStrategy::ComputeStep :76-89, per window (blockIdx.y)
@@ -749,10 +769,6 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
         for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
 }
 
-// lower-triangle element order of a symmetric 6x6 block
-__constant__ signed char c_tri_i[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-__constant__ signed char c_tri_j[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-__constant__ signed char c_tri_diag[6] = {0, 6, 11, 15, 18, 20};
 
 // Normal-equation pieces of the pose (F) columns that only change with the jacobian: one workgroup per free pose
 // gathers its (row, cell) entries through the pose -> entries CSR and forms F'F (lower triangle, 21 values: its diagonal
@@ -2569,10 +2585,9 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     eval(true, S.xp, S.xl, EV_ZERO);
     colnorm(EV_ZERO);
     if (lo.jacobi) {
+        // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): the kernel also turns the
+        // norms, the gradient and F'F into those of the scaled jacobian; the tolerance test unscales the gradient on the fly
         BA_LAUNCH(S, K_SCALE, ba_make_scale_kernel, dim3((d.nc + 255) / 256), dim3(256), 0, st, d);
-        // the LM diagonal is taken from the SCALED jacobian (levenberg_marquardt_strategy.cc:82): the norms again, now
-        // with the scale in place; the gradient is the scaled one, the tolerance test unscales it on the fly
-        colnorm(EV_ZERO);
     }
     BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_JAC>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm, part_model,
               1, o->initial_radius, 0);
