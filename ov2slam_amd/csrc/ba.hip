@@ -94,7 +94,10 @@ struct ba_dev {
     const int *row_ptr;            // n_e + 1
     const int *lm_of_e, *pose_of_f;
     // jacobian storage
-    double *res, *Je, *U;   // per row: residual, landmark block, pose block (2 x 6) of the robustified, UNSCALED jacobian
+    // per row: residual, landmark block and the 2 x 3 block G of the robustified, UNSCALED jacobian; the 2 x 6 pose block of
+    // a row is U = [-G | G x p] (p = the landmark's world point, kept once per landmark block in wpt): 48 bytes per row
+    // instead of 96.  The anchor-pose block of an anchored inverse-depth row is -U, zero for every other type.
+    double *res, *Je, *G, *wpt;
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
     double *rhs, *iete, *ieg;
@@ -192,7 +195,7 @@ __device__ inline void se3_plus(const double *x, const double *d, double *out)
 // one residual block: r, local jacobians, chi2, depth sign  (src/ceres_parametrization.cpp, 5 functors)
 
 struct row_eval {
-    double r[2], Jk[12], Jl[6], chi2;   // the anchor-pose block of an anchored row is -Jk: not formed
+    double r[2], G[6], wp[3], Jl[6], chi2;   // pose block = [-G | G x wp]; the anchor-pose block of an anchored row is its negative
     bool depth_pos;
 };
 
@@ -256,16 +259,10 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
     double JR[6];
     for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c) JR[3 * r + c] = Jc[3 * r] * M[c] + Jc[3 * r + 1] * M[3 + c] + Jc[3 * r + 2] * M[6 + c];
-    for (int i = 0; i < 12; ++i) o.Jk[i] = 0.0;
-    for (int i = 0; i < 6; ++i) o.Jl[i] = 0.0;
-    if (type != OV2_BA_RANCH_INV) {
-        for (int r = 0; r < 2; ++r) {
-            const double a = JR[3 * r], b = JR[3 * r + 1], c = JR[3 * r + 2];
-            const double h0 = b * wpt[2] - c * wpt[1], h1 = c * wpt[0] - a * wpt[2], h2 = a * wpt[1] - b * wpt[0];
-            o.Jk[6 * r + 0] = -inv_sigma * a; o.Jk[6 * r + 1] = -inv_sigma * b; o.Jk[6 * r + 2] = -inv_sigma * c;
-            o.Jk[6 * r + 3] = inv_sigma * h0; o.Jk[6 * r + 4] = inv_sigma * h1; o.Jk[6 * r + 5] = inv_sigma * h2;
-        }
-    }
+    for (int i = 0; i < 6; ++i) { o.G[i] = 0.0; o.Jl[i] = 0.0; }
+    for (int i = 0; i < 3; ++i) o.wp[i] = wpt[i];
+    if (type != OV2_BA_RANCH_INV)   // d r / d (left se3 increment of Twc) = [-G | G x p], G = J_r / sigma (p = world point)
+        for (int i = 0; i < 6; ++i) o.G[i] = inv_sigma * JR[i];
     if (inv) {
         double jl[3];
         if (type == OV2_BA_RANCH_INV) {
@@ -361,9 +358,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             constexpr int e = E;
             d.res[2 * row] = 0.0; d.res[2 * row + 1] = 0.0;
             for (int cc = 0; cc < 2 * e; ++cc) d.Je[(size_t)row * 2 * e + cc] = 0.0;
-            double2 *U2 = reinterpret_cast<double2 *>(d.U + (size_t)row * 12);
+            double2 *G2 = reinterpret_cast<double2 *>(d.G + (size_t)row * 6);
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) U2[cc] = make_double2(0.0, 0.0);
+            for (int cc = 0; cc < 3; ++cc) G2[cc] = make_double2(0.0, 0.0);
         }
     } else if (row < W.row1) {
         row_eval ev;
@@ -385,13 +382,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             constexpr int e = E;   // compile-time: the Jl accesses below must not become scratch-backed dynamic indexing
             if (use_loss) {
                 if (asn == 0.0) {
-                    for (int i = 0; i < 12; ++i) ev.Jk[i] *= sqrt_rho1;
+                    for (int i = 0; i < 6; ++i) ev.G[i] *= sqrt_rho1;
                     for (int i = 0; i < 2 * e; ++i) ev.Jl[i] *= sqrt_rho1;
                 } else {
-                    for (int cc = 0; cc < 6; ++cc) {
-                        const double rtj = ev.Jk[cc] * ev.r[0] + ev.Jk[6 + cc] * ev.r[1];
-                        ev.Jk[cc] = sqrt_rho1 * (ev.Jk[cc] - asn * ev.r[0] * rtj);
-                        ev.Jk[6 + cc] = sqrt_rho1 * (ev.Jk[6 + cc] - asn * ev.r[1] * rtj);
+                    for (int cc = 0; cc < 3; ++cc) {   // the corrector mixes the two rows of a block: the same mix of the rows of G
+                        const double rtj = ev.G[cc] * ev.r[0] + ev.G[3 + cc] * ev.r[1];
+                        ev.G[cc] = sqrt_rho1 * (ev.G[cc] - asn * ev.r[0] * rtj);
+                        ev.G[3 + cc] = sqrt_rho1 * (ev.G[3 + cc] - asn * ev.r[1] * rtj);
                     }
                     for (int cc = 0; cc < e; ++cc) {
                         const double rtj = ev.Jl[cc] * ev.r[0] + ev.Jl[e + cc] * ev.r[1];
@@ -403,14 +400,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
             d.res[2 * row] = ev.r[0];
             d.res[2 * row + 1] = ev.r[1];
-            // Stored UNSCALED: the consumers apply the Jacobi scaling of the column as they read (the same product the
-            // scaled store made, so nothing changes numerically).  The anchor-pose block of an anchored inverse-depth row
-            // is exactly -Jk (ceres_parametrization.cpp: the two blocks differ by sign only) and zero for every other
-            // type, so ONE 2 x 6 block per row is kept: 96 bytes instead of 192.
+            // Stored UNSCALED (the consumers apply the Jacobi scaling of the column as they read) and as the 2 x 3 block G: the
+            // pose block is [-G | G x p] with the landmark's world point p, written once per landmark block.
             for (int cc = 0; cc < 2 * e; ++cc) d.Je[(size_t)row * 2 * e + cc] = ev.Jl[cc];
-            double2 *U2 = reinterpret_cast<double2 *>(d.U + (size_t)row * 12);   // 96-byte rows: six 16-byte stores
+            double2 *G2 = reinterpret_cast<double2 *>(d.G + (size_t)row * 6);   // 48-byte rows: three 16-byte stores
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) U2[cc] = make_double2(ev.Jk[2 * cc], ev.Jk[2 * cc + 1]);
+            for (int cc = 0; cc < 3; ++cc) G2[cc] = make_double2(ev.G[2 * cc], ev.G[2 * cc + 1]);
+            if (d.type[row] != OV2_BA_RANCH_INV) {   // every such row of a landmark holds the same point (same anchor, same depth)
+                const int eb = d.eb[row];
+                for (int k = 0; k < 3; ++k) d.wpt[(size_t)eb * 3 + k] = ev.wp[k];
+            }
         }
     }
     const double tot = block_sum_256(c, sh);
@@ -719,6 +718,19 @@ __device__ __forceinline__ void load_d2(const double *__restrict__ p, double *ou
     for (int i = 0; i < N / 2; ++i) { const double2 v = q[i]; out[2 * i] = v.x; out[2 * i + 1] = v.y; }
 }
 
+// the 2 x 6 pose block of row r: U = [-G | G x p], p = world point of the row's landmark block
+__device__ __forceinline__ void load_U(const ba_dev &d, size_t r, const double *__restrict__ p, double *U)
+{
+    double G[6];
+    load_d2<6>(d.G + r * 6, G);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double a = G[3 * k], b = G[3 * k + 1], c = G[3 * k + 2];
+        U[6 * k] = -a; U[6 * k + 1] = -b; U[6 * k + 2] = -c;
+        U[6 * k + 3] = b * p[2] - c * p[1]; U[6 * k + 4] = c * p[0] - a * p[2]; U[6 * k + 5] = a * p[1] - b * p[0];
+    }
+}
+
 __device__ __forceinline__ double row_sum(double v)
 {
     v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
         const int ent = pose_ent[k], r = ent >> 1;
         double J[12], bb[2];
-        load_d2<12>(d.U + (size_t)r * 12, J);
+        load_U(d, (size_t)r, d.wpt + (size_t)d.eb[r] * 3, J);
         load_d2<2>(d.res + 2 * (size_t)r, bb);
         // the pose's block of this row, Jacobi-scaled; as the row's anchor pose (entry bit 0) the block is -U
 #pragma unroll
@@ -835,14 +847,15 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
-    double acc[E], se[E];
+    double acc[E], se[E], wp[3];
     for (int i = 0; i < E; ++i) { acc[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
+    for (int i = 0; i < 3; ++i) wp[i] = live ? d.wpt[(size_t)l * 3 + i] : 0.0;
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
             const double *Je = d.Je + (size_t)r * 2 * E;
             double Uu[12];
-            load_d2<12>(d.U + (size_t)r * 12, Uu);
+            load_U(d, (size_t)r, wp, Uu);
             double sj0 = d.res[2 * r], sj1 = d.res[2 * r + 1];
             const int fk = d.fk[r], fa = d.fa[r];
             if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; sj0 -= (Uu[c] * sk) * z; sj1 -= (Uu[6 + c] * sk) * z; }
@@ -863,7 +876,7 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
         if (r < r1) {
             const double *Je = d.Je + (size_t)r * 2 * E;
             double Uu[12];
-            load_d2<12>(d.U + (size_t)r * 12, Uu);
+            load_U(d, (size_t)r, wp, Uu);
             double m0 = 0.0, m1 = 0.0;
             for (int i = 0; i < E; ++i) { m0 -= (Je[i] * se[i]) * y[i]; m1 -= (Je[E + i] * se[i]) * y[i]; }
             const int fk = d.fk[r], fa = d.fa[r];
@@ -1787,9 +1800,10 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
-    double ete[E * E], g[E], se[E];
+    double ete[E * E], g[E], se[E], wp[3];
     for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
     for (int i = 0; i < E; ++i) { g[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
+    for (int i = 0; i < 3; ++i) wp[i] = live ? d.wpt[(size_t)l * 3 + i] : 0.0;
     for (int base = r0; base < r1; base += 16) {
         const int r = base + sub;
         if (r < r1) {
@@ -1870,7 +1884,7 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
         for (int i = 0; i < 6; ++i) sk[i] = sf[fk * 6 + i];
         for (int r2 = C.cell_row[c0 + c]; r2 < r1 && d.fk[r2] == fk; ++r2) {
             double J2[12], Je2[2 * E];
-            load_d2<12>(d.U + (size_t)r2 * 12, J2);
+            load_U(d, (size_t)r2, wp, J2);
             load_d2<2 * E>(d.Je + (size_t)r2 * 2 * E, Je2);
 #pragma unroll
             for (int i = 0; i < 6; ++i) { J2[i] *= sk[i]; J2[6 + i] *= sk[i]; }
@@ -1892,7 +1906,7 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
             const int r = base + sub;
             if (r < r1 && d.fa[r] >= 0) {
                 double Ja[12], Je[2 * E];
-                load_d2<12>(d.U + (size_t)r * 12, Ja);
+                load_U(d, (size_t)r, wp, Ja);
                 load_d2<2 * E>(d.Je + (size_t)r * 2 * E, Je);
                 for (int i = 0; i < 6; ++i) { Ja[i] = -(Ja[i] * sa[i]); Ja[6 + i] = -(Ja[6 + i] * sa[i]); }
                 for (int k = 0; k < E; ++k) { Je[k] *= se[k]; Je[E + k] *= se[k]; }
@@ -2006,14 +2020,14 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
             // an entry in which one of the two cells is the landmark's anchor cell adds F'Fa = sum over the observing cell's
             // rows of (its pose block)' (the anchor's block); the anchor block of a row is -U, so whichever of hi / lo
             // observes, element (i of hi, j of lo) is -((U s_hi)_i (U s_lo)_j) summed over the two residual components.
-            // Formed here from the one or two 96-byte rows of the run, lane-parallel like the rest of the entry (nothing
+            // Formed here from the one or two 48-byte rows of the run, lane-parallel like the rest of the entry (nothing
             // materialised per cell: the 288-byte F'Fa records were the largest store of the whole Schur complement).
             if (!(dbg & 4) && (eh < 0 || el < 0)) {
                 const int2 rr = C.qrow[el < 0 ? qh : ql];
-                const double *Ur = d.U + (size_t)rr.x * 12;
-                for (int k = 0; k < rr.y; ++k, Ur += 12) {
+                const double *wp = d.wpt + (size_t)d.eb[rr.x] * 3;   // the rows of a cell belong to one landmark
+                for (int k = 0; k < rr.y; ++k) {
                     double Uu[12], H[12], L[12];
-                    load_d2<12>(Ur, Uu);
+                    load_U(d, (size_t)(rr.x + k), wp, Uu);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         H[i] = Uu[i] * s_hi[i]; H[6 + i] = Uu[6 + i] * s_hi[i];
@@ -2415,7 +2429,8 @@ ov2_status build_program(ba_solver &S)
     const int nr = d.n_rows;
 #undef AL
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
-    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(U, 12 * (size_t)nr);
+    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(G, 6 * (size_t)nr); AL(wpt, 3 * (size_t)d.n_e + 3);
+    OV2_HIP(c, hipMemsetAsync(d.wpt, 0, (3 * (size_t)d.n_e + 3) * sizeof(double), st));
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
     AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e); AL(FFp, (size_t)d.n_f * 21);
     AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);
