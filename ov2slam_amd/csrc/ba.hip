@@ -2076,7 +2076,16 @@ __global__ __launch_bounds__(256) void bs_gather_kernel(ba_dev d, ba_cells C, co
     __shared__ double red[4][27];
     if ((dbg_only & 3) && (((dbg_only & 3) == 1) != ((int)blockIdx.x < d.n_f))) return;   // timing experiments: 1 = diagonal part only, 2 = pairs only
     if ((int)blockIdx.x < d.n_f) bs_diag_block<E>(d, C, pcell_ptr, blockIdx.x, red);
-    else bs_pair_block<E>(d, C, *n_pairs, pair_key, seg_start, pent, fb, ((int)blockIdx.x - d.n_f) * 4 + (int)(threadIdx.x >> 6), dbg_only);
+    else {
+        // Consecutive pairs share their `hi` pose, i.e. they re-read the same run of cell records; workgroups are dealt
+        // round-robin to the eight XCDs, so the pair blocks are renumbered to give every XCD a contiguous range of pairs
+        // (its L2 then holds the runs its pairs share).  The host rounds the grid's pair blocks up to a multiple of 8.
+        const int np = *n_pairs, pb = (int)blockIdx.x - d.n_f;
+        const int npb = (((np + 3) >> 2) + 7) & ~7;   // pair blocks that have work (the grid is sized for an upper bound), a multiple of 8
+        if (pb >= npb) return;
+        const int blk = (pb & 7) * (npb >> 3) + (pb >> 3);
+        bs_pair_block<E>(d, C, np, pair_key, seg_start, pent, fb, blk * 4 + (int)(threadIdx.x >> 6), dbg_only);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2612,7 +2621,7 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
         // ---- ComputeTrustRegionStep
         BA_LAUNCH(S, K_LMDIAG, ba_lmdiag_sinit_kernel, dim3((unsigned)((S.cover_max + 255) / 256), B), dim3(256), 0, st, d, lo.min_d, lo.max_d);
         {
-            const long long gblocks = (long long)d.n_f + (S.pair_cap + 3) / 4;
+            const long long gblocks = (long long)d.n_f + (((S.pair_cap + 3) / 4 + 7) / 8) * 8;   // pair blocks: a multiple of 8 (XCD renumbering)
             if (e == 1) {
                 BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, g_lm, dim3(256), 0, st, d, S.cells);
                 if (gblocks > 0)
