@@ -90,7 +90,8 @@ struct ba_dev {
     const unsigned char *type;
     const int *pose, *lm, *anch;   // global pose / landmark / anchor-pose indices (anch = -1 for XYZ)
     const int *eb, *fk, *fa;       // reduced-program block ids (fk/fa = -1: constant or absent)
-    const double *uv, *inv_sigma, *auv;  // measurement, 1/sigma, anchor pixel per ROW (copied for coalescing)
+    const double *uv, *inv_sigma;  // measurement, 1/sigma per row
+    const double *lm_auv;          // anchor pixel per LANDMARK (batch-wide index): the rows of a landmark sit in adjacent lanes, one line serves them
     const int *row_ptr;            // n_e + 1
     const int *lm_of_e, *pose_of_f;
     // jacobian storage
@@ -211,8 +212,8 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
     double wpt[3] = {0, 0, 0}, anchpt[3] = {0, 0, 0}, Rwa[9], zanch = 0.0;
     if (inv) {
         zanch = 1.0 / lms[l];
-        anchpt[0] = zanch * ((d.auv[2 * row] - wc.Kl[2]) / wc.Kl[0]);
-        anchpt[1] = zanch * ((d.auv[2 * row + 1] - wc.Kl[3]) / wc.Kl[1]);
+        anchpt[0] = zanch * ((d.lm_auv[2 * (size_t)l] - wc.Kl[2]) / wc.Kl[0]);
+        anchpt[1] = zanch * ((d.lm_auv[2 * (size_t)l + 1] - wc.Kl[3]) / wc.Kl[1]);
         anchpt[2] = zanch;
         if (type != OV2_BA_RANCH_INV) {
             double twa[3];
@@ -1519,7 +1520,7 @@ __global__ __launch_bounds__(256) void bb_keys_kernel(ba_raw R, const ba_win *__
 }
 
 struct ba_prog_out {   // the writable twins of the const program arrays in ba_dev
-    unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa; double *uv, *isg, *auv; int *rows, *row_win;
+    unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa; double *uv, *isg; int *rows, *row_win;
 };
 
 __global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const u64 *__restrict__ keys,
@@ -1544,8 +1545,6 @@ __global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const u64 *__res
     O.fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[pa] : -1;
     O.uv[2 * r] = R.uv[2 * i]; O.uv[2 * r + 1] = R.uv[2 * i + 1];
     O.isg[r] = 1.0 / (R.sigma ? R.sigma[i] : 1.0);
-    O.auv[2 * r] = R.inv_depth ? R.lm_auv[2 * l] : 0.0;
-    O.auv[2 * r + 1] = R.inv_depth ? R.lm_auv[2 * l + 1] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void bb_rowptr_kernel(const int *__restrict__ eb, const u64 *__restrict__ hdr,
@@ -2361,7 +2360,7 @@ ov2_status build_program(ba_solver &S)
     AL(lm_of_e, L); AL(pose_of_f, NP); AL(win_of_e, L); AL(win_of_f, NP); AL(vb_start, B + 1);
     AL(keys, n); AL(keys2, n); AL(pk, 2 * (size_t)n); AL(pk2, 2 * (size_t)n);
     AL(O.type, n); AL(O.pose, n); AL(O.lm, n); AL(O.anch, n); AL(O.eb, n); AL(O.fk, n); AL(O.fa, n);
-    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.auv, 2 * (size_t)n); AL(O.rows, n); AL(O.row_win, n);
+    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.rows, n); AL(O.row_win, n);
     AL(row_ptr, L + 1); AL(pose_ptr, NP + 1); AL(pose_ent, 2 * (size_t)n);
     rows = O.rows;
     // row keys: [landmark block : bits(L)] [pose block + 1 : fb] [residual index : nbits], one dead bit above
@@ -2432,7 +2431,7 @@ ov2_status build_program(ba_solver &S)
         if (cov > S.cover_max) S.cover_max = (int)std::min<long long>(cov, 0x7fffffff);
     }
     d.type = O.type; d.pose = O.pose; d.lm = O.lm; d.anch = O.anch; d.eb = O.eb; d.fk = O.fk; d.fa = O.fa;
-    d.uv = O.uv; d.inv_sigma = O.isg; d.auv = O.auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
+    d.uv = O.uv; d.inv_sigma = O.isg; d.lm_auv = R.lm_auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
     d.row_win = O.row_win; d.win_of_e = win_of_e; d.win_of_f = win_of_f; d.vb_start = vb_start;
     S.rows = rows; S.pose_ptr = pose_ptr; S.pose_ent = pose_ent;
     const int nr = d.n_rows;
