@@ -507,19 +507,37 @@ struct BaWorkerNative {
         return (pose0_d || !np) && (lm0_d || !nl) && (Pd.res_uv || !nr);
     }
 
+    // a fresh copy of the window per job: the states of all jobs of a batch live in two contiguous device buffers that
+    // are re-filled from pre-replicated templates with two copies per batch (one copy per job and array was 128 small
+    // transfers in front of every batch of 64)
+    void *tmpl_pose_d = nullptr, *tmpl_lm_d = nullptr, *state_pose_d = nullptr, *state_lm_d = nullptr;
+    size_t state_cap = 0;
+
     bool dev_job_state(size_t nb)
     {
         const size_t e = P.inv_depth ? 1 : 3, pb = 7 * (size_t)P.n_pose * 8, lb = e * (size_t)P.n_lm * 8;
-        while (pose_d.size() < nb) {
-            void *a = nullptr, *b = nullptr;
-            if (ov2_dev_alloc(ctx, pb ? pb : 8, &a) != OV2_OK || ov2_dev_alloc(ctx, lb ? lb : 8, &b) != OV2_OK) return false;
-            owned_d.push_back(a); owned_d.push_back(b);
-            pose_d.push_back(a); lm_d.push_back(b);
+        if (nb > state_cap) {
+            const size_t cap = std::max<size_t>(nb, (size_t)max_batch);
+            std::vector<double> rp((size_t)7 * P.n_pose * cap), rl(e * (size_t)P.n_lm * cap);
+            for (size_t k = 0; k < cap; ++k) {
+                std::copy(pose0.begin(), pose0.end(), rp.begin() + k * pose0.size());
+                std::copy(lm0.begin(), lm0.end(), rl.begin() + k * lm0.size());
+            }
+            void *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+            const size_t bytes[4] = {pb * cap, lb * cap, pb * cap, lb * cap};
+            for (int i = 0; i < 4; ++i) {
+                if (ov2_dev_alloc(ctx, bytes[i] ? bytes[i] : 8, &bufs[i]) != OV2_OK) return false;
+                owned_d.push_back(bufs[i]);
+            }
+            if (pb && ov2_memcpy_h2d(ctx, bufs[0], rp.data(), pb * cap) != OV2_OK) return false;
+            if (lb && ov2_memcpy_h2d(ctx, bufs[1], rl.data(), lb * cap) != OV2_OK) return false;
+            tmpl_pose_d = bufs[0]; tmpl_lm_d = bufs[1]; state_pose_d = bufs[2]; state_lm_d = bufs[3];
+            state_cap = cap;
+            pose_d.assign(cap, nullptr); lm_d.assign(cap, nullptr);
+            for (size_t k = 0; k < cap; ++k) { pose_d[k] = (char *)state_pose_d + k * pb; lm_d[k] = (char *)state_lm_d + k * lb; }
         }
-        for (size_t k = 0; k < nb; ++k) {   // a fresh copy of the window per job, on the solver's stream
-            if (pb && ov2_memcpy_d2d(ctx, pose_d[k], pose0_d, pb) != OV2_OK) return false;
-            if (lb && ov2_memcpy_d2d(ctx, lm_d[k], lm0_d, lb) != OV2_OK) return false;
-        }
+        if (pb && ov2_memcpy_d2d(ctx, state_pose_d, tmpl_pose_d, pb * nb) != OV2_OK) return false;   // on the solver's stream
+        if (lb && ov2_memcpy_d2d(ctx, state_lm_d, tmpl_lm_d, lb * nb) != OV2_OK) return false;
         return true;
     }
 
