@@ -54,6 +54,10 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->ba_host = nullptr;
     c->ba_host_cap = 0;
     c->ba_copy_stream = nullptr;
+    c->klt_counts[0] = c->klt_counts[1] = nullptr;
+    c->klt_counts_words = 0;
+    c->klt_counts_cur = 0;
+    c->klt_counts_dirty = true;
     c->ba_copy_ev[0] = c->ba_copy_ev[1] = nullptr;
     c->ba_arena2 = nullptr;
     c->ba_arena2_cap = 0;
@@ -114,6 +118,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (c->scratch_dev) (void)hipFree(c->scratch_dev);
     if (c->ba_arena) (void)hipFree(c->ba_arena);
     if (c->ba_host) (void)hipHostFree(c->ba_host);
+    for (int i = 0; i < 2; ++i) if (c->klt_counts[i]) (void)hipFree(c->klt_counts[i]);
     if (c->ba_copy_stream) { (void)hipStreamSynchronize(c->ba_copy_stream); (void)hipStreamDestroy(c->ba_copy_stream); }
     for (int i = 0; i < 2; ++i) if (c->ba_copy_ev[i]) (void)hipEventDestroy(c->ba_copy_ev[i]);
     if (c->ba_arena2) (void)hipFree(c->ba_arena2);

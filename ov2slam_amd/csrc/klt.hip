@@ -1053,13 +1053,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned char *__restrict__ out_status,
                                                         const unsigned *__restrict__ counts, int *__restrict__ p3p_req,
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_c,
-                                                        const unsigned *__restrict__ cnt, int batch)
+                                                        const unsigned *__restrict__ cnt, int batch,
+                                                        unsigned *__restrict__ next_counts, int next_words)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
     using M = klt_map<KLT_GL>;
     constexpr int KLT_KPW = M::KPW;
     const int slot = M::slot((int)threadIdx.x), sub = M::sub((int)threadIdx.x);
     const bool lane_ok = M::lane_ok((int)threadIdx.x);
+    // this is the last kernel of a call: it leaves the OTHER counter buffer zeroed for the next call (nothing of this call
+    // reads it), so no memset sits in front of every frame's tracking chain
+    for (int q = blockIdx.x * 64 + threadIdx.x; q < next_words; q += gridDim.x * 64) next_counts[q] = 0u;
     // per-image tally of the first launch: its 64 slots shared out over the lanes of the group
     auto tally = [&](int b, int &n3, int &good) {
         n3 = 0; good = 0;
@@ -1252,13 +1256,31 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
     if (lanes != 3 && ((s = ov2_pyr_need_grad(c, prev)) != OV2_OK || (s = ov2_pyr_need_grad(c, cur)) != OV2_OK)) return s;
     const int B = prev->buf->batch;
     // scratch: [tallies B x 64 | list lengths (3)] zeroed per call, then the three keypoint lists
-    const size_t cnt_bytes = ((size_t)B * 64 + 16) * sizeof(unsigned);
+    // counters: [tallies B x 64 | list lengths (3)] in the ctx's double buffer (zeroed by the previous call's last kernel);
+    // scratch: the three keypoint lists
+    const size_t cnt_words = (size_t)B * 64 + 16;
+    if (cnt_words > c->klt_counts_words) {
+        OV2_HIP(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (c->klt_counts[i]) OV2_HIP(c, hipFree(c->klt_counts[i]));
+            c->klt_counts[i] = nullptr;
+        }
+        c->klt_counts_words = 0;
+        const size_t words = cnt_words + cnt_words / 2;
+        for (int i = 0; i < 2; ++i) OV2_HIP(c, hipMalloc((void **)&c->klt_counts[i], words * sizeof(unsigned)));
+        c->klt_counts_words = words;
+        c->klt_counts_dirty = true;
+    }
+    if (c->klt_counts_dirty)
+        for (int i = 0; i < 2; ++i) OV2_HIP(c, hipMemsetAsync(c->klt_counts[i], 0, c->klt_counts_words * sizeof(unsigned), c->stream));
+    c->klt_counts_dirty = true;   // until this call's last kernel is enqueued
     void *scr = nullptr;
-    s = ov2_scratch(c, cnt_bytes + 3 * (size_t)n * sizeof(int) + 256, &scr);
+    s = ov2_scratch(c, 3 * (size_t)n * sizeof(int) + 256, &scr);
     if (s != OV2_OK) return s;
-    unsigned *counts = (unsigned *)scr, *live_cnt = counts + (size_t)B * 64;
-    int *list_a = (int *)((char *)scr + cnt_bytes), *list_b = list_a + n, *list_c = list_b + n;
-    OV2_HIP(c, hipMemsetAsync(counts, 0, cnt_bytes, c->stream));
+    unsigned *counts = c->klt_counts[c->klt_counts_cur], *live_cnt = counts + (size_t)B * 64;
+    unsigned *next_counts = c->klt_counts[c->klt_counts_cur ^ 1];
+    const int next_words = (int)c->klt_counts_words;
+    int *list_a = (int *)scr, *list_b = list_a + n, *list_c = list_b + n;
     const dim3 cgrid((n + 255) / 256);
 #define KLT_STAGES_GL(W, G)                                                                                     \
     do {                                                                                                        \
@@ -1274,7 +1296,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
         OV2_LAUNCH(c, OV2_K_KLT_STAGE2, (klt_stage2_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_img_idx,   \
                    reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters, list_c,      \
-                   live_cnt, B);                                                                                \
+                   live_cnt, B, next_counts, next_words);                                                       \
     } while (0)
 #define KLT_STAGES(W)                                                                                           \
     do {                                                                                                        \
@@ -1294,5 +1316,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
 #undef KLT_STAGES
 #undef KLT_STAGES_GL
     OV2_HIP(c, hipGetLastError());
+    c->klt_counts_cur ^= 1;
+    c->klt_counts_dirty = false;
     return OV2_OK;
 }

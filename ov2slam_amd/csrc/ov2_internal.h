@@ -87,6 +87,10 @@ struct ov2_ctx {
     size_t ba_arena2_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)
     size_t ba_host_cap;
+    unsigned *klt_counts[2];             // tallies + list lengths of the two-stage KLT, double-buffered: the last kernel of a call
+    size_t klt_counts_words;             //   zeroes the OTHER buffer for the next call (no memset in front of every frame)
+    int klt_counts_cur;
+    bool klt_counts_dirty;               // a call did not run to its end: both buffers are zeroed again
     hipStream_t ba_copy_stream;          // second half of a batch upload (measurements) travels here while the program build sorts
     hipEvent_t ba_copy_ev[2];            // [0] head uploaded (main stream), [1] measurements uploaded (copy stream)
     int klt_lanes;                       // ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = forced lanes per keypoint
