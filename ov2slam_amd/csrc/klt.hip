@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned char *__restrict__ out_status,
                                                         unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_a,
-                                                        const int *__restrict__ list_b, const unsigned *__restrict__ cnt)
+                                                        const int *__restrict__ list_b, unsigned *__restrict__ cnt,
+                                                        int *__restrict__ list_c)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
     using M = klt_map<KLT_GL>;
@@ -1041,6 +1042,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
         // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
         // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
         if (is_a) atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
+    }
+    // the failures of list A are what the second launch re-tracks: appended to its list here (one atomic per wave that
+    // has any; the order of the list does not matter, every keypoint is tracked on its own) -- a compaction launch less
+    // in the frame's chain
+    const bool retry = act && sub == 0 && is_a && !ok;
+    const unsigned long long rm = __ballot(retry);
+    if (rm) {
+        const int lane = (int)threadIdx.x, leader = __ffsll((long long)rm) - 1;
+        int base = 0;
+        if (lane == leader) base = (int)atomicAdd(&cnt[2], (unsigned)__popcll(rm));
+        base = __shfl(base, leader);
+        if (retry) list_c[base + __popcll(rm & ((1ull << lane) - 1ull))] = i;
     }
 }
 
@@ -1290,9 +1303,7 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
         OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), dim3(tgrid.x + 1), dim3(64), 0, c->stream,   \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),              \
                    reinterpret_cast<const float2 *>(d_prior), d_img_idx, reinterpret_cast<float2 *>(d_out_xy),  \
-                   d_out_status, counts, d_iters, list_a, list_b, live_cnt);                                    \
-        OV2_LAUNCH(c, OV2_K_DETECT + 4, klt_compact_kernel, cgrid, dim3(256), 0, c->stream, n, 2, d_has_prior,  \
-                   d_out_status, d_iters, list_c, list_c, live_cnt, d_p3p_req, B);                              \
+                   d_out_status, counts, d_iters, list_a, list_b, live_cnt, list_c);                           \
         OV2_LAUNCH(c, OV2_K_KLT_STAGE2, (klt_stage2_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_img_idx,   \
                    reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters, list_c,      \
