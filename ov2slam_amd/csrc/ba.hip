@@ -610,6 +610,20 @@ __device__ __forceinline__ int win_of_index(const int *__restrict__ off, int B, 
     return lo;
 }
 
+// the same for a wave whose lanes hold ascending indices (i = first + lane): the bisection runs once, on the first
+// lane's index with wave-uniform (scalar) loads, and a lane past the end of that window steps forward
+__device__ __forceinline__ int win_of_index_asc(const int *__restrict__ off, int B, int i)
+{
+    const int i0 = __builtin_amdgcn_readfirstlane(i);
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i0) lo = mid; else hi = mid;
+    }
+    while (lo + 1 < B && off[lo + 1] <= i) ++lo;
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void ba_accept_kernel(ba_dev d, const int *__restrict__ pose_off,
                                                         const int *__restrict__ lm_off, double *__restrict__ xp,
                                                         const double *__restrict__ cp, double *__restrict__ xl,
@@ -1458,7 +1472,7 @@ __global__ __launch_bounds__(256) void bb_mark_kernel(ba_raw R, const ba_win *__
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R.n_res || !R.active[i]) return;
-    const int w = win_of_index(R.res_off, R.B, i);
+    const int w = win_of_index_asc(R.res_off, R.B, i);
     if (W[w].skip) return;
     const int nl = R.lm_off[w + 1] - R.lm_off[w], np = R.pose_off[w + 1] - R.pose_off[w];
     const int t = R.type[i], l = R.lm[i], p = R.pose[i];
@@ -1501,7 +1515,7 @@ __global__ __launch_bounds__(256) void bb_keys_kernel(ba_raw R, const ba_win *__
     bool a = i < R.n_res && R.active[i] != 0;
     u64 k = 1ull << dead_bit;
     if (a) {
-        const int w = win_of_index(R.res_off, R.B, i);
+        const int w = win_of_index_asc(R.res_off, R.B, i);
         if (W[w].skip) a = false;
         else {
             const int t = R.type[i];
