@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(256) void bb_scatter_kernel(const ba_gsrc *__restri
 }
 
 typedef unsigned long long u64;
-enum { BH_ROWS = 0, BH_NE, BH_NF, BH_ERR, BH_ENT, BH_VB, BH_MMAX, BH_STOT, BH_PAIRCAP, BH_N = 12 };
+enum { BH_ROWS = 0, BH_NE, BH_NF, BH_ERR, BH_ENT, BH_VB, BH_MMAX, BH_STOT, BH_PAIRCAP, BH_ROWSLOT = 12 /* 64 partial row counts */, BH_N = 12 + 64 };
 // sort keys of inactive residual blocks carry one bit above the live key bits: they sort behind every live key
 
 __global__ __launch_bounds__(256) void bb_mark_kernel(ba_raw R, const ba_win *__restrict__ W, int *__restrict__ used_lm,
@@ -1529,8 +1529,17 @@ __global__ __launch_bounds__(256) void bb_keys_kernel(ba_raw R, const ba_win *__
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (tot) atomicAdd(&hdr[BH_ROWS], (u64)tot);
+        // one of 64 slots per workgroup: 32 k same-address atomics serialise at ~10 ns each (they, not the key arithmetic,
+        // made this kernel 0.39 ms); bb_rows_kernel adds the slots up
+        if (tot) atomicAdd(&hdr[BH_ROWSLOT + (blockIdx.x & 63)], (u64)tot);
     }
+}
+
+__global__ __launch_bounds__(64) void bb_rows_kernel(u64 *__restrict__ hdr)
+{
+    u64 v = hdr[BH_ROWSLOT + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (threadIdx.x == 0) hdr[BH_ROWS] = v;
 }
 
 struct ba_prog_out {   // the writable twins of the const program arrays in ba_dev
@@ -2405,6 +2414,7 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipMemcpyAsync(hdr + BH_NE, escan + L, sizeof(int), hipMemcpyDeviceToDevice, st));
         OV2_HIP(c, hipMemcpyAsync(hdr + BH_NF, fscan + NP, sizeof(int), hipMemcpyDeviceToDevice, st));
         BA_LAUNCH(S, K_MISC, bb_keys_kernel, gn, dim3(256), 0, st, R, S.W, eidx, fidx, keys, hdr, nbits, fb, dead_bit);
+        BA_LAUNCH(S, K_MISC, bb_rows_kernel, dim3(1), dim3(64), 0, st, hdr);
         OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, keys2, n, nbits, dead_bit + 1, st));
         if (S.meas_pending) {   // the sorted rows take their measurements along: the second half of the upload must be in
             OV2_HIP(c, hipStreamWaitEvent(st, c->ba_copy_ev[1], 0));
@@ -2421,7 +2431,7 @@ ov2_status build_program(ba_solver &S)
     BA_LAUNCH(S, K_MISC, bb_winranges_kernel, dim3(1), dim3(256), 0, st, R, escan, fscan, O.row_win, hdr, S.W, vb_start);
     // sizes + the window ranges come back through the pinned mirror (its upload was enqueued before these copies)
     u64 *h_hdr = (u64 *)c->ba_host;
-    ba_win *h_W = (ba_win *)(h_hdr + 32);
+    ba_win *h_W = (ba_win *)(h_hdr + 128);   // behind the BH_N header words
     OV2_HIP(c, hipMemcpyAsync(h_hdr, hdr, sizeof(u64) * BH_N, hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipMemcpyAsync(h_W, S.W, sizeof(ba_win) * B, hipMemcpyDeviceToHost, st));
     OV2_HIP(c, hipStreamSynchronize(st));
