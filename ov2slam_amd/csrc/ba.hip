@@ -1335,12 +1335,13 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
         const bool at_cand = W.eval_at_cand != 0;
         row_eval ev;
         eval_row<false>(d, d.wc[w], at_cand ? cp : xp, at_cand ? cl : xl, row, ev);
+        // the per-residual outputs go to the ORIGINAL residual index (scattered 8- and 1-byte stores): written only when a
+        // window of the batch asked for them (null otherwise); the solver itself needs the dead byte of the sorted row
         const int i = rows[row];
-        chi2[i] = ev.chi2;
-        depth[i] = ev.depth_pos ? 1 : 0;
+        if (chi2) chi2[i] = ev.chi2;
+        if (depth) depth[i] = ev.depth_pos ? 1 : 0;
         if (ev.chi2 > chi2_th || !ev.depth_pos) {
-            active[i] = 0;
-            outlier[i] = (unsigned char)pass;
+            if (outlier) outlier[i] = (unsigned char)pass;
             d.dead[row] = 1;
             bad = true;
         } else {
@@ -1349,10 +1350,26 @@ __global__ __launch_bounds__(256) void ba_flag_kernel(ba_dev d, const double *__
             right = (t == OV2_BA_R_XYZ || t == OV2_BA_R_INV);
         }
     }
-    // tallies: one atomic per wave and counter when the wave sits inside one window (the usual case)
+    // tallies: the three counters of a window share a cache line and same-line atomics serialise, so they are summed over
+    // the workgroup first (one atomic per counter and workgroup when it sits inside one window -- the usual case; a
+    // workgroup that straddles a window boundary falls back to one atomic per wave / lane)
+    __shared__ int tal[3][4];
+    __shared__ int wfirst[4], wmixed[4];
+    const int wv = threadIdx.x >> 6;
     const int w0 = __builtin_amdgcn_readfirstlane(w);
-    if (__ballot(w != w0) == 0ull) {
-        const int nb = __popcll(__ballot(bad)), nl = __popcll(__ballot(left)), nr = __popcll(__ballot(right));
+    const bool mixed = __ballot(w != w0) != 0ull;
+    const int nb = __popcll(__ballot(bad)), nl = __popcll(__ballot(left)), nr = __popcll(__ballot(right));
+    if ((threadIdx.x & 63) == 0) { tal[0][wv] = nb; tal[1][wv] = nl; tal[2][wv] = nr; wfirst[wv] = w0; wmixed[wv] = mixed ? 1 : 0; }
+    __syncthreads();
+    const bool block_uniform = !(wmixed[0] | wmixed[1] | wmixed[2] | wmixed[3]) && wfirst[0] == wfirst[1] && wfirst[1] == wfirst[2] &&
+                               wfirst[2] == wfirst[3];
+    if (block_uniform) {
+        if (threadIdx.x < 3) {
+            const int tot = tal[threadIdx.x][0] + tal[threadIdx.x][1] + tal[threadIdx.x][2] + tal[threadIdx.x][3];
+            ba_win &W0 = d.W[wfirst[0]];
+            if (tot) atomicAdd(threadIdx.x == 0 ? &W0.nbad : (threadIdx.x == 1 ? &W0.n_left : &W0.n_right), tot);
+        }
+    } else if (!mixed) {
         if ((threadIdx.x & 63) == 0) {
             ba_win &W0 = d.W[w0];
             if (nb) atomicAdd(&W0.nbad, nb);
@@ -2207,6 +2224,7 @@ struct ba_solver {
     bool on_device = false;      // ov2_ba_solve_batch_dev: the problems' arrays and the per-residual outputs are device memory
     const ov2_ba_result *Rdev = nullptr;   // ... the results (for their output pointers)
     const ba_gsrc *gtab = nullptr;         // ... device table of the windows' arrays
+    bool want_chi2 = false, want_depth = false, want_out = false;   // some window of the batch asked for the per-residual output
     bool meas_pending = false;   // the measurement upload is still travelling on the copy stream (first program build waits for it)
 };
 
@@ -2721,7 +2739,8 @@ ov2_status enqueue_flags(ba_solver &S, int pass)
     ba_dev &d = S.d;
     if (d.n_rows == 0) return OV2_OK;
     BA_LAUNCH(S, K_FLAG, ba_flag_kernel, dim3((d.n_rows + 255) / 256), dim3(256), 0, S.c->stream, d, S.xp, S.xl, S.cp, S.cl, S.rows,
-              S.o->chi2_th, pass, S.chi2_dev, S.depth_dev, S.raw.active, S.outlier_dev);
+              S.o->chi2_th, pass, S.want_chi2 ? S.chi2_dev : nullptr, S.want_depth ? S.depth_dev : nullptr, S.raw.active,
+              S.want_out ? S.outlier_dev : nullptr);
     OV2_HIP(S.c, hipGetLastError());
     return OV2_OK;
 }
@@ -2779,6 +2798,7 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
     if (B < 0 || !P || !o || !R) return ov2_set_err(c, OV2_ERR_INVALID, "null problem/options/result");
     ba_solver S;
     S.c = c; S.B = B; S.P = P; S.o = o; S.on_device = on_device; S.Rdev = R;
+    for (int w = 0; w < B; ++w) { S.want_chi2 |= R[w].chi2 != nullptr; S.want_depth |= R[w].depth_positive != nullptr; S.want_out |= R[w].outlier != nullptr; }
     S.e = P[0].inv_depth ? 1 : 3;
     S.res_off.assign(B + 1, 0); S.lm_off.assign(B + 1, 0); S.pose_off.assign(B + 1, 0);
     long long tn = 0, tl = 0, tp = 0;
@@ -2909,8 +2929,7 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
         auto carve = [&](size_t bytes) { char *p = hb + off; off += (bytes + 255) / 256 * 256; return p; };
         ba_win *h_W = (ba_win *)carve(sizeof(ba_win) * B);
         double *h_xp = (double *)carve(7 * NP * 8), *h_xl = (double *)carve(e * L * 8);
-        bool want_chi2 = false, want_depth = false, want_out = false;
-        for (int w = 0; w < B; ++w) { want_chi2 |= R[w].chi2 != nullptr; want_depth |= R[w].depth_positive != nullptr; want_out |= R[w].outlier != nullptr; }
+        const bool want_chi2 = S.want_chi2, want_depth = S.want_depth, want_out = S.want_out;
         double *h_chi2 = want_chi2 ? (double *)carve(n * 8) : nullptr;
         unsigned char *h_depth = want_depth ? (unsigned char *)carve(n) : nullptr, *h_out = want_out ? (unsigned char *)carve(n) : nullptr;
         if (off > c->ba_host_cap) return ov2_set_err(c, OV2_ERR_NOMEM, "BA pinned mirror too small for the results");
