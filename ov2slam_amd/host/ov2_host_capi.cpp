@@ -480,7 +480,6 @@ struct BaWorkerNative {
     // device copy of the state -- what a device-side producer of the problems (the map mirror) hands over
     bool device_resident = false;
     ov2_ba_problem Pd{};                       // P with device pointers
-    void *pose0_d = nullptr, *lm0_d = nullptr;
     std::vector<void *> pose_d, lm_d, owned_d;
 
     bool dev_setup()
@@ -495,7 +494,6 @@ struct BaWorkerNative {
         };
         const size_t e = P.inv_depth ? 1 : 3, np = (size_t)P.n_pose, nl = (size_t)P.n_lm, nr = (size_t)P.n_res;
         Pd = P;
-        pose0_d = up(pose0.data(), 7 * np * 8); lm0_d = up(lm0.data(), e * nl * 8);
         Pd.pose_const = (const uint8_t *)up(P.pose_const, np);
         Pd.lm_anchor_pose = (const int32_t *)up(P.lm_anchor_pose, nl * 4);
         Pd.lm_anchor_uv = (const double *)up(P.lm_anchor_uv, 2 * nl * 8);
@@ -504,7 +502,8 @@ struct BaWorkerNative {
         Pd.res_lm = (const int32_t *)up(P.res_lm, nr * 4);
         Pd.res_uv = (const double *)up(P.res_uv, 2 * nr * 8);
         Pd.res_sigma = (const double *)up(P.res_sigma, nr * 8);
-        return (pose0_d || !np) && (lm0_d || !nl) && (Pd.res_uv || !nr);
+        (void)e;
+        return (Pd.res_uv || !nr) && (Pd.pose_const || !np) && (Pd.res_type || !nr);
     }
 
     // a fresh copy of the window per job: the states of all jobs of a batch live in two contiguous device buffers that
