@@ -171,13 +171,18 @@ __global__ __launch_bounds__(256) void clahe_lut_wave_kernel(const unsigned char
         for (int o = 32; o > 0; o >>= 1) over += __shfl_xor(over, o);
         const int clipped = over;
         const int batch = clipped / 256, residual = clipped - batch * 256;
-        int step = residual ? 256 / residual : 1;
+        // step = 256 / residual and bin / step by float reciprocals: for 0 <= a <= 256 and 1 <= b <= 256,
+        // floor(a / b) = (int)((a + 0.5f) * (1.0f / b)) exactly (the true quotient is at least 0.5 / 256 away from an
+        // integer boundary, the float error is below 1e-4) -- eight integer divisions of ~25 instructions each per lane gone
+        int step = residual ? (int)(256.5f * (1.0f / (float)residual)) : 1;
         if (step < 1) step = 1;
+        const float inv_step = 1.0f / (float)step;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int bin = 4 * lane + k;
             hv[k] += batch;
-            if (residual != 0 && bin % step == 0 && bin / step < residual) hv[k] += 1;
+            const int q = (int)(((float)bin + 0.5f) * inv_step);
+            if (residual != 0 && bin - q * step == 0 && q < residual) hv[k] += 1;
         }
     }
     // inclusive scan over the 256 bins
