@@ -439,6 +439,8 @@ typedef struct ov2_local_ba_setup {
     const int32_t *res_pose, *res_lm;
     const double *res_uv, *res_sigma;
     const int32_t *bad_lmid;         /* n_bad: MapPoint::isBad() landmarks met on the way (set_badlmids, :204-207) */
+    uint8_t *res_outlier;            /* device views only: n_res bytes of the map's block, zeroed by the set-up, for
+                                        ov2_ba_result.outlier of the solve (the update stage reads the flags there); NULL in the host form */
 } ov2_local_ba_setup;
 
 /* Replaces the set-up stage of Optimizer::localBA (src/optimizer.cpp:43-430) for the keyframe newkf:
@@ -453,6 +455,53 @@ typedef struct ov2_local_ba_setup {
 ov2_status ov2_map_local_ba_setup(ov2_map *m, int newkf, int nmin_covscore, int nmin_cst_kfs, int inv_depth,
                                   const double *calib_l /* fx fy cx cy: anchor depth needs no intrinsics; reserved */,
                                   ov2_local_ba_setup *out);
+
+/* The set-up stage for B maps of one context at once (one SLAM instance each: the Estimator threads of B sequences that
+ * have a keyframe pending, src/estimator.cpp:32-98).  Same result per map as ov2_map_local_ba_setup, but
+ *  - every kernel of the chain serves all B maps (map = blockIdx.y), the sizes a kernel needs come from device memory,
+ *    and NOTHING is synchronised until the B headers (16 ints per map) have been gathered: one synchronisation per call,
+ *  - the flat problems stay ON THE DEVICE: dev[b] holds DEVICE pointers (what ov2_ba_solve_batch_dev takes), valid until
+ *    the map's next set-up; dev[b].res_outlier is a zeroed n_res-byte array for the solve's outlier flags,
+ *  - a mostly dead observation table is squeezed BEFORE the chain (from the live count of the map's previous set-up), never
+ *    after it: the update stage needs this set-up's row indices.
+ * calib_l: B x 4 left intrinsics (fx fy cx cy) -- needed by the update stage of the inverse-depth form -- or NULL.
+ * newkf[b] = the new keyframe of map b.  A map may appear only once per call. */
+ov2_status ov2_map_local_ba_setup_batch(ov2_ctx *ctx, int B, ov2_map *const *maps, const int32_t *newkf, int nmin_covscore,
+                                        int nmin_cst_kfs, int inv_depth, const double *calib_l, ov2_local_ba_setup *dev);
+
+/* Replaces the update stage of Optimizer::localBA (src/optimizer.cpp:741-882) on the tables of B maps, from the flat
+ * problems of their last set-up (whose pose / lm arrays now hold the solved states) and the solve's per-block outlier
+ * flags d_outlier[b] (n_res device bytes, e.g. the set-up's res_outlier; NULL = nothing flagged):
+ *  - a flagged right-camera block demotes the observation to mono (Frame::removeStereoKeypointById, :743-751), a flagged
+ *    left block removes it (MapManager::removeMapPointObs(lmid, kfid), :753-764; for an observation of keyframe
+ *    cur_kfid[b] -- the current frame's, -1 = none -- MapPoint::isobs_ is cleared too, removeObsFromCurFrameById),
+ *  - the solved poses of the non-constant keyframes are stored (:767-786),
+ *  - per local landmark: MapPoint::isBad() / fewer than 3 observers, older than newkf - 3 and not in the current frame /
+ *    non-positive anchor depth -> MapManager::removeMapPoint; otherwise its new world point (inverse depth: Twc_anchor *
+ *    (K^-1 [u v 1] / rho) with the UPDATED anchor pose) via MapManager::updateMapPoint (:789-853),
+ *  - the second culling pass over set_badlmids (:856-882).
+ * MapPoint::kfid_ is taken to be the landmark's oldest observer (how MapManager::addMapPoint creates it and
+ * MapPoint::removeKfObs maintains it; mergeMapPoints is out of scope).
+ * out == NULL: fully asynchronous.  out != NULL: one synchronisation; out[b] lists what the host must replay on its own
+ * Frame / MapPoint objects (DEVICE arrays inside the map's block, valid until its next set-up; order arbitrary).
+ */
+typedef struct ov2_local_ba_update {
+    int32_t n_removed_lm, n_removed_obs, n_stereo_off;
+    const int32_t *removed_lmid;     /* MapManager::removeMapPoint(lmid) */
+    const int32_t *removed_obs;      /* pairs (kfid, lmid): MapManager::removeMapPointObs(lmid, kfid) */
+    const int32_t *stereo_off;       /* pairs (kfid, lmid): Frame::removeStereoKeypointById(lmid) on keyframe kfid */
+} ov2_local_ba_update;
+ov2_status ov2_map_local_ba_update_batch(ov2_ctx *ctx, int B, ov2_map *const *maps, const uint8_t *const *d_outlier,
+                                         const int32_t *cur_kfid, ov2_local_ba_update *out);
+
+/* Test / bench support.  ov2_map_save_state keeps a device copy of the mutable state of the tables (poses, landmark points
+ * and states, observation flags); ov2_map_restore_state_batch rewinds B maps to it in one launch, asynchronously (every
+ * bench job starts from the same noisy map, as a new keyframe of a live sequence would bring it).  ov2_map_download copies
+ * the tables to host arrays sized by the returned capacities (any pointer may be NULL; call once with NULLs for sizes). */
+ov2_status ov2_map_save_state(ov2_map *m);
+ov2_status ov2_map_restore_state_batch(ov2_ctx *ctx, int B, ov2_map *const *maps);
+ov2_status ov2_map_download(ov2_map *m, int *n_kf, int *n_lm, int *n_obs, double *kf_pose, uint8_t *kf_state, double *lm_xyz,
+                            uint8_t *lm_state, int32_t *obs_kf, int32_t *obs_lm, uint8_t *obs_flag, double *obs_uv, double *obs_ruv);
 
 /* The flat problem of the last set-up where the kernels left it ON THE DEVICE: `dev` = `host` with every array pointer
  * translated (same validity: until the next set-up call of this map).  These are the pointers ov2_ba_solve_batch_dev

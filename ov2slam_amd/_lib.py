@@ -82,6 +82,11 @@ SIGNATURES = {
     "ov2_map_obs_rows": (C.c_int, [vp, ip, ip, ip]),
     "ov2_map_local_ba_setup": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ov2_map_setup_device_view": (C.c_int, [vp, vp, vp]),
+    "ov2_map_local_ba_setup_batch": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ov2_map_local_ba_update_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "ov2_map_save_state": (C.c_int, [vp]),
+    "ov2_map_restore_state_batch": (C.c_int, [vp, C.c_int, vp]),
+    "ov2_map_download": (C.c_int, [vp, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ov2_triangulate_pairs": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,
                                         vp, vp, vp, vp]),
     "ov2_triangulate_pairs_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float,

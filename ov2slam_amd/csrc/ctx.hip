@@ -63,6 +63,8 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->ba_arena2_cap = 0;
     c->stage_host = c->stage_dev = nullptr;
     c->stage_cap = 0;
+    c->stage_ev = nullptr;
+    c->stage_ev_pending = false;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     // experiment hook: OV2_CU_SPLIT=k keeps the first k compute units of the device for the high-priority contexts
@@ -89,7 +91,8 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
         else e2 = hipStreamCreateWithPriority(&c->stream_pyr, hipStreamNonBlocking, high_priority ? prio_greatest : prio_least);
     }
     if (e1 != hipSuccess || e2 != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return OV2_ERR_HIP;
     }
@@ -126,6 +129,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    if (c->stage_ev) (void)hipEventDestroy(c->stage_ev);
     (void)hipStreamDestroy(c->stream);
     if (c->stream_pyr != c->stream) (void)hipStreamDestroy(c->stream_pyr);
     delete c;
@@ -219,6 +223,10 @@ ov2_status ov2_scratch(ov2_ctx *c, size_t bytes, void **out)
 
 ov2_status ov2_staging(ov2_ctx *c, size_t bytes, void **host, void **dev)
 {
+    if (c->stage_ev_pending) {   // an asynchronous call left an upload out of the pinned block in flight
+        OV2_HIP(c, hipEventSynchronize(c->stage_ev));
+        c->stage_ev_pending = false;
+    }
     if (bytes > c->stage_cap) {
         OV2_HIP(c, hipStreamSynchronize(c->stream));
         if (c->stage_host) OV2_HIP(c, hipHostFree(c->stage_host));

@@ -83,6 +83,8 @@ struct ov2_ctx {
     size_t ba_arena_cap;
     void *stage_host, *stage_dev;        // pinned staging block + its device twin for the host-pointer entry points
     size_t stage_cap;
+    hipEvent_t stage_ev;                 // recorded behind an asynchronous upload out of the pinned staging block;
+    bool stage_ev_pending;               //   ov2_staging waits for it before handing the block out again
     void *ba_arena2;                     // second device block: cell / pair structure of the Schur complement (sized after the build learns the counts)
     size_t ba_arena2_cap;
     void *ba_host;                       // pinned host mirror of the uploaded head of the arena (same offsets)

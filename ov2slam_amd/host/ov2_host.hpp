@@ -132,7 +132,11 @@ public:
     Vec3 getPoint() const { return ptxyz_; }
     std::set<int> getKfObsSet() const { return set_kfids_; }
     void addKfObs(int kfid) { set_kfids_.insert(kfid); }
-    void removeKfObs(int kfid) { set_kfids_.erase(kfid); }
+    void removeKfObs(int kfid)   // src/map_point.cpp:106-126 (descriptor bookkeeping aside): the anchor moves to the oldest observer left
+    {
+        if (!set_kfids_.erase(kfid) || set_kfids_.empty()) return;
+        if (kfid == kfid_) kfid_ = *set_kfids_.begin();
+    }
     bool isBad();   // src/map_point.cpp:215-234
 };
 

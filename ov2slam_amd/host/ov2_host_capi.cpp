@@ -249,6 +249,12 @@ int ov2h_map_attach_device(void *p, void *ctx, int max_kf, int max_lm, int max_o
     return (int)m->map->attachDevice((ov2_ctx *)ctx, max_kf, max_lm, max_obs);
 }
 
+// the ov2_map behind the host map (tests compare its tables with a map updated on the device)
+void *ov2h_map_device_handle(void *p) { return ((HostMap *)p)->map->dev_; }
+
+// MapManager::flushDevice: push the queued edits of the host objects to the device mirror
+int ov2h_map_flush_device(void *p) { return (int)((HostMap *)p)->map->flushDevice(); }
+
 // rows / capacity / compactions of the device mirror's observation table (ov2_map_obs_rows)
 int ov2h_map_device_rows(void *p, int *rows, int *capacity, int *compactions)
 {

@@ -28,6 +28,9 @@ def lib():
         L.ov2h_map_attach_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.ov2h_local_ba_setup_dev.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
         L.ov2h_map_device_rows.argtypes = [C.c_void_p, ip, ip, ip]
+        L.ov2h_map_device_handle.argtypes = [C.c_void_p]
+        L.ov2h_map_device_handle.restype = C.c_void_p
+        L.ov2h_map_flush_device.argtypes = [C.c_void_p]
         L.ov2h_set_distortion.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp]
         L.ov2h_undistort.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.ov2h_project_dist.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_float)]
@@ -155,6 +158,13 @@ class HostMap:
         out = (C.c_float * 2)()
         assert lib().ov2h_project_dist(self.h, int(cam), _dp(np.ascontiguousarray(pc, np.float64)), out) == 0
         return np.array([out[0], out[1]], np.float32)
+
+    def device_handle(self):
+        """the ov2_map* of the attached device mirror"""
+        return C.c_void_p(lib().ov2h_map_device_handle(self.h))
+
+    def flush_device(self):
+        assert lib().ov2h_map_flush_device(self.h) == 0
 
     def device_rows(self):
         """(rows, capacity, compactions) of the device mirror's observation table"""

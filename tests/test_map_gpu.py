@@ -245,3 +245,187 @@ def test_long_sequence_keeps_the_observation_table_bounded(ctx):
     assert got == (ref.aborted, ref.n_pose, ref.n_lm, ref.n_res) and not out.aborted and out.n_res > 1000
     L.ov2_map_destroy(m)
     L.ov2_map_destroy(f)
+
+
+# ---- batched, device-resident set-up (ov2_map_local_ba_setup_batch) and the device-side update stage ---------------
+from ov2slam_amd import device_map as DM   # noqa: E402
+from ov2slam_amd import local_ba   # noqa: E402
+
+
+def _f32(P):
+    """pixels rounded to float32, as Keypoint::unpx_ / runpx_ hold them (cv::Point2f)"""
+    Q = P.copy()
+    Q.res_uv = Q.res_uv.astype(np.float32).astype(np.float64)
+    if Q.lm_anchor_uv is not None:
+        Q.lm_anchor_uv = Q.lm_anchor_uv.astype(np.float32).astype(np.float64)
+    return Q
+
+
+def _single_setup(ctx, m, inv, nmin=25):
+    """ov2_map_local_ba_setup (one map, host form) as a dict keyed like device_map.fetch_view"""
+    out = DM.SetupC()
+    K = np.ascontiguousarray(synth_ba.K_L)
+    assert ctx.lib.ov2_map_local_ba_setup(m.h, m.newkf, nmin, 1, int(inv), K.ctypes.data, C.byref(out)) == 0
+    if out.aborted:
+        return dict(aborted=True)
+    e = 1 if inv else 3
+
+    def arr(ptr, shape, dt):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), (n,)).reshape(shape).copy() if n else np.zeros(shape, dt)
+    P, NL, R, NB = out.n_pose, out.n_lm, out.n_res, out.n_bad
+    kfid, lmid = arr(out.pose_kfid, (P,), np.int32), arr(out.lm_lmid, (NL,), np.int32)
+    anch = arr(out.lm_anchor_pose, (NL,), np.int32)
+    return dict(aborted=False, pose_kfid=kfid, pose_const=arr(out.pose_const, (P,), np.uint8), pose=arr(out.pose, (P, 7), np.float64),
+                lm_lmid=lmid, lm=arr(out.lm, (NL, e), np.float64), lm_anchor_kfid=np.where(anch >= 0, kfid[np.maximum(anch, 0)], -1),
+                lm_anchor_uv=arr(out.lm_anchor_uv, (NL, 2), np.float64), res_type=arr(out.res_type, (R,), np.uint8),
+                res_kfid=kfid[arr(out.res_pose, (R,), np.int32)], res_lmid=lmid[arr(out.res_lm, (R,), np.int32)],
+                res_uv=arr(out.res_uv, (R, 2), np.float64), res_sigma=arr(out.res_sigma, (R,), np.float64),
+                bad_lmid=np.sort(arr(out.bad_lmid, (NB,), np.int32)))
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_batched_setup_equals_single_calls(ctx, inv_depth):
+    """B maps of different sizes in one sync-free chain == B single calls, array for array (same kernels, map = blockIdx.y);
+    one of the maps aborts (too few 3D keypoints), one holds isBad() landmarks"""
+    shapes = [(8, 300), (30, 4000), (14, 900), (50, 10000), (3, 20), (20, 2000)]
+    probs = [synth_ba.make_window(k, l, inv_depth=inv_depth, seed=100 + k + l, max_obs=7) for k, l in shapes]
+    a = [DM.DeviceMap.from_problem(ctx, P, isobs="newest") for P in probs]
+    b = [DM.DeviceMap.from_problem(ctx, P, isobs="newest") for P in probs]
+    for P, ma, mb in zip(probs, a, b):   # a few landmarks down to ONE observer the current frame does not see: isBad()
+        kf, lm, _, _, _ = DM.observations_of(P)
+        cnt = np.bincount(lm, minlength=len(P.lm))
+        seen_now = np.zeros(len(P.lm), bool)
+        seen_now[lm[kf == len(P.pose) - 1]] = True
+        lonely = np.flatnonzero((cnt == 2) & ~seen_now)[:8]
+        first = np.array([np.flatnonzero(lm == l)[0] for l in lonely], np.int64)
+        if len(first):
+            for m in (ma, mb):
+                m.remove_obs(kf[first], lm[first])
+    views = DM.setup_batch(ctx, a, inv_depth=inv_depth, calib_l=synth_ba.K_L)
+    n_bad = 0
+    for k, (ma, mb, v) in enumerate(zip(a, b, views)):
+        got, ref = DM.fetch_view(ctx, v, inv_depth), _single_setup(ctx, mb, inv_depth)
+        assert got["aborted"] == ref["aborted"], k
+        if ref["aborted"]:
+            assert shapes[k] == (3, 20)
+            continue
+        for key in ref:
+            if key != "aborted":
+                assert np.array_equal(got[key], ref[key]), (k, key)
+        assert not got["outlier"].any()
+        n_bad += len(ref["bad_lmid"])
+        assert len(ref["res_type"]) > 100
+    assert n_bad > 0, "no isBad() landmark in any map: the bad list went untested"
+    # a second batched call on the same maps (scratch re-zeroed, blocks reused) gives the same problems again, minus the
+    # landmarks isBad() has meanwhile demoted (is3d_ cleared: src/map_point.cpp:219)
+    views2 = DM.setup_batch(ctx, a, inv_depth=inv_depth, calib_l=synth_ba.K_L)
+    for v1, v2 in zip(views, views2):
+        assert (v1.aborted, v1.n_pose, v1.n_res) == (v2.aborted, v2.n_pose, v2.n_res)
+
+
+def _solve_on_device(ctx, maps, views, proto, inv_depth):
+    pcs, rcs = DM.problems_of(views, proto, inv_depth)
+    o = local_ba.default_options()
+    st = ctx.lib.ov2_ba_solve_batch_dev(ctx.h, len(maps), pcs, C.byref(o), rcs)
+    assert st == 0, ctx.lib.ov2_last_error(ctx.h)
+    return rcs
+
+
+@pytest.mark.parametrize("inv_depth", [True, False])
+def test_device_update_equals_host_update(ctx, inv_depth):
+    """set-up -> solve -> update entirely on the device tables == Estimator::applyLocalBA of the C++ host mirror (hash-map
+    objects, updateAfterLocalBA = src/optimizer.cpp:741-882) followed by the flush of its edits: same poses, same
+    surviving landmarks with the same points and states, same surviving observations with the same stereo flags"""
+    P = _f32(synth_ba.make_window(14, 1200, inv_depth=inv_depth, seed=41, outlier_frac=0.08))
+    hm = host_map.HostMap(P)
+    hm.attach_device(ctx)
+    dm = DM.DeviceMap.from_problem(ctx, P, isobs="all")
+    # landmarks the current frame does not see any more (isobs_ = false) can be culled: every third one, on both sides
+    off = np.arange(0, len(P.lm), 3, dtype=np.int32)
+    for l in off:
+        hm.set_isobs(int(l), 0)
+    dm.set_landmarks(off, None, np.full(len(off), DM.LM_ALIVE | DM.LM_3D | DM.LM_KP3D, np.uint8))
+    hm.flush_device()
+    start = DM.canonical_state(dm.download())
+    _assert_states_close(DM.canonical_state(DM.DeviceMap.download(_Handle(ctx, hm.device_handle()))), start, 1e-13)
+
+    r = hm.apply_local_ba(ctx)
+    assert r[0] == 0 and r[1] > 0
+    hm.flush_device()
+    ref = DM.canonical_state(DM.DeviceMap.download(_Handle(ctx, hm.device_handle())))
+
+    views = DM.setup_batch(ctx, [dm], inv_depth=inv_depth, calib_l=P.calib_l)
+    rcs = _solve_on_device(ctx, [dm], views, P, inv_depth)
+    assert (rcs[0].n_outliers_pass1, rcs[0].n_outliers_pass2) == (r[1], r[2])
+    upd = DM.update_batch(ctx, [dm], views, cur_kfid=[dm.newkf])[0]
+    got = DM.canonical_state(dm.download())
+
+    _assert_states_close(ref, got, 1e-9)
+    kf_g, lm_g, ob_g = got
+    # what the device reports for replay is exactly the difference between the two states
+    kf_s, lm_s, ob_s = start
+    assert set(upd["removed_lmid"].tolist()) == set(lm_s) - set(lm_g)
+    assert len(upd["removed_lmid"]) > 0 and len(upd["removed_obs"]) > 0 and len(upd["stereo_off"]) > 0
+    gone = {(int(k), int(l)) for k, l in upd["removed_obs"]}
+    assert gone == {o for o in ob_s if o not in ob_g and o[1] in lm_g}
+    demoted = {(int(k), int(l)) for k, l in upd["stereo_off"]}
+    assert {o for o in ob_g if ob_s[o] and not ob_g[o]} <= demoted
+
+
+def _assert_states_close(ref, got, tol):
+    kf_r, lm_r, ob_r = ref
+    kf_g, lm_g, ob_g = got
+    assert sorted(kf_r) == sorted(kf_g)
+    for k in kf_r:
+        assert np.allclose(kf_r[k], kf_g[k], rtol=0, atol=tol), k
+    assert sorted(lm_r) == sorted(lm_g), "surviving landmarks differ"
+    for l in lm_r:
+        assert lm_r[l][1] == lm_g[l][1], (l, lm_r[l][1], lm_g[l][1])
+        assert np.allclose(lm_r[l][0], lm_g[l][0], rtol=tol, atol=tol), l
+    assert ob_r == ob_g, "surviving observations / stereo flags differ"
+
+
+class _Handle:
+    """a borrowed ov2_map* with DeviceMap's download()"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.L, self.h = ctx, ctx.lib, h
+    _p = staticmethod(DM.DeviceMap._p)
+
+
+def test_batch_of_distinct_windows_setup_solve_update_and_restore(ctx):
+    """the keyframe job of bench.py: B distinct maps -> batched set-up -> ov2_ba_solve_batch_dev on the device views ->
+    device update; every window's solve is bitwise the solve of the same flat problem alone, the update changes the
+    tables, ov2_map_restore_state_batch brings every table back, and the next job repeats the first bit for bit"""
+    shapes = [(10, 500, 0.02), (16, 1500, 0.10), (12, 900, 0.05), (7, 260, 0.15)]
+    probs = [synth_ba.make_window(k, l, inv_depth=True, seed=7 * k + l, outlier_frac=f) for k, l, f in shapes]
+    maps = [DM.DeviceMap.from_problem(ctx, P, isobs="newest") for P in probs]
+    for m in maps:
+        m.save_state()
+    before = [DM.canonical_state(m.download()) for m in maps]
+    views = DM.setup_batch(ctx, maps, calib_l=synth_ba.K_L)
+    flat = [DM.fetch_view(ctx, v, True) for v in views]
+    rcs = _solve_on_device(ctx, maps, views, probs[0], True)
+    logs = [[(i.cost, i.radius, i.step_is_successful) for i in r.log[:r.n_log]] for r in rcs]
+    solved = [DM.fetch_view(ctx, v, True) for v in views]
+    iters = [r.n_log for r in rcs]
+    assert len(set(iters)) > 1, "every window took the same number of LM iterations: not a ragged batch"
+    for k, (f, s) in enumerate(zip(flat, solved)):
+        # the same flat problem through the host form, alone
+        q = synth_ba.BaProblem(synth_ba.K_L, synth_ba.K_R, probs[0].T_rl, 1, f["pose"], f["pose_const"], f["lm"],
+                               np.searchsorted(f["pose_kfid"], f["lm_anchor_kfid"]).astype(np.int32), f["lm_anchor_uv"], f["res_type"],
+                               np.searchsorted(f["pose_kfid"], f["res_kfid"]).astype(np.int32),
+                               np.searchsorted(f["lm_lmid"], f["res_lmid"]).astype(np.int32), f["res_uv"], f["res_sigma"])
+        r1 = local_ba.Optimizer(ctx).localBA(q)
+        assert np.array_equal(q.pose.view(np.uint64), s["pose"].view(np.uint64)), k
+        assert np.array_equal(q.lm.view(np.uint64), s["lm"].view(np.uint64)), k
+        assert np.array_equal(r1.outlier, s["outlier"]), k
+    DM.update_batch(ctx, maps, views, want_lists=False)
+    after = [DM.canonical_state(m.download()) for m in maps]
+    assert all(a != b for a, b in zip(after, before))
+    DM.restore_state_batch(ctx, maps)
+    assert [DM.canonical_state(m.download()) for m in maps] == before
+    views = DM.setup_batch(ctx, maps, calib_l=synth_ba.K_L)
+    rcs2 = _solve_on_device(ctx, maps, views, probs[0], True)
+    assert [[(i.cost, i.radius, i.step_is_successful) for i in r.log[:r.n_log]] for r in rcs2] == logs
