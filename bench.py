@@ -53,7 +53,9 @@ def parse():
                     help="noise (px) of the motion-model priors; a harder stream (--frame-gap 9 --prior-sigma 3) makes every level "
                          "pass take more LK iterations (the executed mean is reported in config.lk_iterations_per_level_pass)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH cpu_baseline leg (1 thread, N threads)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the N-thread LK leg (0 = host CPU share, at most 16)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the N-thread LK leg (0 = every core this process may run on, SURVEY 8d; a 16-thread and a "
+                         "1-thread leg are reported beside it)")
     ap.add_argument("--instr-batches", type=int, default=300, help="frame-batches of the instrumented (per-kernel hipEvent) pass")
     ap.add_argument("--ba-kfs", type=int, default=50, help="keyframes in the local-BA window (north_star: ~50)")
     ap.add_argument("--ba-lms", type=int, default=10000, help="landmarks in the local-BA window")
@@ -70,8 +72,14 @@ def parse():
                          "134-136 k + 1810-1836, both high 138.9 k + 1736, both normal 140.8 k + 1760)")
     ap.add_argument("--ba-batch", type=int, default=64, help="most windows one ov2_ba_solve_batch call of a worker takes")
     ap.add_argument("--ba-host-windows", action="store_true",
-                    help="the local-BA windows cross PCIe on every solve (ov2_ba_solve_batch on host arrays) instead of being "
-                         "resident in HBM like every other input of the timed region (ov2_ba_solve_batch_dev)")
+                    help="legacy leg: ONE window replicated for every sequence, crossing PCIe on every solve (ov2_ba_solve_batch on "
+                         "host arrays), solve stage only")
+    ap.add_argument("--ba-replicated", action="store_true",
+                    help="legacy leg: ONE window replicated for every sequence, resident in HBM, solve stage only (the round-2 "
+                         "figure); the default is one DISTINCT device map per sequence with set-up + solve + update per job")
+    ap.add_argument("--ba-spread", type=float, default=0.2,
+                    help="the sequences' windows draw their keyframes / landmarks within +-spread of --ba-kfs / --ba-lms")
+    ap.add_argument("--gen-procs", type=int, default=0, help="processes that generate the synthetic windows (0 = host CPU share, at most 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pnp", action="store_true",
                     help="also run the per-frame pose refinement (ceresPnP, SURVEY 8f row 1) on kps 3D points per frame, "
@@ -241,6 +249,97 @@ class Workload:
         return is_kf
 
 
+class BaPipeline:
+    """the Estimator threads of the reference (src/estimator.cpp:32-98), one SLAM instance per sequence, each with its OWN
+    map: a device-resident ov2_map holding a distinct synthetic window (its own keyframe / landmark counts, outlier rate,
+    initial error).  A keyframe job is the WHOLE of Optimizer::localBA on that map: set-up (covisibility walk -> flat
+    problem, src/optimizer.cpp:43-430) -> solve (:439-735) -> update (:741-882), batched over every sequence that has a
+    keyframe pending (ov2_map_local_ba_setup_batch -> ov2_ba_solve_batch_dev -> ov2_map_local_ba_update_batch).  Every job
+    starts from the map's saved state (the stand-in for the mapper having just added the keyframe).  Native thread(s) of
+    libov2host.so on their own HIP context(s)."""
+
+    def __init__(self, fe, device, windows, specs, workers=1, max_batch=64, high_priority=False):
+        from ov2slam_amd import device_map as DM, host_map
+        self.DM, self.windows, self.specs = DM, windows, specs
+        seqs = len(windows)
+        workers = max(1, min(workers, seqs))
+        share = [seqs // workers + (1 if k < seqs % workers else 0) for k in range(workers)]
+        self.ctxs, self.maps, self.ws = [], [], []
+        i = 0
+        for k in range(workers):
+            c = fe.Context(device, high_priority=high_priority)
+            ms = [DM.DeviceMap.from_problem(c, P, isobs="newest") for P in windows[i:i + share[k]]]
+            for m in ms:
+                m.save_state()
+            i += share[k]
+            self.ctxs.append(c); self.maps.append(ms)
+        # the flat problems the set-up makes of these maps (sizes for the report; also the first use of every block)
+        self.flat = []
+        for c, ms in zip(self.ctxs, self.maps):
+            for v in DM.setup_batch(c, ms, calib_l=windows[0].calib_l):
+                self.flat.append(dict(aborted=bool(v.aborted), poses=int(v.n_pose), landmarks=int(v.n_lm), residual_blocks=int(v.n_res)))
+            DM.restore_state_batch(c, ms)
+            c.synchronize()
+        for c, ms in zip(self.ctxs, self.maps):
+            self.ws.append(host_map.EstimatorPipeline(c, ms, windows[0], max_batch=max_batch))
+        for w in self.ws:
+            w.submit_all()                        # warm-up (arenas, code objects); not counted
+        self.solves = self.iters = self.dropped = self.submitted = self.batches = 0
+        self.busy_s = 0.0
+        self.tot = {}
+        self.mode = (f"{workers} native worker thread(s), each on its own {'high' if high_priority else 'normal'}-priority HIP "
+                     f"context, concurrent with the front-end; every sequence owns a device-resident map (ov2_map) with a DISTINCT "
+                     f"window; a keyframe job = set-up + solve + update of Optimizer::localBA on that map; a worker serves all its "
+                     f"sequences that have a keyframe pending in one batch (<= {max_batch}): ov2_map_local_ba_setup_batch -> "
+                     f"ov2_ba_solve_batch_dev -> ov2_map_local_ba_update_batch; robust solve (<=5 it) + L2 (<=10 it); a newer "
+                     f"keyframe of a sequence replaces its pending one (src/estimator.cpp:185-210)")
+
+    def submit_all(self):
+        for w in self.ws:
+            w.submit_all()
+
+    def set_counting(self, on):
+        for w in self.ws:
+            w.set_counting(on)
+
+    def refresh(self):
+        tot = None
+        for w in self.ws:
+            st = w.stats()
+            if st["last_status"] != 0:
+                raise RuntimeError(f"the local-BA pipeline failed in the worker (status {st['last_status']})")
+            if tot is None:
+                tot = st
+            else:
+                for k, v in st.items():
+                    tot[k] = [x + y for x, y in zip(tot[k], v)] if isinstance(v, list) else tot[k] + v
+        self.solves, self.iters, self.dropped = tot["solves"], tot["iters"], tot["dropped"]
+        self.submitted, self.busy_s, self.batches = tot["submitted"], tot["busy_s"] / len(self.ws), tot["batches"]
+        self.tot = tot
+        return tot
+
+    def stop(self):
+        for w in self.ws:
+            w.close()
+
+    def flat_problems(self, k):
+        """the first k flat problems as host BaProblems (for the CPU leg); the workers must have been stopped"""
+        from ov2slam_amd.ba_types import BaProblem
+        DM, out = self.DM, []
+        c, ms = self.ctxs[0], self.maps[0][:k]
+        DM.restore_state_batch(c, ms)
+        P0 = self.windows[0]
+        for v in DM.setup_batch(c, ms, calib_l=P0.calib_l):
+            f = DM.fetch_view(c, v, True)
+            if f["aborted"]:
+                continue
+            out.append(BaProblem(P0.calib_l, P0.calib_r, P0.T_rl, 1, f["pose"], f["pose_const"], f["lm"],
+                                 np.searchsorted(f["pose_kfid"], f["lm_anchor_kfid"]).astype(np.int32), f["lm_anchor_uv"],
+                                 f["res_type"], np.searchsorted(f["pose_kfid"], f["res_kfid"]).astype(np.int32),
+                                 np.searchsorted(f["lm_lmid"], f["res_lmid"]).astype(np.int32), f["res_uv"], f["res_sigma"]))
+        return out
+
+
 class BaWorker:
     """the Estimator thread of the reference (src/estimator.cpp:32-98): runs Optimizer::localBA on the newest pending
     keyframe of any sequence, on its own high-priority HIP context/stream, concurrently with the front-end; a keyframe
@@ -249,6 +348,7 @@ class BaWorker:
     fought the front-end loop for the interpreter lock and made the frames/s depend on the host's load."""
 
     def __init__(self, device, seqs, n_kf, n_lm, seed, workers=1, max_batch=64, high_priority=True, device_resident=True):
+        """legacy legs (--ba-replicated / --ba-host-windows): one window for every sequence, solve stage only"""
         from ov2slam_amd import host_map, synth_ba
         self.P0 = synth_ba.make_window(n_kf, n_lm, inv_depth=True, seed=seed, max_obs=7)
         workers = max(1, min(workers, seqs))
@@ -335,6 +435,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    legacy_ba = a.ba_replicated or a.ba_host_windows
+    windows = specs = None
+    if not a.no_ba and not legacy_ba:
+        # one DISTINCT local-BA window per sequence (numpy; spawned worker processes, made before this process touches the GPU)
+        from ov2slam_amd import synth_ba
+        try:
+            share = len(os.sched_getaffinity(0))
+        except Exception:
+            share = os.cpu_count() or 1
+        procs = a.gen_procs if a.gen_procs > 0 else max(1, min(32, share // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+        specs = synth_ba.sequence_window_specs(a.seqs, seed=20211 + 100003 * rank, n_kf=a.ba_kfs, n_lm=a.ba_lms, spread=a.ba_spread)
+        t_gen = time.perf_counter()
+        windows = synth_ba.make_windows_parallel(specs, procs)
+        t_gen = time.perf_counter() - t_gen
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -359,9 +473,11 @@ def main():
     if a.pnp:
         wl.enable_pnp(seed=777 + rank)
     ba = None
-    if not a.no_ba:
+    if not a.no_ba and legacy_ba:
         ba = BaWorker(local, a.seqs, a.ba_kfs, a.ba_lms, seed=20211 + rank, workers=a.ba_workers, max_batch=a.ba_batch,
                       high_priority=a.ba_priority == "high", device_resident=not a.ba_host_windows)
+    elif not a.no_ba:
+        ba = BaPipeline(fe, local, windows, specs, workers=a.ba_workers, max_batch=a.ba_batch, high_priority=a.ba_priority == "high")
     def run_step():
         """one bench step = a.chunk frame-batches; returns the number of keyframe batches it held"""
         k = 0
@@ -423,11 +539,11 @@ def main():
         "keyframe_batches_per_frame_batch": nkf / nbatches,
         "timed_region_s": el_max,
     }
-    if ba:
+    if ba and legacy_ba:
         out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
                            "solves_per_sec": ba_solves_all / el_max, "solves": ba_solves_all,
                            "measured_over": "timed region (solves that started and completed inside it, concurrent with the "
-                                            "front-end)",
+                                            "front-end); LEGACY leg: one window replicated for every sequence, solve stage only",
                            "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
                            "replaced_fraction": (ba_drop_all / ba_sub_all) if ba_sub_all else 0.0,
                            "window": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "residual_blocks": int(ba.P0.n_res),
@@ -445,6 +561,48 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lb["value"] * it_bytes / 1e9 / HBM_PEAK_GBS,
                           "note": "LM iterations/s of all windows x algorithmic bytes of one iteration, concurrent with the front-end"}
         out["config"]["workload"] += f"; localBA on a {a.ba_kfs}-KF / {a.ba_lms}-landmark window per keyframe job"
+    elif ba:
+        T = ba.tot
+        ok = [f for f in ba.flat if not f["aborted"]]
+        rng3 = lambda key: [int(min(f[key] for f in ok)), float(np.mean([f[key] for f in ok])), int(max(f[key] for f in ok))]
+        nb = max(T["batches"], 1)
+        out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
+                           "solves_per_sec": ba_solves_all / el_max, "solves": ba_solves_all,
+                           "what_a_solve_is": "distinct windows, set-up + solve + update: one whole Optimizer::localBA on the "
+                                              "sequence's own device-resident map (src/optimizer.cpp:43-430 + 439-735 + 741-882)",
+                           "measured_over": "timed region (jobs that started and completed inside it, concurrent with the front-end)",
+                           "keyframe_jobs_submitted": ba_sub_all, "jobs_replaced_by_newer_kf": ba_drop_all,
+                           "replaced_fraction": (ba_drop_all / ba_sub_all) if ba_sub_all else 0.0,
+                           "windows": {"distinct": len(ba.flat), "aborted_setups": len(ba.flat) - len(ok),
+                                       "nominal": {"keyframes": a.ba_kfs, "landmarks": a.ba_lms, "spread": a.ba_spread},
+                                       "poses_min_mean_max": rng3("poses"), "landmarks_min_mean_max": rng3("landmarks"),
+                                       "residual_blocks_min_mean_max": rng3("residual_blocks"),
+                                       "outlier_fraction_min_max": [min(sp["outlier_frac"] for sp in specs), max(sp["outlier_frac"] for sp in specs)],
+                                       "parametrisation": "anchored inverse depth (buse_inv_depth: 1)",
+                                       "generated_in_s": t_gen},
+                           "lm_iterations_per_window": {"robust_histogram_0_to_7": T["hist_robust"], "l2_histogram_0_to_15": T["hist_l2"],
+                                                        "mean": (T["iters"] / T["solves"]) if T["solves"] else 0.0,
+                                                        "slowest_window_of_a_batch_mean": T["slowest_sum"] / nb,
+                                                        "note": "a batch runs as long as its slowest window: robust pass <= 5, L2 pass <= 10"},
+                           "workers_per_gpu": len(ba.ws), "batches": ba.batches,
+                           "windows_per_batch": (ba.solves / ba.batches) if ba.batches else 0.0,
+                           "ms_per_batch": {"setup_incl_state_restore": 1e3 * T["setup_s"] / nb, "solve": 1e3 * T["solve_s"] / nb,
+                                            "update_incl_final_sync": 1e3 * T["update_s"] / nb,
+                                            "setup_per_window": 1e3 * T["setup_s"] / max(T["solves"], 1)},
+                           "mode": ba.mode,
+                           "worker_busy_frac": (ba.busy_s / el) if el > 0 else 0.0}
+        # one LM iteration touches every residual block once (32 B record + 16 B residual + 208 B jacobian for
+        # the inverse-depth functors), S twice and the parameters once; summed over the windows actually iterated
+        mean_free = float(np.mean([f["poses"] - 1 for f in ok])) if ok else 0.0
+        mean_par = float(np.mean([7 * f["poses"] + f["landmarks"] for f in ok])) * 8.0 if ok else 0.0
+        bytes_all = T["iter_blocks"] * 256.0 + T["iters"] * (2.0 * (6 * mean_free) ** 2 * 8.0 + mean_par)
+        lb = out["local_ba"]
+        lb["roofline"] = {"bound": "hbm", "alg_bytes_total": bytes_all, "achieved": bytes_all / el / 1e9, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": bytes_all / el / 1e9 / HBM_PEAK_GBS,
+                          "note": "sum over the solved windows of LM iterations x algorithmic bytes of one iteration of THAT window "
+                                  "(256 B per residual block + S twice + parameters), over the timed region, concurrent with the front-end"}
+        out["config"]["workload"] += (f"; localBA (set-up + solve + update) per keyframe job on {len(ba.flat)} DISTINCT device-resident "
+                                      f"maps around {a.ba_kfs} KFs / {a.ba_lms} landmarks (+-{int(100 * a.ba_spread)} %)")
 
     if rank == 0 and not a.no_roofline:
         # second, instrumented pass over the same steps: every launch bracketed by hipEvents on the ctx stream
@@ -567,18 +725,24 @@ def main():
             share = len(os.sched_getaffinity(0))
         except Exception:
             share = os.cpu_count() or 1
-        nthr = a.cpu_threads if a.cpu_threads > 0 else max(1, min(share, 16))   # a one-GPU box gives 16 cores
-        fps1, nfr1, sec1 = cpu_baseline(wl, a.kf_every, a.cpu_seconds, threads=1)
-        fpsn, nfrn, secn = cpu_baseline(wl, a.kf_every, a.cpu_seconds, threads=nthr)
+        # one thread per host core this process may run on (OpenCV's parallel_for_ default); the 16-thread and the
+        # 1-thread figures beside it
+        nthr = a.cpu_threads if a.cpu_threads > 0 else max(1, share)
+        legs = {}
+        for t in sorted({1, min(16, nthr), min(64, nthr), nthr}):
+            fps, nfr, sec = cpu_baseline(wl, a.kf_every, a.cpu_seconds, threads=t)
+            legs[t] = {"value": fps, "unit": "frames/s", "cores": t, "sample": f"{nfr} frames ({sec:.1f} s), same build, {t} thread(s)"}
         build = "-O3 -march=native" if native else "-O2 (native build failed)"
+        fpsn = legs[nthr]["value"]
         out["cpu_baseline"] = {"value": fpsn, "unit": "frames/s", "cores": nthr, "kind": "port",
-                               "sample": f"{nfrn} frames of one sequence of the same workload ({secn:.1f} s), oracle/ C port of "
-                                         f"the OpenCV path built {build}, {nthr} threads over the points of every LK call and "
+                               "sample": legs[nthr]["sample"] + f" of one sequence of the same workload, oracle/ C port of "
+                                         f"the OpenCV path built {build}, threads split the points of every LK call and "
                                          "the rows / tiles of CLAHE, pyrDown and Scharr (cv::parallel_for_); host has "
                                          f"{os.cpu_count()} logical cores, {share} usable",
-                               "single_thread": {"value": fps1, "unit": "frames/s", "cores": 1,
-                                                 "sample": f"{nfr1} frames ({sec1:.1f} s), same build, 1 thread"}}
-    if do_cpu and ba:
+                               "single_thread": legs[1],
+                               "by_threads": {str(t): v for t, v in legs.items()},
+                               "best": max(legs.values(), key=lambda v: v["value"])}
+    if do_cpu and ba and legacy_ba:
         Pc = ba.P0.copy()
         t1 = time.perf_counter()
         Rc = O.ba_solve(Pc)
@@ -587,14 +751,35 @@ def main():
                                            "kind": "port", "sample": f"one solve of the same window ({dt:.2f} s), "
                                            "oracle/ C restatement of the Ceres LM + Schur path, 1 thread "
                                            "(the reference runs localBA with num_threads = 1, src/optimizer.cpp:460)"}
+    elif do_cpu and ba:
+        # the CPU port on the SAME distinct windows: the flat problems the device set-up makes of the first maps, solved one
+        # after the other by the oracle (1 thread: the reference runs localBA with num_threads = 1) until the budget is spent
+        try:
+            probs = ba.flat_problems(min(len(ba.flat), 48))
+            t1 = time.perf_counter()
+            its, nsolved = 0, 0
+            for Pc in probs:
+                Rc = O.ba_solve(Pc)
+                its += sum(Rc.summary()["iterations"]); nsolved += 1
+                if time.perf_counter() - t1 > a.cpu_seconds:
+                    break
+            dt = time.perf_counter() - t1
+            out["local_ba"]["cpu_baseline"] = {"value": its / dt, "unit": "iters/s", "solves_per_sec": nsolved / dt, "cores": 1,
+                                               "kind": "port",
+                                               "sample": f"the solve stage of the first {nsolved} of the same distinct windows "
+                                               f"({dt:.1f} s; the flat problems the device set-up produced), oracle/ C restatement "
+                                               "of the Ceres LM + Schur path, 1 thread (the reference runs localBA with "
+                                               "num_threads = 1, src/optimizer.cpp:460); set-up and update of the host mirror are in `setup`"}
+        except Exception as e:
+            out["local_ba"]["cpu_baseline"] = {"error": repr(e)}
     if do_cpu and ba:
-        # set-up stage of Optimizer::localBA on a map holding the same window: the reference-style hash-map walk (C++
-        # host mirror, this host's core) beside the scans of the device map mirror (whole call: scans, 2 syncs, D2H of
+        # set-up stage of Optimizer::localBA on a map holding one of the windows: the reference-style hash-map walk (C++
+        # host mirror, this host's core) beside the one-map form of the device scans (whole call: scans, 2 syncs, D2H of
         # the flat problem, host id maps).  Outside the timed region; reported, not part of `value`.
         try:
             import ctypes as C
             from ov2slam_amd import host_map
-            hm = host_map.HostMap(ba.P0)
+            hm = host_map.HostMap(ba.P0 if legacy_ba else windows[0])
             hm.attach_device(ctx)
             HL = host_map.lib()
             na, nb, nc = C.c_int(), C.c_int(), C.c_int()
@@ -606,9 +791,10 @@ def main():
                     fn(hm.h, hm.newkf, C.byref(na), C.byref(nb), C.byref(nc))
                 return 1e3 * (time.perf_counter() - t) / reps
             out["local_ba"]["setup"] = {"hash_map_walk_ms": t_setup(HL.ov2h_local_ba_setup),
-                                        "device_map_scans_ms": t_setup(HL.ov2h_local_ba_setup_dev),
+                                        "device_map_scans_one_map_ms": t_setup(HL.ov2h_local_ba_setup_dev),
                                         "problem": {"poses": na.value, "landmarks": nb.value, "residual_blocks": nc.value},
-                                        "note": "src/optimizer.cpp:43-430; walk = C++ mirror of the reference's maps on 1 host core"}
+                                        "note": "src/optimizer.cpp:43-430; walk = C++ mirror of the reference's maps on 1 host core; "
+                                                "the batched form inside the timed region is local_ba.ms_per_batch.setup_per_window"}
             del hm
         except Exception as e:   # the set-up comparison is a side report: never lose the bench line to it
             out["local_ba"]["setup"] = {"error": repr(e)}

@@ -549,7 +549,7 @@ struct BaWorkerNative {
     void loop()
     {
         size_t rr = 0;
-        bool dev_ready = false;
+        bool dev_ready = false, dev_failed = false, use_dev = false;
         std::vector<int> jobs;
         std::vector<std::vector<double>> poses, lms;   // per job: the window's own state (solved in place)
         std::vector<ov2_ba_problem> Ps;
@@ -569,22 +569,23 @@ struct BaWorkerNative {
                     cv.wait_for(lk, std::chrono::milliseconds(2));
                 }
                 counted = counting;   // a batch counts only if it started inside the counted region
+                use_dev = device_resident;   // latched under the mutex ov2h_ba_worker_set_device_resident takes
             }
             const size_t nb = jobs.size();
             if (poses.size() < nb) { poses.resize(nb); lms.resize(nb); }
             Ps.assign(nb, P);
             Rs.resize(nb);
             for (size_t k = 0; k < nb; ++k) {
-                if (!device_resident) {
+                if (!use_dev) {
                     poses[k] = pose0; lms[k] = lm0;
                     Ps[k].pose = poses[k].data(); Ps[k].lm = lms[k].data();
                 }
                 std::memset(&Rs[k], 0, sizeof(ov2_ba_result));
             }
-            if (device_resident && !dev_ready) dev_ready = dev_setup();
+            if (use_dev && !dev_ready && !dev_failed) { dev_ready = dev_setup(); dev_failed = !dev_ready; }   // a failed upload is not retried
             const auto t0 = std::chrono::steady_clock::now();
             ov2_status s;
-            if (device_resident) {
+            if (use_dev) {
                 s = OV2_ERR_NOMEM;
                 if (dev_ready && dev_job_state(nb)) {
                     Ps.assign(nb, Pd);
@@ -609,6 +610,186 @@ struct BaWorkerNative {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same Estimator threads with the WHOLE of Optimizer::localBA per keyframe job, on device-resident maps: every
+// sequence owns an ov2_map (its own keyframes / landmarks / observations, its own window size and outlier rate); a job is
+//     [the mapper's edits: here the map is rewound to its saved state, ov2_map_restore_state_batch]
+//     set-up   ov2_map_local_ba_setup_batch    src/optimizer.cpp:43-430   (one synchronisation for all pending maps)
+//     solve    ov2_ba_solve_batch_dev          :439-735                   (on the flat problems the set-up left in HBM)
+//     update   ov2_map_local_ba_update_batch   :741-882                   (on the tables, asynchronous)
+// and a batch ends with one synchronisation of the worker's context, so that the counted time closes over all three stages.
+// The context and the maps are created by the caller (on that context) and belong to this thread until it is destroyed.
+struct BaPipelineNative {
+    ov2_ctx *ctx = nullptr;
+    std::vector<ov2_map *> maps;
+    std::vector<int32_t> newkf;
+    std::vector<double> calib_l;   // nseq x 4
+    ov2_ba_problem proto{};
+    ov2_ba_options opt{};
+    int inv_depth = 1, max_batch = 64;
+    std::vector<uint8_t> pending;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread th;
+    bool stop = false, counting = false;
+    long long solves = 0, iters = 0, dropped = 0, submitted = 0, batches = 0, slowest_sum = 0, res_blocks = 0, aborted = 0, iter_blocks = 0;
+    long long hist_robust[8] = {0}, hist_l2[16] = {0};
+    double busy_s = 0.0, t_setup = 0.0, t_solve = 0.0, t_update = 0.0;
+    int last_status = 0;
+
+    void loop()
+    {
+        size_t rr = 0;
+        std::vector<int> jobs;
+        std::vector<ov2_map *> M;
+        std::vector<int32_t> nk;
+        std::vector<double> K;
+        std::vector<ov2_local_ba_setup> V;
+        std::vector<ov2_ba_problem> Ps;
+        std::vector<ov2_ba_result> Rs;
+        std::vector<const uint8_t *> outl;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double>(b - a).count();
+        };
+        for (;;) {
+            jobs.clear();
+            bool counted = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (stop) return;
+                    for (size_t k = 0; k < pending.size() && (int)jobs.size() < max_batch; ++k) {
+                        const size_t b = (rr + k) % pending.size();
+                        if (pending[b]) { pending[b] = 0; jobs.push_back((int)b); }
+                    }
+                    if (!jobs.empty()) { rr = ((size_t)jobs.back() + 1) % pending.size(); break; }
+                    cv.wait_for(lk, std::chrono::milliseconds(2));
+                }
+                counted = counting;   // a batch counts only if it started inside the counted region
+            }
+            const int nb = (int)jobs.size();
+            M.resize(nb); nk.resize(nb); K.resize(4 * (size_t)nb); V.resize(nb); Ps.resize(nb); Rs.resize(nb); outl.resize(nb);
+            for (int k = 0; k < nb; ++k) {
+                M[k] = maps[jobs[k]]; nk[k] = newkf[jobs[k]];
+                for (int q = 0; q < 4; ++q) K[4 * (size_t)k + q] = calib_l[4 * (size_t)jobs[k] + q];
+            }
+            const auto t0 = now();
+            ov2_status s = ov2_map_restore_state_batch(ctx, nb, M.data());
+            if (s == OV2_OK) s = ov2_map_local_ba_setup_batch(ctx, nb, M.data(), nk.data(), 25, 1, inv_depth, K.data(), V.data());
+            const auto t1 = now();
+            long long blocks = 0, nab = 0;
+            if (s == OV2_OK) {
+                for (int k = 0; k < nb; ++k) {
+                    const ov2_local_ba_setup &v = V[k];
+                    ov2_ba_problem &P = Ps[k];
+                    P = proto;
+                    for (int q = 0; q < 4; ++q) P.calib_l[q] = K[4 * (size_t)k + q];
+                    P.inv_depth = inv_depth;
+                    if (v.aborted) { P.n_pose = P.n_lm = P.n_res = 0; ++nab; }
+                    else { P.n_pose = v.n_pose; P.n_lm = v.n_lm; P.n_res = v.n_res; blocks += v.n_res; }
+                    P.pose = v.pose; P.pose_const = v.pose_const; P.lm = v.lm; P.lm_anchor_pose = v.lm_anchor_pose; P.lm_anchor_uv = v.lm_anchor_uv;
+                    P.res_type = v.res_type; P.res_pose = v.res_pose; P.res_lm = v.res_lm; P.res_uv = v.res_uv; P.res_sigma = v.res_sigma;
+                    std::memset(&Rs[k], 0, sizeof(ov2_ba_result));
+                    Rs[k].outlier = v.aborted ? nullptr : v.res_outlier;
+                    outl[k] = Rs[k].outlier;
+                }
+                s = ov2_ba_solve_batch_dev(ctx, nb, Ps.data(), &opt, Rs.data());
+            }
+            const auto t2 = now();
+            if (s == OV2_OK) s = ov2_map_local_ba_update_batch(ctx, nb, M.data(), outl.data(), nk.data(), nullptr);
+            if (s == OV2_OK) s = ov2_ctx_synchronize(ctx);
+            const auto t3 = now();
+            std::lock_guard<std::mutex> lk(mu);
+            last_status = s;
+            if (counted && counting && s == OV2_OK) {   // ... and finished inside it
+                ++batches;
+                int slowest = 0;
+                for (int k = 0; k < nb; ++k) {
+                    ++solves;
+                    const int n1 = Rs[k].n_log_robust > 0 ? Rs[k].n_log_robust - 1 : 0;
+                    const int n2 = Rs[k].l2_done ? Rs[k].n_log - Rs[k].n_log_robust - 1 : 0;
+                    iters += n1 + (n2 > 0 ? n2 : 0);
+                    hist_robust[n1 < 7 ? n1 : 7]++;
+                    hist_l2[n2 < 0 ? 0 : (n2 < 15 ? n2 : 15)]++;
+                    slowest = std::max(slowest, n1 + (n2 > 0 ? n2 : 0));
+                    iter_blocks += (long long)(n1 + (n2 > 0 ? n2 : 0)) * Ps[k].n_res;
+                }
+                slowest_sum += slowest; res_blocks += blocks; aborted += nab;
+                busy_s += sec(t0, t3); t_setup += sec(t0, t1); t_solve += sec(t1, t2); t_update += sec(t2, t3);
+            }
+        }
+    }
+};
+
+void *ov2h_ba_pipeline_create(void *ctx, int nseq, void *const *maps, const int *newkf, const double *calib_l, const ov2_ba_problem *proto,
+                              float robust_mono_th, int inv_depth, int max_batch)
+{
+    if (!ctx || nseq <= 0 || !maps || !newkf || !calib_l || !proto) return nullptr;
+    BaPipelineNative *w = new BaPipelineNative();
+    w->ctx = (ov2_ctx *)ctx;
+    w->maps.assign((ov2_map *const *)maps, (ov2_map *const *)maps + nseq);
+    w->newkf.assign(newkf, newkf + nseq);
+    w->calib_l.assign(calib_l, calib_l + 4 * (size_t)nseq);
+    w->proto = *proto;   // calibrations + extrinsic; the array pointers are replaced per job
+    w->inv_depth = inv_depth ? 1 : 0;
+    w->max_batch = max_batch > 0 ? max_batch : 1;
+    ov2_ba_default_options(&w->opt, robust_mono_th);
+    w->pending.assign((size_t)nseq, 0);
+    w->th = std::thread([w] { w->loop(); });
+    return w;
+}
+
+void ov2h_ba_pipeline_submit_all(void *p)
+{
+    BaPipelineNative *w = (BaPipelineNative *)p;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        for (auto &f : w->pending) {
+            if (f && w->counting) ++w->dropped;
+            f = 1;
+            if (w->counting) ++w->submitted;
+        }
+    }
+    w->cv.notify_one();
+}
+
+void ov2h_ba_pipeline_set_counting(void *p, int on)
+{
+    BaPipelineNative *w = (BaPipelineNative *)p;
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->counting = on != 0;
+}
+
+// out[40]: 0 solves, 1 LM iterations, 2 jobs replaced by a newer keyframe, 3 jobs submitted, 4 busy seconds, 5 last status,
+// 6 batches, 7 set-up s, 8 solve s, 9 update s, 10 sum over batches of the slowest window's iterations, 11 residual blocks solved,
+// 12 aborted set-ups, 13 sum over windows of LM iterations x residual blocks, 16..23 windows by robust iterations (0..7+), 24..39 windows by L2 iterations (0..15+)
+void ov2h_ba_pipeline_stats(void *p, double *out)
+{
+    BaPipelineNative *w = (BaPipelineNative *)p;
+    std::lock_guard<std::mutex> lk(w->mu);
+    for (int i = 0; i < 40; ++i) out[i] = 0.0;
+    out[0] = (double)w->solves; out[1] = (double)w->iters; out[2] = (double)w->dropped; out[3] = (double)w->submitted;
+    out[4] = w->busy_s; out[5] = (double)w->last_status; out[6] = (double)w->batches;
+    out[7] = w->t_setup; out[8] = w->t_solve; out[9] = w->t_update; out[10] = (double)w->slowest_sum; out[11] = (double)w->res_blocks;
+    out[12] = (double)w->aborted; out[13] = (double)w->iter_blocks;
+    for (int i = 0; i < 8; ++i) out[16 + i] = (double)w->hist_robust[i];
+    for (int i = 0; i < 16; ++i) out[24 + i] = (double)w->hist_l2[i];
+}
+
+// stops the thread; the context and the maps stay with the caller
+void ov2h_ba_pipeline_destroy(void *p)
+{
+    BaPipelineNative *w = (BaPipelineNative *)p;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+}
 
 void *ov2h_ba_worker_create(int device, const ov2_ba_problem *P, float robust_mono_th, int nseq, int max_batch, int high_priority)
 {

@@ -57,6 +57,12 @@ def lib():
         L.ov2h_ba_worker_stats.restype = None
         L.ov2h_ba_worker_destroy.argtypes = [C.c_void_p]
         L.ov2h_ba_worker_destroy.restype = None
+        L.ov2h_ba_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, ip, dp, C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.ov2h_ba_pipeline_create.restype = C.c_void_p
+        for fn in (L.ov2h_ba_pipeline_submit_all, L.ov2h_ba_pipeline_destroy):
+            fn.argtypes, fn.restype = [C.c_void_p], None
+        L.ov2h_ba_pipeline_set_counting.argtypes, L.ov2h_ba_pipeline_set_counting.restype = [C.c_void_p, C.c_int], None
+        L.ov2h_ba_pipeline_stats.argtypes, L.ov2h_ba_pipeline_stats.restype = [C.c_void_p, dp], None
         L.ov2h_compute_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, ip]
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
@@ -316,6 +322,48 @@ class EstimatorWorker:
     def close(self):
         if getattr(self, "h", None):
             lib().ov2h_ba_worker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class EstimatorPipeline:
+    """the Estimator threads of `len(maps)` SLAM instances as ONE native thread that runs the WHOLE of Optimizer::localBA per
+    keyframe job on device-resident maps (ov2slam_amd/device_map.DeviceMap, all created on `ctx`): set-up
+    (ov2_map_local_ba_setup_batch, src/optimizer.cpp:43-430) -> solve (ov2_ba_solve_batch_dev, :439-735) -> update
+    (ov2_map_local_ba_update_batch, :741-882) for every sequence that has a keyframe pending, in one batch.  `ctx` and the
+    maps belong to the thread until close(); the caller must have saved the maps' state (every job starts from it)."""
+
+    def __init__(self, ctx, maps, proto, robust_mono_th=5.9915, max_batch=64):
+        self.ctx, self.maps, self.proto = ctx, maps, proto
+        n = len(maps)
+        hs = (C.c_void_p * n)(*[m.h for m in maps])
+        nk = np.ascontiguousarray([m.newkf for m in maps], np.int32)
+        K = np.ascontiguousarray(np.tile(np.asarray(proto.calib_l, np.float64), (n, 1)))
+        pc = proto.as_c()
+        self.h = lib().ov2h_ba_pipeline_create(ctx.h, n, hs, nk.ctypes.data_as(C.POINTER(C.c_int)), _dp(K), C.addressof(pc),
+                                               robust_mono_th, int(proto.inv_depth), max_batch)
+        if not self.h:
+            raise RuntimeError("ov2h_ba_pipeline_create failed")
+
+    def submit_all(self):
+        lib().ov2h_ba_pipeline_submit_all(self.h)
+
+    def set_counting(self, on):
+        lib().ov2h_ba_pipeline_set_counting(self.h, int(bool(on)))
+
+    def stats(self):
+        o = np.zeros(40)
+        lib().ov2h_ba_pipeline_stats(self.h, _dp(o))
+        return dict(solves=int(o[0]), iters=int(o[1]), dropped=int(o[2]), submitted=int(o[3]), busy_s=float(o[4]),
+                    last_status=int(o[5]), batches=int(o[6]), setup_s=float(o[7]), solve_s=float(o[8]), update_s=float(o[9]),
+                    slowest_sum=int(o[10]), res_blocks=int(o[11]), aborted=int(o[12]), iter_blocks=int(o[13]),
+                    hist_robust=[int(x) for x in o[16:24]], hist_l2=[int(x) for x in o[24:40]])
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ov2h_ba_pipeline_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -70,7 +70,11 @@ def stereo_extrinsic():
 
 def make_window(n_kf=20, n_lm=2000, inv_depth=True, seed=SEED_BA, max_obs=12, px_noise=0.5, outlier_frac=0.05,
                 pose_noise=(0.02, np.deg2rad(0.5)), depth_noise=0.03, fixed_frac=0.2, stereo=True, spacing=0.4,
-                return_gt=False):
+                return_gt=False, obs_pick="nearest"):
+    """obs_pick: which `max_obs` of the keyframes that see a landmark keep their observation -- 'nearest' (in index, to the
+    keyframe that generated it: short tracks, the newest keyframe is covisible with a handful of others) or 'random' (tracks
+    broken by occlusion: every pair of keyframes shares landmarks, so the covisibility walk of Optimizer::localBA,
+    reference src/optimizer.cpp:128-190, optimises the whole window)"""
     rng = np.random.default_rng(seed)
     T_rl7, T_rl = stereo_extrinsic()
     # lawn-mower trajectory in the world XY plane, camera looking along its heading, yaw wobble +-15 deg
@@ -111,7 +115,9 @@ def make_window(n_kf=20, n_lm=2000, inv_depth=True, seed=SEED_BA, max_obs=12, px
         ids = np.nonzero(ok)[0]
         if len(ids) < 2:
             continue
-        if len(ids) > max_obs:   # keep the observers closest (in index) to the generating keyframe
+        if len(ids) > max_obs and obs_pick == "random":
+            ids = np.sort(rng.choice(ids, max_obs, replace=False))
+        elif len(ids) > max_obs:   # keep the observers closest (in index) to the generating keyframe
             ids = np.sort(ids[np.argsort(np.abs(ids - k0), kind="stable")[:max_obs]])
         lst = []
         for k in ids:
@@ -176,6 +182,37 @@ def make_window(n_kf=20, n_lm=2000, inv_depth=True, seed=SEED_BA, max_obs=12, px
     if return_gt:
         return prob, dict(poses=poses_gt, lm=lm_gt, xyz=lm_xyz)
     return prob
+
+
+def sequence_window_specs(nseq, seed, n_kf=50, n_lm=10000, spread=0.2):
+    """nseq DISTINCT local-BA windows around a nominal size (one per SLAM instance of a batch): keyframes and landmarks
+    drawn within +-spread of the nominal, outlier rate 1-12 %, initial pose / depth error spread around the default -- so that the
+    windows of a batch differ in size, sparsity and in the LM iterations they take (initial error log-uniform over 0.1-4x the
+    default: from a map that is nearly converged to one far off).  Returns make_window kwargs."""
+    rng = np.random.default_rng(seed)
+    specs = []
+    for b in range(nseq):
+        f = float(np.exp(rng.uniform(np.log(0.1), np.log(4.0))))
+        specs.append(dict(n_kf=int(round(n_kf * rng.uniform(1 - spread, 1 + spread))),
+                          n_lm=int(round(n_lm * rng.uniform(1 - spread, 1 + spread))), inv_depth=True, seed=int(seed + 1000 + 17 * b),
+                          max_obs=7, outlier_frac=float(rng.uniform(0.01, 0.12)), pose_noise=(0.02 * f, np.deg2rad(0.5) * f),
+                          depth_noise=float(np.exp(rng.uniform(np.log(0.003), np.log(0.1)))), obs_pick="random"))
+    return specs
+
+
+def _make_window_kw(kw):
+    return make_window(**kw)
+
+
+def make_windows_parallel(specs, procs):
+    """make_window for every spec on a pool of SPAWNED processes (numpy only; safe to call before or after the parent has
+    initialised the GPU, since the children never inherit its state)"""
+    if procs <= 1 or len(specs) <= 1:
+        return [make_window(**kw) for kw in specs]
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=min(procs, len(specs)), mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_make_window_kw, specs, chunksize=1))
 
 
 def make_pnp(n=300, seed=SEED_BA, px_noise=0.5, outlier_frac=0.1, rot_pert=0.02, trans_pert=0.05, behind=0,

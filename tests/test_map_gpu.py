@@ -183,12 +183,7 @@ def test_observation_table_is_squeezed_when_mostly_dead(ctx, inv_depth):
     assert hm.device_rows()[2] == 1
 
 
-class _SetupC(C.Structure):
-    _fields_ = [("aborted", C.c_int32), ("n_pose", C.c_int32), ("n_lm", C.c_int32), ("n_res", C.c_int32), ("n_bad", C.c_int32),
-                ("pose_kfid", C.c_void_p), ("pose_const", C.c_void_p), ("pose", C.c_void_p), ("lm_lmid", C.c_void_p),
-                ("lm", C.c_void_p), ("lm_anchor_pose", C.c_void_p), ("lm_anchor_uv", C.c_void_p), ("res_type", C.c_void_p),
-                ("res_pose", C.c_void_p), ("res_lm", C.c_void_p), ("res_uv", C.c_void_p), ("res_sigma", C.c_void_p),
-                ("bad_lmid", C.c_void_p)]
+from ov2slam_amd.device_map import SetupC as _SetupC   # noqa: E402  (ov2_local_ba_setup)
 
 
 def test_long_sequence_keeps_the_observation_table_bounded(ctx):
@@ -226,9 +221,9 @@ def test_long_sequence_keeps_the_observation_table_bounded(ctx):
             gone = gone[gone >= 0]
             if len(gone):
                 assert L.ov2_map_remove_landmarks(m, len(gone), vp(gone)) == 0
-        if k % 25 == 24:
-            assert L.ov2_map_local_ba_setup(m, k, 25, 1, 0, None, C.byref(out)) == 0
-    assert L.ov2_map_local_ba_setup(m, NKF - 1, 25, 1, 0, None, C.byref(out)) == 0
+        if k % 25 == 24:   # the last of these is the set-up of the newest keyframe; a second call on the same map would see the
+            assert L.ov2_map_local_ba_setup(m, k, 25, 1, 0, None, C.byref(out)) == 0   # is3d_ flags MapPoint::isBad() cleared in the first
+    assert (NKF - 1) % 25 == 24
     rows, cap, nsq = C.c_int(), C.c_int(), C.c_int()
     assert L.ov2_map_obs_rows(m, C.byref(rows), C.byref(cap), C.byref(nsq)) == 0
     live = WIN * PER
