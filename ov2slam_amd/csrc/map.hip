@@ -590,29 +590,39 @@ __global__ __launch_bounds__(256) void mu_obs_kernel(const map_job *__restrict__
 {
     const map_job &j = J[blockIdx.y];
     const map_view &M = j.M;
+    if (!j.outlier || j.hdr[MH_ABORT] || (int)blockIdx.x * 256 >= M.n_obs) return;   // uniform per workgroup
+    __shared__ int s_cnt[2], s_base[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M.n_obs || !j.outlier || j.hdr[MH_ABORT]) return;
-    const int c = j.obs_cnt[i];
-    if (!c) return;
     const flat_out O = flat_of(j, inv);
-    const int o = j.obs_off[i];
     bool left = false, right = false;
-    for (int k = 0; k < c; ++k)
-        if (j.outlier[o + k]) {
-            const int t = O.res_type[o + k];
-            if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) left = true; else right = true;
-        }
+    const int c = i < M.n_obs ? j.obs_cnt[i] : 0;
+    if (c) {
+        const int o = j.obs_off[i];
+        for (int k = 0; k < c; ++k)
+            if (j.outlier[o + k]) {
+                const int t = O.res_type[o + k];
+                if (t == OV2_BA_L_XYZ || t == OV2_BA_L_INV) left = true; else right = true;
+            }
+    }
+    // the two report lists: ranks inside the workgroup from LDS counters, ONE global atomic per workgroup and list
+    // (one per flagged row on the map's header line serialised the whole launch: 1.66 ms for 64 maps of 65 k rows)
+    const int rl = left ? atomicAdd(&s_cnt[0], 1) : 0, rr = right ? atomicAdd(&s_cnt[1], 1) : 0;
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&j.hdr[threadIdx.x == 0 ? MH_NRM_OBS : MH_NST_OFF], s_cnt[threadIdx.x]);
+    __syncthreads();
     if (!left && !right) return;
     const int kf = M.obs_kf[i], lm = M.obs_lm[i];
     atomicOr(&j.lm_sel[lm], 4);
     if (right) {
         j.obs_flag_w[i] = M.obs_flag[i] & ~OBS_STEREO;
-        O.st_off[atomicAdd(&j.hdr[MH_NST_OFF], 1)] = make_int2(kf, lm);
+        O.st_off[s_base[1] + rr] = make_int2(kf, lm);
     }
     if (left) {
         j.obs_flag_w[i] = 0;
         atomicSub(&j.lm_nobs[lm], 1);
-        O.rm_obs[atomicAdd(&j.hdr[MH_NRM_OBS], 1)] = make_int2(kf, lm);
+        O.rm_obs[s_base[0] + rl] = make_int2(kf, lm);
         if (kf == j.cur_kfid) j.lm_state_w[lm] = M.lm_state[lm] & ~OV2_LM_OBS;   // one observation per (keyframe, landmark): one writer
         // the oldest observer is gone (XYZ only: an anchor observation carries no left block): MapPoint::removeKfObs moves
         // kfid_ to the next one (src/map_point.cpp:124-126); pass 1b recounts it

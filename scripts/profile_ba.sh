@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-trace stats of the stand-alone batched local BA (scripts/ba_batch_time.py B); output gpurun_out/prof_ba_<tag>/
+# kernel-trace stats of the stand-alone batched local BA (scripts/ba_pipeline_time.py B: distinct windows, set-up + solve + update; BA_SCRIPT=ba_batch_time.py for the replicated solve-only form); output gpurun_out/prof_ba_<tag>/
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-ba}
@@ -7,7 +7,7 @@ B=${2:-64}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_ba_$TAG
 rm -rf $O && mkdir -p $O
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/scripts/ba_batch_time.py $B > $O/kt.log 2>&1 || { tail -5 $O/kt.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/scripts/${BA_SCRIPT:-ba_pipeline_time.py} $B > $O/kt.log 2>&1 || { tail -5 $O/kt.log; exit 1; }
 tail -3 $O/kt.log
 F=$(find $O/kt -name "*kernel_stats.csv" | head -1)
 python3 - "$F" <<'PY'

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ issue / stall / LDS counters of the batched local BA alone (BA_DEV=1 scripts/ba_batch_time.py 64), two rocprofv3 --pmc passes
+# SQ issue / stall / LDS counters of the batched local BA alone (scripts/ba_pipeline_time.py 64), two rocprofv3 --pmc passes
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
@@ -9,7 +9,7 @@ i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES" \
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAVES"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $SET --output-format csv -d $O/set$i -- python3 $R/scripts/ba_batch_time.py 64 > $O/set$i.log 2>&1 || { echo "set failed: $SET"; tail -3 $O/set$i.log; continue; }
+  timeout -k 10 150 rocprofv3 --pmc $SET --output-format csv -d $O/set$i -- python3 $R/scripts/${BA_SCRIPT:-ba_pipeline_time.py} 64 3 > $O/set$i.log 2>&1 || { echo "set failed: $SET"; tail -3 $O/set$i.log; continue; }
 done
 python3 - <<PY
 import csv, glob, collections, re
