@@ -80,8 +80,8 @@ void ov2_images_destroy(ov2_images *imgs);
  * The returned pyramid holds levels 0..L (L <= max_level, same early stop as OpenCV), each level a u8 image
  * padded by `win` px of REFLECT_101 and an int16 (Ix,Iy) Scharr gradient padded by `win` px of zeros.
  * The gradient planes (withDerivatives = true in OpenCV: 4 of the 5 bytes per pixel) are written ON DEMAND, by the first
- * consumer that reads them (the tracking kernels for other window sizes than 9 or calls below 4096 keypoints,
- * ov2_pyr_download_level with a gradient pointer); the 9 x 9 path of large calls derives the same Scharr integers from
+ * consumer that reads them (the tracking kernels for other window sizes than 9, or a forced 8 / 16-lane mapping,
+ * ov2_pyr_download_level with a gradient pointer); the 9 x 9 path derives the same Scharr integers from
  * the image windows inside its kernel and a build that only feeds it never writes them.
  * Handles are ref-counted because the reference shares pyramids by value between threads
  * (src/ov2slam.cpp:175-180). */
@@ -136,9 +136,9 @@ ov2_status ov2_klt_tracking_frame_dev(ov2_ctx *ctx, const ov2_pyr *prev, const o
                                       int32_t *d_p3p_req /* [batch] */, uint32_t *d_iters /* 2n work words: [0,n) stage 1, [n,2n) stage 2; may be NULL */);
 
 /* Tuning / test knob: lanes of a wavefront that share one keypoint in the tracking kernels.  0 (default) picks by call
- * size: 9 x 9 windows (nklt_win_size of every parameter file of the reference) take THREE lanes per keypoint from 4096
- * keypoints per call on (20 keypoints per wave, Scharr derivatives formed in the kernel, no gradient planes read);
- * otherwise 8 lanes from 65 536 keypoints on, 16 below.  All mappings give bit-identical results. */
+ * size: 9 x 9 windows (nklt_win_size of every parameter file of the reference) take THREE lanes per keypoint at every
+ * call size (20 keypoints per wave, Scharr derivatives formed in the kernel, no gradient planes read);
+ * other windows 8 lanes from 65 536 keypoints on, 16 below.  All mappings give bit-identical results. */
 ov2_status ov2_klt_set_lanes(ov2_ctx *ctx, int lanes);
 
 /* ---- stereo matching (keyframe rate) -------------------------------------------------------------- */

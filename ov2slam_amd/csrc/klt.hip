@@ -1123,10 +1123,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     }
 }
 
-// Lanes per keypoint for a call of n keypoints.  9 x 9 windows (the reference's nklt_win_size) have the three-lane
-// mapping (20 keypoints per wave) once the call fills the device with such waves; ov2_klt_set_lanes (or OV2_KLT_LANES
-// = 3 / 8 / 16 in the environment) forces one mapping: tests run every mapping against the oracle.
-#define KLT_GL3_MIN_KPS 4096
+// Lanes per keypoint for a call of n keypoints.  9 x 9 windows (the reference's nklt_win_size) take the three-lane
+// mapping (20 keypoints per wave, Scharr derivatives formed in the kernel) at EVERY call size: measured per frame-batch of
+// 308 keypoints (EuRoC size, scripts/klt_small_time.py), pyramid build + two-stage tracking back to back: 1 sequence 64.1 us
+// against 71.4 us with the 16-lane kernels (which first need the four gradient-plane launches), 8 sequences 77.9 / 90.5,
+// 64 sequences 109.8 / 182.5; synchronised latency of one frame 103 / 121 us.  ov2_klt_set_lanes (or OV2_KLT_LANES = 3 / 8 /
+// 16 in the environment) forces one mapping: tests run every mapping against the oracle.
+#define KLT_GL3_MIN_KPS 0
 int klt_lanes_for(const ov2_ctx *c, int n, int win, const ov2_pyr *a, const ov2_pyr *b)
 {
     static const int env = [] { const char *e = getenv("OV2_KLT_LANES"); return e ? atoi(e) : 0; }();

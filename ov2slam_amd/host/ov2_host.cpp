@@ -766,8 +766,11 @@ ov2_status VisualFrontEnd::computePose()
     std::vector<Vec2> vkps;
     std::vector<Vec3> vwpts;
     std::vector<int> vkpids, voutliersidx, vscales;
-    for (const auto &it : pcurframe_->mapkps_) {                           // :688-708
-        const Keypoint &kp = it.second;
+    std::vector<int> order;                                               // the reference walks its hash map; ascending ids make the
+    for (const auto &it : pcurframe_->mapkps_) order.push_back(it.first);  // summation order of the solve independent of the hash
+    std::sort(order.begin(), order.end());
+    for (const int id : order) {                                           // :688-708
+        const Keypoint &kp = pcurframe_->mapkps_.at(id);
         if (!kp.is3d_) continue;
         auto plm = pmap_->getMapPoint(kp.lmid_);
         if (!plm) continue;

@@ -186,6 +186,12 @@ struct SlamParams {   // the subset of include/slam_params.hpp the path reads (Y
     bool blocalba_is_on_ = false, bforce_realtime_ = true;
     bool dop3p_ = false;
     bool bdo_stereo_rect_ = false;   // parameters_files/*/euroc_stereo.yaml: 0
+    // keyframe creation / selection (src/slam_params.cpp:95-125, YAML keys of the same name)
+    int nmaxdist_ = 35, nbmaxkps_ = 308;            // nbmaxkps_ = ceil(w / nmaxdist) * ceil(h / nmaxdist) (:107-110)
+    bool use_fast_ = false, use_singlescale_detector_ = true, use_brief_ = false, doepipolar_ = false;
+    double dmaxquality_ = 0.001;
+    int nfast_th_ = 10;
+    float finit_parallax_ = 20.f, fmax_reproj_err_ = 3.f;
 };
 
 struct Vec2 {

@@ -1,7 +1,9 @@
 // ov2_host_capi.cpp -- flat C hooks around the C++ host mirror so that pytest can build a Frame/MapPoint graph,
 // run Optimizer::setupLocalBA (CPU only) or the whole Estimator::applyLocalBA (GPU) and read the map back.
 // Test/bring-up surface only; a real integration uses the C++ classes of ov2_host.hpp directly.
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -9,6 +11,7 @@
 #include <thread>
 
 #include "ov2_host.hpp"
+#include "ov2_slam.hpp"
 
 using namespace ov2;
 
@@ -457,6 +460,70 @@ int ov2h_count_keypoints(void *p, int kfid, int *nbkps, int *nb3d, int *nbstereo
     *nbkps = (int)f->nbkps_; *nb3d = (int)f->nb3dkps_; *nbstereo = (int)f->nb_stereo_kps_;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ov2::SlamManager (ov2_slam.hpp): one stereo frame per call through visualTracking and, on keyframes, Mapper::run +
+// Estimator::applyLocalBA -- the closed loop in C++.  policy = {kf_every, ba_window, ba_fixed, compose_motion, midpoint_stereo,
+// pose_from_kf} (all zero = the reference's own heuristics); rect != 0: rectified rig (bdo_stereo_rect_).
+void *ov2h_slam_create(void *ctx, const double *K4, double baseline, int w, int h, int cell, int rect, const int *policy, int use_device_map)
+{
+    auto st = std::make_shared<SlamParams>();
+    st->stereo_ = true; st->mono_ = false; st->bdo_stereo_rect_ = rect != 0;
+    st->nmaxdist_ = cell;
+    st->nbmaxkps_ = (int)(std::ceil((float)w / cell) * std::ceil((float)h / cell));   // src/slam_params.cpp:107-110
+    auto cl = std::make_shared<CameraCalibration>(), cr = std::make_shared<CameraCalibration>();
+    cl->fx_ = cr->fx_ = K4[0]; cl->fy_ = cr->fy_ = K4[1]; cl->cx_ = cr->cx_ = K4[2]; cl->cy_ = cr->cy_ = K4[3];
+    cl->img_w_ = cr->img_w_ = w; cl->img_h_ = cr->img_h_ = h;
+    cr->Tc0ci_.v = {baseline, 0, 0, 0, 0, 0, 1};
+    LoopPolicy pol;
+    if (policy) {
+        pol.kf_every = policy[0]; pol.ba_window = policy[1]; pol.ba_fixed = policy[2]; pol.compose_motion = policy[3] != 0;
+        pol.midpoint_stereo = policy[4] != 0; pol.pose_from_kf = policy[5] != 0;
+    }
+    SlamManager *S = new SlamManager((ov2_ctx *)ctx, st, cl, cr, pol);
+    if (use_device_map && S->pmap_->attachDevice((ov2_ctx *)ctx, 64, 4096, 16384) != OV2_OK) { delete S; return nullptr; }
+    return S;
+}
+
+int ov2h_slam_add_stereo(void *p, double time, const uint8_t *left, const uint8_t *right, int w, int h)
+{
+    return (int)((SlamManager *)p)->addNewStereoImages(time, left, right, w, h, w);
+}
+
+void ov2h_slam_pose(void *p, double *Twc7)
+{
+    const SE3 T = ((SlamManager *)p)->pose();
+    for (int i = 0; i < 7; ++i) Twc7[i] = T.v[i];
+}
+
+// out[16]: frame, keypoints, 3D keypoints, keyframe?, new keypoints, stereo keypoints, 3D landmarks, BA ran?, residual blocks,
+// robust iterations, L2 iterations, outliers, cost before, cost after, keyframes so far, landmarks so far
+void ov2h_slam_stats(void *p, double *out)
+{
+    SlamManager *S = (SlamManager *)p;
+    const SlamStats &s = S->last_;
+    const double v[16] = {(double)s.frame, (double)s.tracked, (double)s.n3d, (double)s.is_kf, (double)s.n_new, (double)s.n_stereo,
+                          (double)s.n_lm3d, (double)s.ba_done, (double)s.ba_res, (double)s.ba_it_robust, (double)s.ba_it_l2,
+                          (double)s.ba_outliers, s.ba_cost0, s.ba_cost1, (double)S->pmap_->map_pkfs_.size(), (double)S->pmap_->map_plms_.size()};
+    for (int i = 0; i < 16; ++i) out[i] = v[i];
+}
+
+// ids + world points of the 3D landmarks (capacity cap); returns the count
+int ov2h_slam_landmarks(void *p, int cap, int *lmid, double *xyz)
+{
+    SlamManager *S = (SlamManager *)p;
+    std::vector<int> ids;
+    for (const auto &kv : S->pmap_->map_plms_) if (kv.second->is3d_) ids.push_back(kv.first);
+    std::sort(ids.begin(), ids.end());
+    int n = 0;
+    for (int id : ids) {
+        if (n < cap) { const Vec3 q = S->pmap_->getMapPoint(id)->getPoint(); lmid[n] = id; xyz[3 * n] = q.x; xyz[3 * n + 1] = q.y; xyz[3 * n + 2] = q.z; }
+        ++n;
+    }
+    return n;
+}
+
+void ov2h_slam_destroy(void *p) { delete (SlamManager *)p; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Estimator threads of `nseq` SLAM instances (reference src/estimator.cpp:32-98 run(): wait for a keyframe ->

@@ -1,0 +1,476 @@
+// ov2_slam.cpp -- see ov2_slam.hpp.  Frame / keyframe drivers of the reference restated on the host mirror; every
+// arithmetic stage is a call of the mirror (and so of the C ABI).  Reference line numbers (in /root/reference) per block.
+#include "ov2_slam.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <set>
+
+namespace ov2 {
+
+// ---------------------------------------------------------------------------------------------- se3 log / exp
+static const double kEps = 1e-10;   // Sophus::Constants<double>::epsilon()
+
+void se3_log(const SE3 &T, double out[6])
+{   // Sophus SO3::logAndTheta (so3.hpp) + SE3::log (se3.hpp): omega from the quaternion, upsilon = V^-1 t
+    double x = T.v[3], y = T.v[4], z = T.v[5], w = T.v[6];
+    const double qn = std::sqrt(x * x + y * y + z * z + w * w);
+    x /= qn; y /= qn; z /= qn; w /= qn;
+    const double sn = x * x + y * y + z * z, n = std::sqrt(sn);
+    double two_atan;
+    if (sn < kEps * kEps) two_atan = 2. / w - (2. / 3.) * sn / (w * w * w);
+    else if (std::fabs(w) < kEps) two_atan = (w > 0. ? M_PI : -M_PI) / n;
+    else two_atan = 2. * std::atan(n / w) / n;
+    const double theta = two_atan * n;
+    const double om[3] = {two_atan * x, two_atan * y, two_atan * z};
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    double c2;
+    if (std::fabs(theta) < kEps) c2 = 1. / 12.;
+    else { const double h = 0.5 * theta; c2 = (1. - theta * std::cos(h) / (2. * std::sin(h))) / (theta * theta); }
+    for (int r = 0; r < 3; ++r) {
+        double s = 0;
+        for (int c = 0; c < 3; ++c) s += ((r == c ? 1. : 0.) - 0.5 * O[3 * r + c] + c2 * O2[3 * r + c]) * T.v[c];
+        out[r] = s;
+    }
+    out[3] = om[0]; out[4] = om[1]; out[5] = om[2];
+}
+
+SE3 se3_exp(const double a[6])
+{   // Sophus::SE3::exp (se3.hpp:763-784) / SO3::expAndTheta (so3.hpp:585-621)
+    const double *u = a, *w = a + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double theta, imag, real;
+    if (th2 < kEps * kEps) {
+        theta = 0.;
+        const double th4 = th2 * th2;
+        imag = 0.5 - (1. / 48.) * th2 + (1. / 3840.) * th4;
+        real = 1. - (1. / 8.) * th2 + (1. / 384.) * th4;
+    } else {
+        theta = std::sqrt(th2);
+        imag = std::sin(0.5 * theta) / theta;
+        real = std::cos(0.5 * theta);
+    }
+    SE3 q;
+    q.v = {0, 0, 0, imag * w[0], imag * w[1], imag * w[2], real};
+    double R[9], V[9];
+    q.rotation(R);
+    if (theta < kEps) {
+        for (int i = 0; i < 9; ++i) V[i] = R[i];
+    } else {
+        const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double O2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+        const double t2 = theta * theta, c1 = (1. - std::cos(theta)) / t2, c2 = (theta - std::sin(theta)) / (t2 * theta);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1. : 0.) + c1 * O[i] + c2 * O2[i];
+    }
+    for (int r = 0; r < 3; ++r) q.v[r] = V[3 * r] * u[0] + V[3 * r + 1] * u[1] + V[3 * r + 2] * u[2];
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------------- MotionModel
+void MotionModel::applyMotionModel(SE3 &Twc, double time)
+{
+    if (prev_time_ > 0) {
+        double d[6];
+        se3_log(Twc * prevTwc_.inverse(), d);
+        bool zero = true;
+        for (double v : d) zero = zero && std::fabs(v) <= 1.e-5;
+        if (!zero) prevTwc_ = Twc;   // "might happen in case of LC"
+        const double dt = time - prev_time_;
+        double a[6];
+        for (int i = 0; i < 6; ++i) a[i] = log_relT_[i] * dt;
+        Twc = Twc * se3_exp(a);
+    }
+}
+
+void MotionModel::updateMotionModel(const SE3 &Twc, double time)
+{
+    if (prev_time_ < 0.) { prev_time_ = time; prevTwc_ = Twc; return; }
+    const double dt = time - prev_time_;
+    prev_time_ = time;
+    if (dt <= 0.) { prevTwc_ = Twc; return; }   // the reference exits on an older image
+    double d[6];
+    se3_log(prevTwc_.inverse() * Twc, d);
+    for (int i = 0; i < 6; ++i) log_relT_[i] = d[i] / dt;
+    prevTwc_ = Twc;
+}
+
+// ---------------------------------------------------------------------------------------------- SlamManager
+SlamManager::SlamManager(ov2_ctx *ctx, std::shared_ptr<SlamParams> pstate, std::shared_ptr<CameraCalibration> cl,
+                         std::shared_ptr<CameraCalibration> cr, const LoopPolicy &policy)
+    : ctx_(ctx), pslamstate_(pstate), policy_(policy)
+{   // src/ov2slam.cpp:38-150 (constructor): frame, map, tracker, extractor, front-end, optimiser, estimator
+    pcurframe_ = std::make_shared<Frame>();
+    pcurframe_->pcalib_leftcam_ = cl; pcurframe_->pcalib_rightcam_ = cr;
+    pcurframe_->id_ = -1; pcurframe_->kfid_ = 0;
+    pcurframe_->initGrid((size_t)pstate->nmaxdist_);
+    pmap_ = std::make_shared<MapManager>();
+    pmap_->pcurframe_ = pcurframe_;
+    ptracker_ = std::make_shared<FeatureTracker>(ctx, pstate->nmax_iter_, pstate->fmax_px_precision_);
+    pfeatextract_ = std::make_shared<FeatureExtractor>(ctx, (size_t)pstate->nbmaxkps_, (size_t)pstate->nmaxdist_, pstate->dmaxquality_,
+                                                       pstate->nfast_th_);
+    pvisualfrontend_ = std::make_shared<VisualFrontEnd>(ctx, pstate, pcurframe_, pmap_, ptracker_);
+    poptimizer_ = std::make_shared<Optimizer>(ctx, pstate, pmap_);
+    pestimator_ = std::make_shared<Estimator>(pstate, pmap_, poptimizer_);
+}
+
+ov2_status SlamManager::addNewStereoImages(double time, const uint8_t *im0, const uint8_t *im1, int w, int h, int stride)
+{   // src/ov2slam.cpp:152-205
+    ++frame_id_;
+    pcurframe_->id_ = frame_id_; pcurframe_->img_time_ = time;   // Frame::updateFrame
+    last_ = SlamStats();
+    last_.frame = frame_id_;
+    ov2_status st = OV2_OK;
+    const bool is_kf_req = visualTracking(im0, w, h, stride, time, &st);
+    if (st != OV2_OK) return st;
+    if (is_kf_req) {
+        Keyframe kf;
+        kf.kfid_ = pcurframe_->kfid_; kf.vpyr_imleft_ = pvisualfrontend_->cur_pyr_; kf.imrightraw_ = im1; kf.w = w; kf.h = h; kf.stride = stride;
+        if ((st = mapperRun(kf)) != OV2_OK) return st;
+    }
+    last_.is_kf = is_kf_req;
+    last_.tracked = (int)pcurframe_->nbkps_; last_.n3d = (int)pcurframe_->nb3dkps_;
+    stats_.push_back(last_);
+    traj_.push_back(pcurframe_->getTwc());
+    return OV2_OK;
+}
+
+bool SlamManager::visualTracking(const uint8_t *iml, int w, int h, int stride, double time, ov2_status *st)
+{   // src/visual_front_end.cpp:40-62
+    const bool iskfreq = trackMono(iml, w, h, stride, time, st);
+    if (*st != OV2_OK) return false;
+    if (iskfreq) *st = createKeyframe();
+    return iskfreq;
+}
+
+bool SlamManager::trackMono(const uint8_t *im, int w, int h, int stride, double time, ov2_status *st)
+{   // src/visual_front_end.cpp:66-130
+    VisualFrontEnd &fe = *pvisualfrontend_;
+    if ((*st = fe.preprocessImage(im, w, h, stride)) != OV2_OK) return false;
+    if (pcurframe_->id_ == 0) return true;                       // first frame: keyframe
+    SE3 Twc = pcurframe_->getTwc();
+    if (policy_.compose_motion) {
+        const SE3 pred = have_prev_ ? Twc * (Twc_prev_.inverse() * Twc) : Twc;
+        Twc_prev_ = Twc; have_prev_ = true;
+        Twc = pred;
+    } else {
+        motion_model_.applyMotionModel(Twc, time);
+    }
+    pcurframe_->setTwc(Twc);
+    if ((*st = fe.kltTracking()) != OV2_OK) return false;
+    if (pslamstate_->doepipolar_) { *st = OV2_ERR_UNSUPPORTED; return false; }   // epipolar2d2dFiltering: 5-point RANSAC (OpenGV)
+    if ((*st = fe.computePose()) != OV2_OK) return false;
+    if (!policy_.compose_motion) motion_model_.updateMotionModel(pcurframe_->Twc_, time);
+    if (policy_.kf_every > 0) return pcurframe_->id_ % policy_.kf_every == 0;
+    return checkNewKfReq();
+}
+
+bool SlamManager::checkNewKfReq()
+{   // src/visual_front_end.cpp:985-1064
+    auto pkf = pmap_->getKeyframe(pcurframe_->kfid_);
+    if (!pkf) return false;
+    const SlamParams &S = *pslamstate_;
+    const double med_rot_parallax = computeParallax(pkf->kfid_, true, true, false);
+    const int nbimfromkf = pcurframe_->id_ - pkf->id_;
+    if (pcurframe_->noccupcells_ < 0.33 * S.nbmaxkps_ && nbimfromkf >= 5 && !S.blocalba_is_on_) return true;
+    if (pcurframe_->nb3dkps_ < 20 && nbimfromkf >= 2) return true;
+    if (pcurframe_->nb3dkps_ > 0.5 * S.nbmaxkps_ && (S.blocalba_is_on_ || nbimfromkf < 2)) return false;
+    const double time_diff = pcurframe_->img_time_ - pkf->img_time_;
+    if (S.stereo_ && time_diff > 1. && !S.blocalba_is_on_) return true;
+    const bool cx = med_rot_parallax >= S.finit_parallax_ / 2. || (S.stereo_ && !S.blocalba_is_on_ && pcurframe_->id_ - pkf->id_ > 2);
+    const bool c0 = med_rot_parallax >= S.finit_parallax_;
+    const bool c1 = pcurframe_->nb3dkps_ < 0.75 * pkf->nb3dkps_;
+    const bool c2 = pcurframe_->noccupcells_ < 0.5 * S.nbmaxkps_ && pcurframe_->nb3dkps_ < 0.85 * pkf->nb3dkps_ && !S.blocalba_is_on_;
+    return (c0 || c1 || c2) && cx;
+}
+
+float SlamManager::computeParallax(int kfid, bool do_unrot, bool bmedian, bool b2donly)
+{   // src/visual_front_end.cpp:1069-1142
+    auto pkf = pmap_->getKeyframe(kfid);
+    if (!pkf) return 0.f;
+    double Rkfcur[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (do_unrot) {
+        double Rkfw[9], Rwcur[9];
+        pkf->getTcw().rotation(Rkfw);
+        pcurframe_->getTwc().rotation(Rwcur);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rkfcur[3 * i + j] = Rkfw[3 * i] * Rwcur[j] + Rkfw[3 * i + 1] * Rwcur[3 + j] + Rkfw[3 * i + 2] * Rwcur[6 + j];
+    }
+    float avg_parallax = 0.f;
+    int nbparallax = 0;
+    std::set<float> set_parallax;
+    for (const auto &it : pcurframe_->mapkps_) {
+        const Keypoint &kp = it.second;
+        if (b2donly && kp.is3d_) continue;
+        const Keypoint kfkp = pkf->getKeypointById(kp.lmid_);
+        if (kfkp.lmid_ != kp.lmid_) continue;
+        Point2f unpx = kp.unpx_;
+        if (do_unrot) {
+            const Vec3 b{Rkfcur[0] * kp.bv_.x + Rkfcur[1] * kp.bv_.y + Rkfcur[2] * kp.bv_.z, Rkfcur[3] * kp.bv_.x + Rkfcur[4] * kp.bv_.y + Rkfcur[5] * kp.bv_.z,
+                         Rkfcur[6] * kp.bv_.x + Rkfcur[7] * kp.bv_.y + Rkfcur[8] * kp.bv_.z};
+            const Vec3 px = pkf->pcalib_leftcam_->projectCamToImage(b);
+            unpx = Point2f{(float)px.x, (float)px.y};
+        }
+        const float dx = unpx.x - kfkp.unpx_.x, dy = unpx.y - kfkp.unpx_.y;
+        const float parallax = (float)std::sqrt((double)dx * dx + (double)dy * dy);   // cv::norm(Point2f)
+        avg_parallax += parallax;
+        nbparallax++;
+        if (bmedian) set_parallax.insert(parallax);
+    }
+    if (nbparallax == 0) return 0.f;
+    avg_parallax /= nbparallax;
+    if (bmedian) { auto it = set_parallax.begin(); std::advance(it, set_parallax.size() / 2); avg_parallax = *it; }
+    return avg_parallax;
+}
+
+// ---------------------------------------------------------------------------------------------- MapManager::createKeyframe
+ov2_status SlamManager::createKeyframe()
+{   // src/map_manager.cpp:43-60
+    prepareFrame();
+    const ov2_status s = extractKeypoints();
+    if (s != OV2_OK) return s;
+    addKeyframe();
+    return OV2_OK;
+}
+
+void SlamManager::prepareFrame()
+{   // src/map_manager.cpp:64-115
+    pcurframe_->kfid_ = nkfid_;
+    if (policy_.kf_every == 0 && (int)pcurframe_->nbkps_ > pslamstate_->nbmaxkps_) {   // thin out crowded cells (:73-98)
+        const auto grid = pcurframe_->vgridkps_;
+        for (const auto &vkpids : grid) {
+            if (vkpids.size() <= 2) continue;
+            int lmid2remove = -1;
+            size_t minnbobs = (size_t)-1;
+            for (const int lmid : vkpids) {
+                auto plm = pmap_->getMapPoint(lmid);
+                if (plm) {
+                    const size_t nbobs = plm->getKfObsSet().size();
+                    if (nbobs < minnbobs) { lmid2remove = lmid; minnbobs = nbobs; }
+                } else { pmap_->removeObsFromCurFrameById(lmid); break; }
+            }
+            if (lmid2remove >= 0) pmap_->removeObsFromCurFrameById(lmid2remove);
+        }
+    }
+    for (const auto &kp : pcurframe_->getKeypoints()) {
+        auto plm = pmap_->getMapPoint(kp.lmid_);
+        if (!plm) { pmap_->removeObsFromCurFrameById(kp.lmid_); continue; }
+        plm->addKfObs(nkfid_);
+    }
+}
+
+ov2_status SlamManager::extractKeypoints()
+{   // src/map_manager.cpp:286-340 (BRIEF description of the keypoints is out of scope here: use_brief_ = 0)
+    std::vector<Keypoint> vkps = pcurframe_->getKeypoints();
+    // the detector's result does not depend on the order of the existing keypoints (discs + occupied cells); ids ascending
+    std::sort(vkps.begin(), vkps.end(), [](const Keypoint &a, const Keypoint &b) { return a.lmid_ < b.lmid_; });
+    std::vector<Point2f> vpts;
+    for (const auto &kp : vkps) vpts.push_back(kp.px_);
+    const int nb2detect = pslamstate_->nbmaxkps_ - (int)pcurframe_->noccupcells_;
+    if (nb2detect <= 0) return OV2_OK;
+    const CameraCalibration &c = *pcurframe_->pcalib_leftcam_;
+    const int roi[4] = {0, 0, c.img_w_, c.img_h_};
+    std::vector<Point2f> vnewpts;
+    if (pslamstate_->use_fast_) vnewpts = pfeatextract_->detectGridFAST(pvisualfrontend_->cur_pyr_, pslamstate_->nmaxdist_, vpts, roi);
+    else if (pslamstate_->use_singlescale_detector_) vnewpts = pfeatextract_->detectSingleScale(pvisualfrontend_->cur_pyr_, pslamstate_->nmaxdist_, vpts, roi);
+    else return OV2_ERR_UNSUPPORTED;   // detectGFTT
+    if (pfeatextract_->last_status_ != OV2_OK) return pfeatextract_->last_status_;
+    last_.n_new = (int)vnewpts.size();
+    if (!vnewpts.empty()) addKeypointsToFrame(vnewpts, *pcurframe_);
+    return OV2_OK;
+}
+
+void SlamManager::addKeypointsToFrame(const std::vector<Point2f> &vpts, Frame &frame)
+{   // src/map_manager.cpp:196-211 + addMapPoint :636-659
+    for (const Point2f &pt : vpts) {
+        Keypoint kp;
+        kp.lmid_ = nlmid_;
+        frame.computeKeypoint(pt, kp);
+        frame.addKeypoint(kp);
+        pmap_->map_plms_.emplace(nlmid_, std::make_shared<MapPoint>(nlmid_, nkfid_, true));
+        pmap_->touchMapPoint(nlmid_);
+        nlmid_++;
+    }
+}
+
+void SlamManager::addKeyframe()
+{   // src/map_manager.cpp:621-634: an independent copy of the current frame enters the map
+    auto pkf = std::make_shared<Frame>(*pcurframe_);
+    pmap_->map_pkfs_.emplace(nkfid_, pkf);
+    nkfid_++;
+}
+
+// ---------------------------------------------------------------------------------------------- Mapper::run (one keyframe)
+ov2_status SlamManager::mapperRun(const Keyframe &kf)
+{   // src/mapper.cpp:38-189
+    auto pnewkf = pmap_->getKeyframe(kf.kfid_);
+    if (!pnewkf) return OV2_ERR_INVALID;
+    const SlamParams &S = *pslamstate_;
+    ov2_status s;
+    if (S.stereo_) {
+        ov2_pyr *pr = nullptr;   // :70-81: CLAHE + pyramid of the right image
+        if ((s = ov2_pyramid_build(ctx_, kf.imrightraw_, kf.w, kf.h, kf.stride, S.nklt_win_size_, S.nklt_pyr_lvl_, S.use_clahe_ ? 1 : 0,
+                                   S.fclahe_val_, kf.w / 50, kf.h / 50, &pr)) != OV2_OK) return s;
+        Pyramid vpyr_imright(pr);
+        if ((s = pmap_->stereoMatching(*pnewkf, kf.vpyr_imleft_, vpyr_imright, *ptracker_, S)) != OV2_OK) return s;
+        last_.n_stereo = (int)pnewkf->nb_stereo_kps_;
+        if (pnewkf->nb2dkps_ > 0 && pnewkf->nb_stereo_kps_ > 0 && (s = triangulateStereo(*pnewkf)) != OV2_OK) return s;
+    }
+    // triangulateTemporal (:191-344) needs keypoints that stayed 2D over two keyframes with enough parallax: with a stereo rig
+    // every matched keypoint is 3D after its first keyframe; the mono-only path is not built here.
+    pmap_->updateFrameCovisibility(*pnewkf);                     // :160
+    pcurframe_->map_covkfs_ = pnewkf->map_covkfs_;               // :163
+    if (S.use_brief_) return OV2_ERR_UNSUPPORTED;                // matchingToLocalMap needs the BRIEF table of opencv_contrib
+    last_.n_lm3d = 0;
+    for (const auto &kv : pmap_->map_plms_) last_.n_lm3d += kv.second->is3d_;
+    // Estimator::addNewKf -> applyLocalBA (src/estimator.cpp:67-98)
+    if (policy_.ba_window > 0) return fixedWindowBA();
+    if (pmap_->dev_ && (s = pmap_->addKeyframeToDevice(*pnewkf)) != OV2_OK) return s;   // the mirror learns the keyframe with its stereo observations
+    pestimator_->pnewkf_ = pnewkf;
+    s = pestimator_->applyLocalBA();
+    const ov2_ba_result &r = poptimizer_->last_result_;
+    if (s == OV2_OK && r.n_log > 0) {
+        last_.ba_done = 1; last_.ba_it_robust = r.n_log_robust - 1; last_.ba_it_l2 = r.l2_done ? r.n_log - r.n_log_robust - 1 : 0;
+        last_.ba_outliers = r.n_outliers_pass1 + r.n_outliers_pass2; last_.ba_cost0 = r.initial_cost;
+        last_.ba_cost1 = r.l2_done ? r.l2_final_cost : r.final_cost;
+    }
+    return s;
+}
+
+ov2_status SlamManager::triangulateStereo(Frame &frame)
+{   // src/mapper.cpp:346-461: the per-keypoint body (triangulation, depth and reprojection gates, world point) is
+    // ov2_triangulate_pairs; what stays here is the selection and the bookkeeping of its verdicts
+    std::vector<Keypoint> vkps;
+    for (const auto &kv : frame.mapkps_)
+        if (kv.second.is_stereo_ && !kv.second.is3d_) vkps.push_back(kv.second);
+    if (vkps.empty()) return OV2_OK;
+    std::sort(vkps.begin(), vkps.end(), [](const Keypoint &a, const Keypoint &b) { return a.lmid_ < b.lmid_; });
+    const size_t n = vkps.size();
+    std::vector<double> bvl(3 * n), bvr(3 * n), pt(3 * n), wpt(3 * n);
+    std::vector<float> ul(2 * n), ur(2 * n);
+    std::vector<uint8_t> status(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Keypoint &k = vkps[i];
+        bvl[3 * i] = k.bv_.x; bvl[3 * i + 1] = k.bv_.y; bvl[3 * i + 2] = k.bv_.z;
+        bvr[3 * i] = k.rbv_.x; bvr[3 * i + 1] = k.rbv_.y; bvr[3 * i + 2] = k.rbv_.z;
+        ul[2 * i] = k.unpx_.x; ul[2 * i + 1] = k.unpx_.y; ur[2 * i] = k.runpx_.x; ur[2 * i + 1] = k.runpx_.y;
+    }
+    const CameraCalibration &cl = *frame.pcalib_leftcam_, &cr = *frame.pcalib_rightcam_;
+    const double Kl[4] = {cl.fx_, cl.fy_, cl.cx_, cl.cy_}, Kr[4] = {cr.fx_, cr.fy_, cr.cx_, cr.cy_};
+    const SE3 Tlr = cr.Tc0ci_, Twc = frame.getTwc();
+    const int method = (pslamstate_->bdo_stereo_rect_ && !policy_.midpoint_stereo) ? OV2_TRI_RECTIFIED : OV2_TRI_MIDPOINT;
+    const ov2_status s = ov2_triangulate_pairs(ctx_, (int)n, method, 1, Tlr.v.data(), Twc.v.data(), nullptr, bvl.data(), bvr.data(), ul.data(),
+                                               ur.data(), Kl, Kr, pslamstate_->fmax_reproj_err_, pt.data(), wpt.data(), nullptr, status.data());
+    if (s != OV2_OK) return s;
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] != OV2_TRI_OK) {
+            if (!policy_.midpoint_stereo) { frame.removeStereoKeypointById(vkps[i].lmid_); pmap_->touchStereoOff(frame.kfid_, vkps[i].lmid_); }
+            continue;
+        }
+        pmap_->updateMapPoint(vkps[i].lmid_, Vec3{wpt[3 * i], wpt[3 * i + 1], wpt[3 * i + 2]}, 1. / pt[3 * i + 2]);
+    }
+    return OV2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- LoopPolicy::ba_window
+// The local BA of ov2slam_amd/slam_loop.py (SlamLoop._local_ba): the last ba_window keyframes, the oldest ba_fixed constant,
+// every 3D landmark they observe (anchored inverse depth, the flat layout of Optimizer::localBA, src/optimizer.cpp:219-392),
+// solved by ov2_ba_solve; poses, landmarks and the flagged observations written back.
+ov2_status SlamManager::fixedWindowBA()
+{
+    std::vector<int> ids;
+    for (const auto &kv : pmap_->map_pkfs_) ids.push_back(kv.first);
+    std::sort(ids.begin(), ids.end());
+    if (ids.size() < 2) return OV2_OK;
+    if ((int)ids.size() > policy_.ba_window) ids.erase(ids.begin(), ids.end() - policy_.ba_window);
+    const int nw = (int)ids.size();
+    std::vector<std::shared_ptr<Frame>> win;
+    for (int k : ids) win.push_back(pmap_->getKeyframe(k));
+    const int nfix = nw > policy_.ba_fixed ? policy_.ba_fixed : 1;
+    std::set<int> lmset;
+    for (const auto &f : win)
+        for (const auto &kv : f->mapkps_) {
+            auto plm = pmap_->getMapPoint(kv.first);
+            if (plm && plm->is3d_) lmset.insert(kv.first);
+        }
+    const CameraCalibration &cl = *pcurframe_->pcalib_leftcam_, &cr = *pcurframe_->pcalib_rightcam_;
+    std::vector<double> pose(7 * (size_t)nw), lm, auv, ruv;
+    std::vector<uint8_t> pconst((size_t)nw, 0), rtype;
+    std::vector<int32_t> anch, rpose, rlm;
+    std::vector<int> lm_id;
+    struct Key { int p, lmid, right; };
+    std::vector<Key> rkey;
+    for (int p = 0; p < nw; ++p) { const SE3 T = win[p]->getTwc(); for (int k = 0; k < 7; ++k) pose[7 * (size_t)p + k] = T.v[k]; pconst[p] = p < nfix; }
+    for (int lmid : lmset) {
+        std::vector<int> seen;
+        for (int p = 0; p < nw; ++p) if (win[p]->mapkps_.count(lmid)) seen.push_back(p);
+        if (seen.empty()) continue;
+        const Keypoint k0 = win[seen[0]]->getKeypointById(lmid);
+        if (seen.size() < 2 && !k0.is_stereo_) continue;           // a single mono observation constrains nothing
+        const int pa = seen[0];
+        const double z = (win[pa]->getTcw() * pmap_->getMapPoint(lmid)->getPoint()).z;
+        if (!(z > 0)) continue;
+        const int l = (int)lm.size();
+        lm.push_back(1. / z); anch.push_back(pa); auv.push_back(k0.unpx_.x); auv.push_back(k0.unpx_.y); lm_id.push_back(lmid);
+        auto put = [&](int type, int p, const Point2f &uv, int right) {
+            rtype.push_back((uint8_t)type); rpose.push_back(p); rlm.push_back(l); ruv.push_back(uv.x); ruv.push_back(uv.y);
+            rkey.push_back({p, lmid, right});
+        };
+        for (int p : seen) {
+            const Keypoint kp = win[p]->getKeypointById(lmid);
+            if (p == pa) { if (kp.is_stereo_) put(OV2_BA_RANCH_INV, p, kp.runpx_, 1); }
+            else { put(OV2_BA_L_INV, p, kp.unpx_, 0); if (kp.is_stereo_) put(OV2_BA_R_INV, p, kp.runpx_, 1); }
+        }
+    }
+    if (rtype.empty()) return OV2_OK;
+    ov2_ba_problem P;
+    std::memset(&P, 0, sizeof(P));
+    P.calib_l[0] = cl.fx_; P.calib_l[1] = cl.fy_; P.calib_l[2] = cl.cx_; P.calib_l[3] = cl.cy_;
+    P.calib_r[0] = cr.fx_; P.calib_r[1] = cr.fy_; P.calib_r[2] = cr.cx_; P.calib_r[3] = cr.cy_;
+    const SE3 Trl = cr.Tc0ci_.inverse();
+    for (int i = 0; i < 7; ++i) P.T_rl[i] = Trl.v[i];
+    P.inv_depth = 1;
+    P.n_pose = nw; P.pose = pose.data(); P.pose_const = pconst.data();
+    P.n_lm = (int)lm.size(); P.lm = lm.data(); P.lm_anchor_pose = anch.data(); P.lm_anchor_uv = auv.data();
+    P.n_res = (int)rtype.size(); P.res_type = rtype.data(); P.res_pose = rpose.data(); P.res_lm = rlm.data(); P.res_uv = ruv.data();
+    ov2_ba_options o;
+    ov2_ba_default_options(&o, pslamstate_->robust_mono_th_);
+    ov2_ba_result R;
+    std::memset(&R, 0, sizeof(R));
+    std::vector<uint8_t> outlier((size_t)P.n_res);
+    R.outlier = outlier.data();
+    const ov2_status s = ov2_ba_solve(ctx_, &P, &o, &R);
+    if (s != OV2_OK) return s;
+    last_.ba_done = 1; last_.ba_res = P.n_res; last_.ba_it_robust = R.n_log_robust - 1;
+    last_.ba_it_l2 = R.l2_done ? R.n_log - R.n_log_robust - 1 : 0;
+    last_.ba_cost0 = R.initial_cost; last_.ba_cost1 = R.l2_done ? R.l2_final_cost : R.final_cost;
+    for (int p = 0; p < nw; ++p)
+        if (!pconst[p]) { SE3 T; for (int k = 0; k < 7; ++k) T.v[k] = pose[7 * (size_t)p + k]; win[p]->setTwc(T); }
+    for (size_t l = 0; l < lm.size(); ++l) {   // landmark back to world coordinates through its (updated) anchor
+        const int pa = anch[l];
+        const double zi = 1. / lm[l], u = auv[2 * l], v = auv[2 * l + 1];
+        const Vec3 pc{(u - cl.cx_) / cl.fx_ * zi, (v - cl.cy_) / cl.fy_ * zi, zi};
+        pmap_->getMapPoint(lm_id[l])->setPoint(win[pa]->getTwc() * pc);
+    }
+    for (int j = 0; j < P.n_res; ++j) {
+        if (!outlier[j]) continue;
+        ++last_.ba_outliers;
+        const Key &q = rkey[j];
+        auto &f = win[q.p];
+        if (!f->mapkps_.count(q.lmid)) continue;
+        if (q.right) f->removeStereoKeypointById(q.lmid);
+        else {
+            f->removeKeypointById(q.lmid);
+            if (q.p == nw - 1) pcurframe_->removeKeypointById(q.lmid);
+        }
+    }
+    if (policy_.pose_from_kf) pcurframe_->setTwc(win[nw - 1]->getTwc());
+    return OV2_OK;
+}
+
+}  // namespace ov2

@@ -63,6 +63,13 @@ def lib():
             fn.argtypes, fn.restype = [C.c_void_p], None
         L.ov2h_ba_pipeline_set_counting.argtypes, L.ov2h_ba_pipeline_set_counting.restype = [C.c_void_p, C.c_int], None
         L.ov2h_ba_pipeline_stats.argtypes, L.ov2h_ba_pipeline_stats.restype = [C.c_void_p, dp], None
+        L.ov2h_slam_create.argtypes = [C.c_void_p, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int]
+        L.ov2h_slam_create.restype = C.c_void_p
+        L.ov2h_slam_add_stereo.argtypes = [C.c_void_p, C.c_double, u8, u8, C.c_int, C.c_int]
+        L.ov2h_slam_pose.argtypes, L.ov2h_slam_pose.restype = [C.c_void_p, dp], None
+        L.ov2h_slam_stats.argtypes, L.ov2h_slam_stats.restype = [C.c_void_p, dp], None
+        L.ov2h_slam_landmarks.argtypes = [C.c_void_p, C.c_int, ip, dp]
+        L.ov2h_slam_destroy.argtypes, L.ov2h_slam_destroy.restype = [C.c_void_p], None
         L.ov2h_compute_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_int, dp, ip]
         L.ov2h_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
         L.ov2h_get_landmark.argtypes = [C.c_void_p, C.c_int, dp, ip]
@@ -323,6 +330,58 @@ class EstimatorWorker:
         if getattr(self, "h", None):
             lib().ov2h_ba_worker_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class CppSlam:
+    """ov2::SlamManager of libov2host.so (host/ov2_slam.hpp): the closed loop in C++ -- VisualFrontEnd::visualTracking per
+    frame, MapManager::createKeyframe + Mapper::run + Estimator::applyLocalBA per keyframe -- driven one stereo frame per call.
+    policy: None = the reference's own heuristics (checkNewKfReq, covisibility local BA, se3 motion model, its triangulation);
+    'slam_loop' = the fixed stand-ins of ov2slam_amd.slam_loop.SlamLoop (keyframe every kf_every frames, BA over the last
+    ba_window keyframes, ...), which makes the two loops comparable pose by pose."""
+
+    STAT_KEYS = ("frame", "tracked", "n3d", "kf", "new_kps", "stereo", "n_lm", "ba", "ba_res", "ba_it_robust", "ba_it_l2",
+                 "ba_outliers", "ba_cost0", "ba_cost1", "keyframes", "landmarks")
+
+    def __init__(self, ctx, K4, baseline, w, h, cell=35, rectified=True, policy=None, kf_every=5, ba_window=8, ba_fixed=2,
+                 device_map=False):
+        pol = np.zeros(6, np.int32)
+        if policy == "slam_loop":
+            pol[:] = [kf_every, ba_window, ba_fixed, 1, 1, 1]
+        elif policy is not None:
+            raise ValueError(policy)
+        K = np.ascontiguousarray(K4, np.float64)
+        self.w, self.h, self.ctx = w, h, ctx
+        self.h_ = lib().ov2h_slam_create(ctx.h, _dp(K), float(baseline), w, h, cell, int(bool(rectified)),
+                                         pol.ctypes.data_as(C.POINTER(C.c_int)), int(bool(device_map)))
+        if not self.h_:
+            raise RuntimeError("ov2h_slam_create failed")
+        self.traj, self.stats = [], []
+
+    def step(self, time, img_left, img_right):
+        u8 = C.POINTER(C.c_uint8)
+        a, b = np.ascontiguousarray(img_left, np.uint8), np.ascontiguousarray(img_right, np.uint8)
+        st = lib().ov2h_slam_add_stereo(self.h_, float(time), a.ctypes.data_as(u8), b.ctypes.data_as(u8), self.w, self.h)
+        if st != 0:
+            raise RuntimeError(f"SlamManager::addNewStereoImages failed ({st}): {self.ctx.lib.ov2_last_error(self.ctx.h)}")
+        T, s = np.zeros(7), np.zeros(16)
+        lib().ov2h_slam_pose(self.h_, _dp(T))
+        lib().ov2h_slam_stats(self.h_, _dp(s))
+        self.traj.append(T)
+        self.stats.append(dict(zip(self.STAT_KEYS, s.tolist())))
+        return T
+
+    def landmarks(self, cap=1 << 16):
+        ids, xyz = np.zeros(cap, np.int32), np.zeros((cap, 3))
+        n = lib().ov2h_slam_landmarks(self.h_, cap, ids.ctypes.data_as(C.POINTER(C.c_int)), _dp(xyz))
+        return ids[:n].copy(), xyz[:n].copy()
+
+    def close(self):
+        if getattr(self, "h_", None):
+            lib().ov2h_slam_destroy(self.h_)
+            self.h_ = None
 
     def __del__(self):
         self.close()

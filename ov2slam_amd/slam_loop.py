@@ -95,6 +95,7 @@ class SlamLoop:
         self.kfs = []            # dict(kfid, Twc, obs {lmid: (ul (2,), ur (2,) or None)})
         self.traj = []
         self.stats = []
+        self.kps_log = []        # ids of the keypoints in the current frame at the end of every step
 
     # ---- helpers
     def _bv(self, px):
@@ -148,6 +149,7 @@ class SlamLoop:
         self.prev_pyr = cur_pyr
         self.traj.append(self.Twc.copy())
         self.stats.append(st)
+        self.kps_log.append(sorted(self.kps))
         return self.Twc
 
     # ---- keyframe: detect, stereo match, triangulate, local BA

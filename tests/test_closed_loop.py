@@ -47,3 +47,47 @@ def test_hip_loop_matches_oracle_loop(ctx, oracle_loop, scene):
         assert np.abs(a[3:] - b[3:]).max() <= 1e-4, t
     assert [s["tracked"] for s in gl.stats] == [s["tracked"] for s in ol.stats]
     assert sorted(gl.lms) == sorted(ol.lms)
+
+
+@pytest.mark.gpu
+def test_cpp_loop_matches_the_python_loop(ctx, scene):
+    """ov2::SlamManager (libov2host.so: visualTracking -> createKeyframe -> Mapper::run -> local BA, all in C++ over the C
+    ABI) with the fixed stand-ins of SlamLoop for the keyframe decision / BA window reproduces the Python loop over the same
+    ABI pose by pose (the Python loop in turn equals the loop over the CPU oracle, test above): same track counts, same
+    landmark ids, poses to 1e-9 (the two differ in the order their hash maps hand keypoints to ceresPnP and in how they
+    compose the motion prediction)."""
+    from ov2slam_amd import host_map
+    n = 16
+    pl = _run(slam_loop.HipBackend(ctx), scene, n)
+    cl = host_map.CppSlam(ctx, synth_scene.K4, synth_scene.BASELINE, synth_scene.W, synth_scene.H, policy="slam_loop")
+    for t in range(n):
+        cl.step(0.05 * t, scene.left(t), scene.right(t))
+    assert [int(s["tracked"]) for s in cl.stats[1:]] == [len(k) for k in _kps_per_frame(pl)][1:]
+    assert [bool(s["kf"]) for s in cl.stats] == [s["kf"] for s in pl.stats]
+    for t, (a, b) in enumerate(zip(cl.traj, pl.traj)):
+        assert np.abs(a[:3] - b[:3]).max() <= 1e-9 and np.abs(np.abs(a[3:]) - np.abs(b[3:])).max() <= 1e-9, (t, a, b)
+    ids, xyz = cl.landmarks()
+    assert ids.tolist() == sorted(pl.lms)
+    assert np.abs(xyz - np.array([pl.lms[i] for i in sorted(pl.lms)])).max() < 1e-8
+
+
+def _kps_per_frame(loop):
+    """keypoints in the current frame at the END of every step of a SlamLoop (after PnP outliers, detection and BA removals)"""
+    return loop.kps_log
+
+
+@pytest.mark.gpu
+def test_cpp_loop_with_the_reference_policies_follows_ground_truth(ctx, scene):
+    """the same driver with the reference's own heuristics (checkNewKfReq, se3 motion model, covisibility local BA through
+    the device map mirror, rectified disparity triangulation): no oracle loop has those policies, so the check is ground truth"""
+    from ov2slam_amd import host_map
+    cl = host_map.CppSlam(ctx, synth_scene.K4, synth_scene.BASELINE, synth_scene.W, synth_scene.H, policy=None, device_map=True)
+    n = 30
+    for t in range(n):
+        cl.step(0.05 * t, scene.left(t), scene.right(t))
+    gt = [scene.pose(t) for t in range(n)]
+    assert slam_loop.ate_rmse(cl.traj, gt) < 0.01
+    assert sum(int(s["kf"]) for s in cl.stats) >= 3 and sum(int(s["ba"]) for s in cl.stats) >= 2
+    assert all(s["tracked"] > 150 for s in cl.stats[1:])
+    ids, xyz = cl.landmarks()
+    assert len(ids) > 200 and np.median(np.abs(xyz @ scene.nrm - scene.d)) < 0.05
