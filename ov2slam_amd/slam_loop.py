@@ -61,7 +61,8 @@ class HipBackend:
         return xy, st
 
     def pnp(self, unpx, wpts, Twc, K4):
-        return self.mvg.ceresPnP(unpx, wpts, Twc, 5, 5.9915, True, True, *K4)
+        # the reference's signature takes the intrinsics as float (include/multi_view_geometry.hpp:88-93)
+        return self.mvg.ceresPnP(unpx, wpts, Twc, 5, 5.9915, True, True, *np.float32(K4).astype(np.float64))
 
     def detect(self, pyr, img, cur_kps):
         return self.ext.detectSingleScale(pyr, cur_kps)

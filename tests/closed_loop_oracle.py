@@ -18,7 +18,7 @@ class OracleBackend:
         return out, st.astype(bool)
 
     def pnp(self, unpx, wpts, Twc, K4):
-        ok, T, outl, _ = self.O.pnp_solve(unpx, wpts, K4, Twc)
+        ok, T, outl, _ = self.O.pnp_solve(unpx, wpts, np.float32(K4).astype(np.float64), Twc)   # float intrinsics, as the reference passes them
         return ok, T, np.flatnonzero(outl).astype(np.int32)
 
     def detect(self, pyr, img, cur_kps):

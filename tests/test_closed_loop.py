@@ -60,13 +60,16 @@ def test_cpp_loop_matches_the_python_loop(ctx, scene):
     n = 16
     pl = _run(slam_loop.HipBackend(ctx), scene, n)
     cl = host_map.CppSlam(ctx, synth_scene.K4, synth_scene.BASELINE, synth_scene.W, synth_scene.H, policy="slam_loop")
-    for t in range(n):
-        cl.step(0.05 * t, scene.left(t), scene.right(t))
+    try:
+        for t in range(n):
+            cl.step(0.05 * t, scene.left(t), scene.right(t))
+        ids, xyz = cl.landmarks()
+    finally:
+        cl.close()   # before the session's context goes away
     assert [int(s["tracked"]) for s in cl.stats[1:]] == [len(k) for k in _kps_per_frame(pl)][1:]
     assert [bool(s["kf"]) for s in cl.stats] == [s["kf"] for s in pl.stats]
     for t, (a, b) in enumerate(zip(cl.traj, pl.traj)):
         assert np.abs(a[:3] - b[:3]).max() <= 1e-9 and np.abs(np.abs(a[3:]) - np.abs(b[3:])).max() <= 1e-9, (t, a, b)
-    ids, xyz = cl.landmarks()
     assert ids.tolist() == sorted(pl.lms)
     assert np.abs(xyz - np.array([pl.lms[i] for i in sorted(pl.lms)])).max() < 1e-8
 
@@ -82,12 +85,15 @@ def test_cpp_loop_with_the_reference_policies_follows_ground_truth(ctx, scene):
     the device map mirror, rectified disparity triangulation): no oracle loop has those policies, so the check is ground truth"""
     from ov2slam_amd import host_map
     cl = host_map.CppSlam(ctx, synth_scene.K4, synth_scene.BASELINE, synth_scene.W, synth_scene.H, policy=None, device_map=True)
-    n = 30
-    for t in range(n):
-        cl.step(0.05 * t, scene.left(t), scene.right(t))
+    n = 64   # the scene moves slowly: the reference's rule for this stream is 'stereo and more than 1 s since the last keyframe'
+    try:
+        for t in range(n):
+            cl.step(0.05 * t, scene.left(t), scene.right(t))
+        ids, xyz = cl.landmarks()
+    finally:
+        cl.close()
     gt = [scene.pose(t) for t in range(n)]
     assert slam_loop.ate_rmse(cl.traj, gt) < 0.01
     assert sum(int(s["kf"]) for s in cl.stats) >= 3 and sum(int(s["ba"]) for s in cl.stats) >= 2
     assert all(s["tracked"] > 150 for s in cl.stats[1:])
-    ids, xyz = cl.landmarks()
     assert len(ids) > 200 and np.median(np.abs(xyz @ scene.nrm - scene.d)) < 0.05
