@@ -157,26 +157,41 @@ ov2_status ov2_line_min_sad_dev(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr
                                 int go_left, int n, const float *d_pts_xy, const int32_t *d_img_idx, float *d_xprior,
                                 float *d_l1err);
 
+/* Lens model of a camera (CameraCalibration, src/camera_calibration.cpp): intrinsics + the distortion coefficients Dcv_.
+ * model 0: none (undistortImagePoint is the identity, :317-319); 1: radial-tangential k1 k2 p1 p2 [k3] (`pinhole`:
+ * cv::undistortPoints with P = K, five fixed-point sweeps / cv::projectPoints); 2: fisheye k1..k4 (cv::fisheye::
+ * undistortPoints, Newton on theta / cv::fisheye::distortPoints).  OpenCV is not vendored by the reference: restated from
+ * its published algorithms, the same restatement as the C++ host mirror's CameraCalibration (parity unpinned). */
+typedef struct ov2_cam_model {
+    double K[4];        /* fx fy cx cy */
+    int32_t model;      /* 0 none, 1 radial-tangential, 2 fisheye */
+    int32_t n_coeffs;   /* coefficients given in D (the others are 0) */
+    double D[5];
+} ov2_cam_model;
+
 /* Replaces the tracking + gating part of MapManager::stereoMatching(frame, vleftpyr, vrightpyr) (include/map_manager.hpp:96,
  * src/map_manager.cpp:493-604): keypoints with has_prior[i] are tracked left -> right on 2 levels from prior_xy[i]
  * (:497-541; priors from the 3D point or the neighbours' depth), their failures are re-queued on the full pyramid with the
  * UPDATED prior (:533-537, no 33 % rule here), the others on the full pyramid from prior_xy[i] (:544-580: kp.px_ or the
  * SAD prior); then the epipolar gate (:583-604): rectified != 0: |lunpx.y - r.y| <= 2 and the right point is moved onto
  * the left row (:592); otherwise MultiViewGeometry::computeSampsonDistance(F_rl, lunpx, runpx) <= 2
- * (src/multi_view_geometry.cpp:798-821; F_rl row-major = Frame::Frl_, src/frame.cpp:62).  Cameras without distortion
- * (Dcv_.empty(), src/camera_calibration.cpp:317-319: undistortImagePoint is the identity); lunpx_xy = the left undistorted
- * pixels (NULL = kps_xy).  out_status[i] = 1 where the reference reaches Frame::updateKeypointStereo(id, out_rxy[i]).
+ * (src/multi_view_geometry.cpp:798-821; F_rl row-major = Frame::Frl_, src/frame.cpp:62).  The gate works on UNDISTORTED
+ * pixels as the reference does (:586): lunpx_xy = the left undistorted pixels (NULL = kps_xy), and the tracked right pixel
+ * goes through right_cam's undistortImagePoint first (right_cam NULL or model 0: identity -- rectified / undistorted
+ * streams; the EuRoC stereo files of the reference run with bdo_stereo_rect 0 and radial-tangential lenses, i.e. with a
+ * model here).  out_rxy stays the RAW right pixel (Frame::updateKeypointStereo undistorts it itself).
+ * out_status[i] = 1 where the reference reaches Frame::updateKeypointStereo(id, out_rxy[i]).
  * Host pointers; the _dev form takes device pointers (F_rl stays a host pointer), is asynchronous, d_iters as in
  * ov2_klt_tracking_frame_dev. */
 ov2_status ov2_stereo_matching(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
                                int max_iter, float eps, float err_th, float fb_th, int n, const float *kps_xy,
                                const float *prior_xy, const uint8_t *has_prior, const float *lunpx_xy, int rectified,
-                               const double *F_rl, float *out_rxy, uint8_t *out_status);
+                               const double *F_rl, const ov2_cam_model *right_cam, float *out_rxy, uint8_t *out_status);
 ov2_status ov2_stereo_matching_dev(ov2_ctx *ctx, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
                                    int max_iter, float eps, float err_th, float fb_th, int n, const float *d_kps_xy,
                                    const float *d_prior_xy, const uint8_t *d_has_prior, const int32_t *d_img_idx,
-                                   const float *d_lunpx_xy, int rectified, const double *F_rl, float *d_out_rxy,
-                                   uint8_t *d_out_status, uint32_t *d_iters);
+                                   const float *d_lunpx_xy, int rectified, const double *F_rl, const ov2_cam_model *right_cam,
+                                   float *d_out_rxy, uint8_t *d_out_status, uint32_t *d_iters);
 
 /* ---- detectors (keyframe rate) -------------------------------------------------------------------- */
 enum { OV2_DETECT_FAST = 0, OV2_DETECT_MINEIG = 1 };
@@ -565,7 +580,8 @@ ov2_status ov2_describe_brief_dev(ov2_ctx *ctx, const ov2_pyr *pyr, int n, const
  * each; an empty set = desc_.empty()).  Keyframe lists = MapPoint::set_kfids_, ascending; kp_kf_px = the pixel of the
  * keypoint's map point in each of those keyframes (Frame::getKeypointById(lmid).px_); kf_Twc is indexed by kfid.
  * grid = Frame::vgridkps_ restricted to the listed keypoints, cells row-major (nbwcells = ceil(img_w / cell)), ids in
- * their vector order (they decide ties).  Cameras without distortion. */
+ * their vector order (they decide ties).  cam: the lens model of Frame::projWorldToImageDist (:631, :706; NULL or model 0 =
+ * the pinhole projection with K). */
 typedef struct ov2_match_input {
     double Twc[7], K[4];
     int32_t img_w, img_h, cell, nb3dkps;
@@ -586,6 +602,7 @@ typedef struct ov2_match_input {
     const int32_t *cand_kfids;
     int32_t n_kf;
     const double *kf_Twc;          /* n_kf x 7 */
+    const ov2_cam_model *cam;      /* lens model of the projections (host pointer), NULL = pinhole K */
 } ov2_match_input;
 
 /* match_cand[k] = index of the candidate matched to keypoint k or -1 (the reference's map_previd_newid: keypoint lmid ->

@@ -424,7 +424,7 @@ def _st_lib():
         L.ov2o_sampson_distance.argtypes = [f64p, C.c_float, C.c_float, C.c_float, C.c_float]
         L.ov2o_sampson_distance.restype = C.c_float
         L.ov2o_stereo_matching.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
-                                           C.c_int, f32p, f32p, u8p, f32p, C.c_int, f64p, f32p, u8p]
+                                           C.c_int, f32p, f32p, u8p, f32p, C.c_int, f64p, C.c_void_p, f32p, u8p]
         L._st_bound = True
     return L
 
@@ -463,7 +463,7 @@ def sampson_distance(F, l, r):
 
 
 def stereo_matching(left, right, kps_xy, prior_xy, has_prior, win=9, nlevels=3, err_th=30.0, fb_th=0.5, max_iter=30,
-                    eps=0.01, lunpx=None, rectified=True, F_rl=None):
+                    eps=0.01, lunpx=None, rectified=True, F_rl=None, right_cam=None):
     """tracking + gate of MapManager::stereoMatching on flat arrays. returns (right pixels, status)."""
     kps = np.ascontiguousarray(kps_xy, np.float32).reshape(-1, 2)
     pri = np.ascontiguousarray(prior_xy, np.float32).reshape(-1, 2)
@@ -474,8 +474,23 @@ def stereo_matching(left, right, kps_xy, prior_xy, has_prior, win=9, nlevels=3, 
     out, st = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
     _st_lib().ov2o_stereo_matching(left._h, right._h, win, nlevels, err_th, fb_th, max_iter, eps, n, _p(kps, f32p),
                                    _p(pri, f32p), _p(hp, u8p), None if lu is None else _p(lu, f32p), int(bool(rectified)),
-                                   _p(F, f64p), _p(out, f32p), _p(st, u8p))
+                                   _p(F, f64p), None if right_cam is None else C.cast(C.addressof(right_cam), C.c_void_p),
+                                   _p(out, f32p), _p(st, u8p))
     return out, st.astype(bool)
+
+
+def cam_undistort(cam, pts):
+    """CameraCalibration::undistortImagePoint for (n, 2) float32 pixels"""
+    L = _st_lib()
+    L.ov2o_cam_undistort.argtypes = [C.c_void_p, C.c_float, C.c_float, f32p, f32p]
+    L.ov2o_cam_undistort.restype = None
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    a, b = C.c_float(), C.c_float()
+    for i, (u, v) in enumerate(pts):
+        L.ov2o_cam_undistort(None if cam is None else C.addressof(cam), float(u), float(v), C.byref(a), C.byref(b))
+        out[i] = (a.value, b.value)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -126,13 +126,19 @@ float ov2o_sampson_distance(const double F[9], float lx, float ly, float rx, flo
 /* tracking + epipolar gate of MapManager::stereoMatching on flat arrays (src/map_manager.cpp:493-604) */
 void ov2o_stereo_matching(const ov2o_pyr *left, const ov2o_pyr *right, int win, int nlevels_full, float err_th, float fb_th,
                           int max_iter, float eps, int n, const float *kps_xy, const float *prior_xy,
-                          const uint8_t *has_prior, const float *lunpx_xy, int rectified, const double F_rl[9],
+                          const uint8_t *has_prior, const float *lunpx_xy, int rectified, const double F_rl[9], const ov2_cam_model *right_cam,
                           float *out_rxy, uint8_t *out_status);
 
 /* ---- keyframe descriptors and map matching (ov2_oracle_match.c) ------------------------------------ */
 /* FeatureExtractor::describeBRIEF (src/feature_extractor.cpp:224-285) with a caller-supplied 256 x 4 test table */
 void ov2o_describe_brief(const uint8_t *img, int w, int h, int stride, int n, const float *pts_xy, const int8_t *pattern,
                          uint8_t *desc, uint8_t *valid);
+/* CameraCalibration::undistortImagePoint / projectCamToImageDist (src/camera_calibration.cpp:254-332) = OpenCV's
+ * undistortPoints (5 sweeps) / projectPoints / fisheye::undistortPoints / fisheye::distortPoints restated from their published
+ * definitions (OpenCV is not vendored: parity unpinned).  cam NULL or model 0: the pinhole maps. */
+void ov2o_cam_undistort(const ov2_cam_model *cam, float u, float v, float *ou, float *ov);
+void ov2o_cam_project_dist(const ov2_cam_model *cam, const double K[4], const double pc[3], float *px, float *py);
+
 /* Mapper::matchToMap (src/mapper.cpp:576-774) on the flat inputs of ov2_match_input (include/ov2slam_hip.h) */
 void ov2o_match_to_map(const ov2_match_input *in, float fmaxprojerr, float fdistratio, int32_t *match_cand, float *match_dist);
 

@@ -101,8 +101,8 @@ void ov2o_match_to_map(const ov2_match_input *in, float fmaxprojerr, float fdist
         if (campt[2] < 0.1) continue;                                       /* :631 */
         const float view_angle = (float)(campt[2] / sqrt(campt[0] * campt[0] + campt[1] * campt[1] + campt[2] * campt[2]));
         if (fabsf(view_angle) < view_th) continue;                          /* :637 */
-        const double invz = 1. / campt[2];
-        const float px = (float)(in->K[0] * (campt[0] * invz) + in->K[2]), py = (float)(in->K[1] * (campt[1] * invz) + in->K[3]);
+        float px, py;                                        /* Frame::projWorldToImageDist (:631) */
+        ov2o_cam_project_dist(in->cam, in->K, campt, &px, &py);
         if (!(px >= 0 && py >= 0 && px < (float)in->img_w && py < (float)in->img_h)) continue;   /* isInImage :643 */
         const float mindist = (float)((double)(32.f * fdistratio) * 8.);    /* desc_.cols * fdistratio * 8. */
         int bestid = -1, secid = -1;
@@ -134,8 +134,8 @@ void ov2o_match_to_map(const ov2_match_input *in, float fmaxprojerr, float fdist
                         if (kfid < 0 || kfid >= in->n_kf) continue;
                         double cp[3];
                         world_to_cam(in->kf_Twc + 7 * (size_t)kfid, wpt, cp);
-                        const double iz = 1. / cp[2];
-                        const float qx = (float)(in->K[0] * (cp[0] * iz) + in->K[2]), qy = (float)(in->K[1] * (cp[1] * iz) + in->K[3]);
+                        float qx, qy;
+                        ov2o_cam_project_dist(in->cam, in->K, cp, &qx, &qy);
                         const float ex = in->kp_kf_px[2 * e] - qx, ey = in->kp_kf_px[2 * e + 1] - qy;
                         coprojpx = (float)((double)coprojpx + sqrt((double)ex * ex + (double)ey * ey));
                         nbcokp++;

@@ -144,6 +144,69 @@ float ov2o_sampson_distance(const double F[9], float lx, float ly, float rx, flo
     return sqrtf(num / den);
 }
 
+/* ---- lens models (see ov2_oracle.h) ------------------------------------------------------------------------------ */
+static double coef(const ov2_cam_model *c, int i) { return (c && i < c->n_coeffs && i < 5) ? c->D[i] : 0.0; }
+
+void ov2o_cam_undistort(const ov2_cam_model *c, float u_, float v_, float *ou, float *ov)
+{
+    if (!c || c->model == 0 || c->n_coeffs <= 0) { *ou = u_; *ov = v_; return; }
+    const double u = u_, v = v_, fx = c->K[0], fy = c->K[1], cx = c->K[2], cy = c->K[3];
+    if (c->model == 1) {   /* cv::undistortPoints(src, dst, K, D, noArray(), K): five fixed-point sweeps, no epsilon test */
+        const double k1 = coef(c, 0), k2 = coef(c, 1), p1 = coef(c, 2), p2 = coef(c, 3), k3 = coef(c, 4);
+        double x = (u - cx) * (1. / fx), y = (v - cy) * (1. / fy);
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1. + ((k3 * r2 + k2) * r2 + k1) * r2);
+            if (icdist < 0) { x = (u - cx) * (1. / fx); y = (v - cy) * (1. / fy); break; }
+            const double dX = 2. * p1 * x * y + p2 * (r2 + 2. * x * x), dY = p1 * (r2 + 2. * y * y) + 2. * p2 * x * y;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        *ou = (float)(fx * x + cx); *ov = (float)(fy * y + cy);
+        return;
+    }
+    /* cv::fisheye::undistortPoints: Newton on theta, at most ten steps */
+    const double pwx = (u - cx) / fx, pwy = (v - cy) / fy;
+    double theta_d = sqrt(pwx * pwx + pwy * pwy);
+    const double hp = 1.5707963267948966;
+    theta_d = theta_d < -hp ? -hp : (theta_d > hp ? hp : theta_d);
+    double scale = 1.0;
+    if (theta_d > 1e-8) {
+        double theta = theta_d;
+        for (int j = 0; j < 10; ++j) {
+            const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+            const double k0t2 = coef(c, 0) * t2, k1t4 = coef(c, 1) * t4, k2t6 = coef(c, 2) * t6, k3t8 = coef(c, 3) * t8;
+            const double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) / (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+            theta -= fix;
+            if (fabs(fix) < 1e-8) break;
+        }
+        scale = tan(theta) / theta_d;
+    }
+    *ou = (float)(fx * (pwx * scale) + cx); *ov = (float)(fy * (pwy * scale) + cy);
+}
+
+void ov2o_cam_project_dist(const ov2_cam_model *c, const double K[4], const double pc[3], float *px, float *py)
+{
+    const double invz = 1. / pc[2], x = pc[0] * invz, y = pc[1] * invz, fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    if (!c || c->model == 0 || c->n_coeffs <= 0) { *px = (float)(fx * x + cx); *py = (float)(fy * y + cy); return; }
+    const double xf = (double)(float)x, yf = (double)(float)y;   /* the reference hands OpenCV a Point3f / Point2f */
+    if (c->model == 1) {
+        const double k1 = coef(c, 0), k2 = coef(c, 1), p1 = coef(c, 2), p2 = coef(c, 3), k3 = coef(c, 4);
+        const double r2 = xf * xf + yf * yf, r4 = r2 * r2, r6 = r4 * r2;
+        const double a1 = 2 * xf * yf, a2 = r2 + 2 * xf * xf, a3 = r2 + 2 * yf * yf;
+        const double cdist = 1 + k1 * r2 + k2 * r4 + k3 * r6;
+        const double xd = xf * cdist + p1 * a1 + p2 * a2, yd = yf * cdist + p1 * a3 + p2 * a1;
+        *px = (float)(xd * fx + cx); *py = (float)(yd * fy + cy);
+        return;
+    }
+    const double r = sqrt(xf * xf + yf * yf), theta = atan(r);
+    const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double theta_d = theta * (1 + coef(c, 0) * t2 + coef(c, 1) * t4 + coef(c, 2) * t6 + coef(c, 3) * t8);
+    const double inv_r = r > 1e-8 ? 1.0 / r : 1.0, cdist = r > 1e-8 ? theta_d * inv_r : 1.0;
+    *px = (float)(fx * (xf * cdist) + cx); *py = (float)(fy * (yf * cdist) + cy);
+}
+
 /* The tracking + gating part of MapManager::stereoMatching on flat arrays (src/map_manager.cpp:493-604), for a camera
  * pair without distortion (Dcv_.empty(): undistortImagePoint is the identity, src/camera_calibration.cpp:317-319):
  *   has_prior[i] != 0 : keypoint i goes through the 2-level call with prior_xy[i] (v3dkps / v3dpriors, :497-541);
@@ -155,7 +218,7 @@ float ov2o_sampson_distance(const double F[9], float lx, float ly, float rx, flo
 void ov2o_stereo_matching(const ov2o_pyr *left, const ov2o_pyr *right, int win, int nlevels_full, float err_th, float fb_th,
                           int max_iter, float eps, int n, const float *kps_xy, const float *prior_xy,
                           const uint8_t *has_prior, const float *lunpx_xy /* NULL = kps_xy */, int rectified,
-                          const double F_rl[9], float *out_rxy, uint8_t *out_status)
+                          const double F_rl[9], const ov2_cam_model *right_cam, float *out_rxy, uint8_t *out_status)
 {
     int *ida = (int *)malloc((size_t)(n + 1) * sizeof(int)), *idb = (int *)malloc((size_t)(n + 1) * sizeof(int));
     float *ka = (float *)malloc((size_t)(n + 1) * 8), *pa = (float *)malloc((size_t)(n + 1) * 8);
@@ -187,7 +250,8 @@ void ov2o_stereo_matching(const ov2o_pyr *left, const ov2o_pyr *right, int win, 
     for (int i = 0; i < n; ++i) {                            /* :583-604 */
         if (!trk[i]) continue;
         const float lx = lunpx_xy ? lunpx_xy[2 * i] : kps_xy[2 * i], ly = lunpx_xy ? lunpx_xy[2 * i + 1] : kps_xy[2 * i + 1];
-        const float rx = out_rxy[2 * i], ry = out_rxy[2 * i + 1];   /* runpx = undistortImagePoint(r) = r */
+        float rx, ry;                                        /* runpx = pcalib_rightcam_->undistortImagePoint(r) (:586) */
+        ov2o_cam_undistort(right_cam, out_rxy[2 * i], out_rxy[2 * i + 1], &rx, &ry);
         float epi_err;
         if (rectified) {
             epi_err = fabsf(ly - ry);

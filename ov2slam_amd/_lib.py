@@ -56,9 +56,9 @@ SIGNATURES = {
     "ov2_line_min_sad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "ov2_line_min_sad_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "ov2_stereo_matching": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
-                                      vp, vp, vp, vp, C.c_int, vp, vp, vp]),
+                                      vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "ov2_stereo_matching_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,
-                                          vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
+                                          vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]),
     "ov2_detect_grid": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp, vp, C.c_int, ip, vp]),
     "ov2_detect_grid_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), ip, vp, vp, C.c_int, ip, vp, C.c_int]),
     "ov2_detect_grid_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]),

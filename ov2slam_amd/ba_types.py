@@ -15,6 +15,21 @@ u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)
 
 
+class CamModelC(C.Structure):
+    """ov2_cam_model: lens model of a camera (model 0 none, 1 radial-tangential k1 k2 p1 p2 [k3], 2 fisheye k1..k4)"""
+    _fields_ = [("K", C.c_double * 4), ("model", C.c_int32), ("n_coeffs", C.c_int32), ("D", C.c_double * 5)]
+
+    @classmethod
+    def make(cls, K4, model, coeffs):
+        m = cls()
+        m.K[:] = [float(v) for v in K4]
+        m.model = {"none": 0, "pinhole": 1, "radtan": 1, "fisheye": 2}.get(model, model)
+        c = [float(v) for v in coeffs][:5]
+        m.n_coeffs = len(c)
+        m.D[:] = c + [0.0] * (5 - len(c))
+        return m
+
+
 class BaProblemC(C.Structure):
     _fields_ = [("calib_l", C.c_double * 4), ("calib_r", C.c_double * 4), ("T_rl", C.c_double * 7),
                 ("inv_depth", C.c_int32), ("n_pose", C.c_int32), ("pose", dp), ("pose_const", u8p),

@@ -4,6 +4,7 @@
 //   match_*        Mapper::matchToMap src/mapper.cpp:576-774 on flat arrays (ov2_match_input)
 // Integer box sums and Hamming distances => bit-exact against the oracle; the float gates are evaluated in its order.
 #include "ov2_internal.h"
+#include "ov2_cam.h"
 
 namespace {
 
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(64) void brief_kernel(ov2_pyr_view pv, int n, const
 
 struct match_dev {   // device twin of ov2_match_input
     double Twc[7], K[4];
+    ov2_cam_model cam;   // Frame::projWorldToImageDist (model 0: the pinhole map with K)
     int img_w, img_h, cell, nb3dkps, n_kp, n_cand, n_kf, nbw, ncells;
     const float2 *kp_px; const int *kp_desc_ptr; const unsigned char *kp_descs; const int *kp_kf_ptr, *kp_kfids; const float2 *kp_kf_px;
     const int *grid_ptr, *grid_kp;
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(64) void match_cand_kernel(match_dev M, float dmaxp
     if (campt[2] < 0.1) return;
     const float view_angle = (float)(campt[2] / sqrt(campt[0] * campt[0] + campt[1] * campt[1] + campt[2] * campt[2]));
     if (fabsf(view_angle) < view_th) return;
-    const double invz = 1. / campt[2];
-    const float px = (float)(M.K[0] * (campt[0] * invz) + M.K[2]), py = (float)(M.K[1] * (campt[1] * invz) + M.K[3]);
+    float px, py;
+    ov2_cam_project_dist(M.cam, campt, px, py);
     if (!(px >= 0 && py >= 0 && px < (float)M.img_w && py < (float)M.img_h)) return;
     int bestid = -1, secid = -1;
     float bestdist = mindist, secdist = mindist;
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(64) void match_cand_kernel(match_dev M, float dmaxp
                         if (kfid < 0 || kfid >= M.n_kf) continue;
                         double cp[3];
                         world_to_cam(M.kf_Twc + 7 * (size_t)kfid, wpt, cp);
-                        const double iz = 1. / cp[2];
-                        const float qx = (float)(M.K[0] * (cp[0] * iz) + M.K[2]), qy = (float)(M.K[1] * (cp[1] * iz) + M.K[3]);
+                        float qx, qy;
+                        ov2_cam_project_dist(M.cam, cp, qx, qy);
                         const float ex = M.kp_kf_px[e].x - qx, ey = M.kp_kf_px[e].y - qy;
                         coprojpx = (float)((double)coprojpx + sqrt((double)ex * ex + (double)ey * ey));
                         ++nbcokp;
@@ -268,6 +270,9 @@ extern "C" ov2_status ov2_match_to_map(ov2_ctx *c, const ov2_match_input *in, fl
     match_dev M;
     for (int i = 0; i < 7; ++i) M.Twc[i] = in->Twc[i];
     for (int i = 0; i < 4; ++i) M.K[i] = in->K[i];
+    M.cam = ov2_cam_normalised(in->cam);
+    for (int i = 0; i < 4; ++i) M.cam.K[i] = in->K[i];   // one set of intrinsics: the frame's
+    if (M.cam.model < 0 || M.cam.model > 2) return ov2_set_err(c, OV2_ERR_INVALID, "unknown lens model %d", M.cam.model);
     M.img_w = in->img_w; M.img_h = in->img_h; M.cell = in->cell; M.nb3dkps = in->nb3dkps; M.n_kp = nkp; M.n_cand = nc; M.n_kf = in->n_kf;
     M.nbw = nbw; M.ncells = ncells;
     M.kp_px = (const float2 *)(d + o_kpx); M.kp_desc_ptr = (const int *)(d + o_kdp); M.kp_descs = (const unsigned char *)(d + o_kd);

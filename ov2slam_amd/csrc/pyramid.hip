@@ -1000,21 +1000,29 @@ ov2_status ov2_pyr_need_grad(ov2_ctx *c, const ov2_pyr *p)
 {
     if (!c || !p) return OV2_ERR_INVALID;
     ov2_pyr_buf *buf = p->buf;
-    std::lock_guard<std::mutex> g(p->ctx->mu);
-    if (buf->grad_built) {
-        OV2_HIP(c, hipStreamWaitEvent(c->stream, buf->grad_ev, 0));
-        return OV2_OK;
+    // The HIP calls run under the owning context's mutex (two consumer contexts must not both write the planes), so their
+    // failures are collected and reported AFTER the guard is gone: ov2_set_err locks the same mutex when c == p->ctx.
+    hipError_t err = hipSuccess;
+    const char *what = "";
+    {
+        std::lock_guard<std::mutex> g(p->ctx->mu);
+        if (buf->grad_built) {
+            err = hipStreamWaitEvent(c->stream, buf->grad_ev, 0); what = "hipStreamWaitEvent(grad_ev)";
+        } else if ((err = hipStreamWaitEvent(c->stream, buf->ready_ev, 0)) != hipSuccess) {
+            what = "hipStreamWaitEvent(ready_ev)";
+        } else {
+            const ov2_pyr_view &v = buf->view;
+            for (int l = 0; l < v.nlevels; ++l) {
+                const ov2_level_desc &L = v.lv[l];
+                OV2_LAUNCH(c, OV2_K_LEVEL, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, buf->batch), dim3(256), 0,
+                           c->stream, v, l, 0, 1);
+            }
+            if ((err = hipGetLastError()) != hipSuccess) what = "level_kernel launch";
+            else if ((err = hipEventRecord(buf->grad_ev, c->stream)) != hipSuccess) what = "hipEventRecord(grad_ev)";
+            else buf->grad_built = true;
+        }
     }
-    OV2_HIP(c, hipStreamWaitEvent(c->stream, buf->ready_ev, 0));
-    const ov2_pyr_view &v = buf->view;
-    for (int l = 0; l < v.nlevels; ++l) {
-        const ov2_level_desc &L = v.lv[l];
-        OV2_LAUNCH(c, OV2_K_LEVEL, level_kernel, dim3((L.w + TILE_W - 1) / TILE_W, (L.h + TILE_H - 1) / TILE_H, buf->batch), dim3(256), 0,
-                   c->stream, v, l, 0, 1);
-    }
-    OV2_HIP(c, hipGetLastError());
-    OV2_HIP(c, hipEventRecord(buf->grad_ev, c->stream));
-    buf->grad_built = true;
+    if (err != hipSuccess) return ov2_set_err(c, OV2_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
     return OV2_OK;
 }
 

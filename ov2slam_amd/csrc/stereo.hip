@@ -6,6 +6,7 @@
 // Integer SAD on 16-bit fixed-point bilinear samples (cv::getRectSubPix 8U -> 8U) => bit-exact against the oracle;
 // the gate's float expressions are evaluated in the oracle's order (-ffp-contract=off).
 #include "ov2_internal.h"
+#include "ov2_cam.h"
 
 namespace {
 
@@ -174,9 +175,11 @@ __global__ __launch_bounds__(64) void sad_kernel(ov2_pyr_view lv, ov2_pyr_view r
 struct gate_params {
     double F[9];
     int rectified;
+    ov2_cam_model rcam;   // the right camera's lens model (model 0: undistortImagePoint is the identity)
 };
 
-// src/map_manager.cpp:583-604 for cameras without distortion (undistortImagePoint = identity)
+// src/map_manager.cpp:583-604: the gate compares UNDISTORTED pixels (runpx = pcalib_rightcam_->undistortImagePoint(r), :586);
+// what is stored is the raw right pixel (its row snapped onto lunpx.y for rectified rigs, :592)
 __global__ __launch_bounds__(256) void epi_gate_kernel(int n, gate_params G, const float2 *__restrict__ kps,
                                                        const float2 *__restrict__ lunpx, float2 *__restrict__ rxy,
                                                        unsigned char *__restrict__ status)
@@ -185,13 +188,15 @@ __global__ __launch_bounds__(256) void epi_gate_kernel(int n, gate_params G, con
     if (i >= n || !status[i]) return;
     const float2 l = lunpx ? lunpx[i] : kps[i];
     float2 r = rxy[i];
+    float2 ru;
+    ov2_cam_undistort(G.rcam, r.x, r.y, ru.x, ru.y);
     float epi_err;
     if (G.rectified) {
-        epi_err = fabsf(l.y - r.y);
+        epi_err = fabsf(l.y - ru.y);
         r.y = l.y;            // :592: the right keypoint is put on the left row before the gate decides
         rxy[i] = r;
     } else {
-        const double lv[3] = {(double)l.x, (double)l.y, 1.0}, rv[3] = {(double)r.x, (double)r.y, 1.0};
+        const double lv[3] = {(double)l.x, (double)l.y, 1.0}, rv[3] = {(double)ru.x, (double)ru.y, 1.0};
         double Fl[3], Ftr[3];
         for (int k = 0; k < 3; ++k) {
             Fl[k] = G.F[3 * k] * lv[0] + G.F[3 * k + 1] * lv[1] + G.F[3 * k + 2] * lv[2];
@@ -261,8 +266,9 @@ extern "C" ov2_status ov2_line_min_sad(ov2_ctx *c, const ov2_pyr *left, const ov
 extern "C" ov2_status ov2_stereo_matching_dev(ov2_ctx *c, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
                                               int max_iter, float eps, float err_th, float fb_th, int n, const float *d_kps_xy,
                                               const float *d_prior_xy, const uint8_t *d_has_prior, const int32_t *d_img_idx,
-                                              const float *d_lunpx_xy, int rectified, const double *F_rl, float *d_out_rxy,
-                                              uint8_t *d_out_status, uint32_t *d_iters)
+                                              const float *d_lunpx_xy, int rectified, const double *F_rl,
+                                              const ov2_cam_model *right_cam, float *d_out_rxy, uint8_t *d_out_status,
+                                              uint32_t *d_iters)
 {
     if (!c) return OV2_ERR_INVALID;
     if (n == 0) return OV2_OK;
@@ -273,6 +279,8 @@ extern "C" ov2_status ov2_stereo_matching_dev(ov2_ctx *c, const ov2_pyr *left, c
     gate_params G;
     for (int k = 0; k < 9; ++k) G.F[k] = F_rl ? F_rl[k] : 0.0;
     G.rectified = rectified ? 1 : 0;
+    G.rcam = ov2_cam_normalised(right_cam);
+    if (G.rcam.model < 0 || G.rcam.model > 2) return ov2_set_err(c, OV2_ERR_INVALID, "unknown lens model %d", G.rcam.model);
     OV2_LAUNCH(c, K_GATE, epi_gate_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, G,
                reinterpret_cast<const float2 *>(d_kps_xy), reinterpret_cast<const float2 *>(d_lunpx_xy),
                reinterpret_cast<float2 *>(d_out_rxy), d_out_status);
@@ -283,7 +291,7 @@ extern "C" ov2_status ov2_stereo_matching_dev(ov2_ctx *c, const ov2_pyr *left, c
 extern "C" ov2_status ov2_stereo_matching(ov2_ctx *c, const ov2_pyr *left, const ov2_pyr *right, int win, int nlevels_full,
                                           int max_iter, float eps, float err_th, float fb_th, int n, const float *kps_xy,
                                           const float *prior_xy, const uint8_t *has_prior, const float *lunpx_xy, int rectified,
-                                          const double *F_rl, float *out_rxy, uint8_t *out_status)
+                                          const double *F_rl, const ov2_cam_model *right_cam, float *out_rxy, uint8_t *out_status)
 {
     if (!c) return OV2_ERR_INVALID;
     if (n == 0) return OV2_OK;
@@ -303,7 +311,7 @@ extern "C" ov2_status ov2_stereo_matching(ov2_ctx *c, const ov2_pyr *left, const
     OV2_HIP(c, hipMemcpyAsync(d + 4 * nb, h + 4 * nb, (size_t)n, hipMemcpyHostToDevice, c->stream));
     s = ov2_stereo_matching_dev(c, left, right, win, nlevels_full, max_iter, eps, err_th, fb_th, n, (const float *)d,
                                 (const float *)(d + nb), (const uint8_t *)(d + 4 * nb), nullptr,
-                                lunpx_xy ? (const float *)(d + 2 * nb) : nullptr, rectified, F_rl, (float *)(d + 3 * nb),
+                                lunpx_xy ? (const float *)(d + 2 * nb) : nullptr, rectified, F_rl, right_cam, (float *)(d + 3 * nb),
                                 (uint8_t *)(d + 4 * nb + n), nullptr);
     if (s != OV2_OK) return s;
     OV2_HIP(c, hipMemcpyAsync(h + 3 * nb, d + 3 * nb, nb, hipMemcpyDeviceToHost, c->stream));

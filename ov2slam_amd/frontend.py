@@ -277,8 +277,9 @@ class FeatureTracker:
         return xp, er
 
     def stereoMatching(self, vleftpyr, vrightpyr, nwinsize, nklt_pyr_lvl, ferr, fmax_fbklt_dist, vkps, vpriors, has_prior,
-                       lunpx=None, rectified=True, F_rl=None):
+                       lunpx=None, rectified=True, F_rl=None, right_cam=None):
         """tracking + epipolar gate of MapManager::stereoMatching (src/map_manager.cpp:493-604) on flat arrays.
+        right_cam: ba_types.CamModelC of the right camera (its undistortImagePoint feeds the gate, :586) or None.
         returns (right pixels (n,2) f32, status (n,) bool)."""
         ctx = self.ctx
         kps = np.ascontiguousarray(vkps, np.float32).reshape(-1, 2)
@@ -294,12 +295,13 @@ class FeatureTracker:
                                                   hp.ctypes.data_as(C.c_void_p),
                                                   None if lu is None else lu.ctypes.data_as(C.c_void_p), int(bool(rectified)),
                                                   None if F is None else F.ctypes.data_as(C.c_void_p),
+                                                  None if right_cam is None else C.addressof(right_cam),
                                                   out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
         return out, st.astype(bool)
 
     def stereoMatching_dev(self, vleftpyr, vrightpyr, nwinsize, nklt_pyr_lvl, ferr, fmax_fbklt_dist, d_kps, d_prior,
                            d_has_prior, d_out_rxy, d_out_status, n, d_img_idx=None, d_lunpx=None, rectified=True, F_rl=None,
-                           d_iters=None):
+                           d_iters=None, right_cam=None):
         """device-resident asynchronous form (ov2_stereo_matching_dev)"""
         ctx = self.ctx
         ptr = lambda a: None if a is None else (a.ptr if isinstance(a, DeviceArray) else a)
@@ -308,7 +310,8 @@ class FeatureTracker:
                                                       self.fmax_px_precision, ferr, fmax_fbklt_dist, n, ptr(d_kps),
                                                       ptr(d_prior), ptr(d_has_prior), ptr(d_img_idx), ptr(d_lunpx),
                                                       int(bool(rectified)),
-                                                      None if F is None else F.ctypes.data_as(C.c_void_p), ptr(d_out_rxy),
+                                                      None if F is None else F.ctypes.data_as(C.c_void_p),
+                                                      None if right_cam is None else C.addressof(right_cam), ptr(d_out_rxy),
                                                       ptr(d_out_status), ptr(d_iters)))
 
 

@@ -671,10 +671,18 @@ ov2_status MapManager::stereoMatching(Frame &frame, const Pyramid &vleftpyr, con
     static_assert(sizeof(Point2f) == 8, "packed floats");
     std::vector<Point2f> vout((size_t)n);
     std::vector<uint8_t> vstatus((size_t)n);
+    // the gate undistorts the tracked right pixel with the right camera's lens model (:586)
+    const CameraCalibration &cr = *frame.pcalib_rightcam_;
+    ov2_cam_model rcam;
+    std::memset(&rcam, 0, sizeof(rcam));
+    rcam.K[0] = cr.fx_; rcam.K[1] = cr.fy_; rcam.K[2] = cr.cx_; rcam.K[3] = cr.cy_;
+    rcam.model = cr.D_.empty() ? 0 : (cr.model_ == CameraCalibration::Fisheye ? 2 : 1);
+    rcam.n_coeffs = (int32_t)std::min<size_t>(cr.D_.size(), 5);
+    for (int k = 0; k < rcam.n_coeffs; ++k) rcam.D[k] = cr.D_[k];
     const ov2_status s = ov2_stereo_matching(tracker.ctx_, vleftpyr.h, vrightpyr.h, st.nklt_win_size_, st.nklt_pyr_lvl_,
                                              tracker.nmax_iter_, tracker.fmax_px_precision_, st.nklt_err_, st.fmax_fbklt_dist_, n,
                                              &vkps[0].x, &vpriors[0].x, vhas.data(), &vlunpx[0].x, st.bdo_stereo_rect_ ? 1 : 0,
-                                             frame.Frl_, &vout[0].x, vstatus.data());
+                                             frame.Frl_, &rcam, &vout[0].x, vstatus.data());
     if (s != OV2_OK) return s;
     for (int i = 0; i < n; ++i)                                             // :597-601
         if (vstatus[i]) frame.updateKeypointStereo(vids[i], vout[i]);

@@ -16,7 +16,7 @@ class MatchInputC(C.Structure):
                 ("nb3dkps", C.c_int32), ("n_kp", C.c_int32), ("kp_px", f32p), ("kp_desc_ptr", i32p), ("kp_descs", u8p),
                 ("kp_kf_ptr", i32p), ("kp_kfids", i32p), ("kp_kf_px", f32p), ("grid_ptr", i32p), ("grid_kp", i32p),
                 ("n_cand", C.c_int32), ("cand_wpt", f64p), ("cand_desc_ptr", i32p), ("cand_descs", u8p), ("cand_kf_ptr", i32p),
-                ("cand_kfids", i32p), ("n_kf", C.c_int32), ("kf_Twc", f64p)]
+                ("cand_kfids", i32p), ("n_kf", C.c_int32), ("kf_Twc", f64p), ("cam", C.c_void_p)]
 
 
 def _csr(lists, dtype, width=1):

@@ -123,3 +123,40 @@ def test_line_min_sad_bit_exact(ctx, oracle, stream, pair, level):
     gt = stream.stereo_gt(kps)[:, 0] / (1 << level)
     ok = (xp >= 0) & (pts[:2048, 0] > 40.0 / (1 << level) + 4)
     assert np.median(np.abs(xp[ok] - gt[ok])) < 1.0
+
+
+# EuRoC cam1 (parameters_files/accurate/euroc/euroc_stereo.yaml): radial-tangential coefficients of the right camera; the
+# reference runs these files with bdo_stereo_rect 0 / bdo_undist 0, i.e. through the Sampson gate on undistorted pixels
+EUROC_D1 = [-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05]
+K_R4 = [457.587, 456.134, 379.999, 255.238]
+
+
+@pytest.mark.parametrize("model,coeffs", [("radtan", EUROC_D1), ("fisheye", [-0.012, 0.009, -0.004, 0.001])])
+@pytest.mark.parametrize("rectified", [False, True])
+def test_stereo_gate_undistorts_the_right_pixel(ctx, oracle, stream, pair, model, coeffs, rectified):
+    """the epipolar gate with a distorted right camera (MapManager::stereoMatching :586: runpx = undistortImagePoint(r)):
+    same statuses and bit-identical stored right pixels as the oracle, and NOT the result of gating the raw pixels"""
+    from ov2slam_amd.ba_types import CamModelC
+    gl, gr, ol, orr = pair
+    n = 2048
+    kps = synth.grid_keypoints(n, seed=35)
+    gt = stream.stereo_gt(kps).astype(np.float32)
+    pri, has = synth.make_priors(kps, gt, seed=9)
+    cam = CamModelC.make(K_R4, model, coeffs)
+    # left undistorted pixels consistent with the lens: the right track undistorted, moved back by the disparity, so that the
+    # undistorted pair passes the gate while the raw pair (several px of distortion off the axis) often does not
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    raw, st0 = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, lunpx=kps, rectified=True)
+    und = oracle.cam_undistort(cam, raw)
+    lunpx = kps.copy()
+    lunpx[:, 1] = und[:, 1] + np.float32(0.3)
+    rxy, st = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, lunpx=lunpx, rectified=rectified, F_rl=F_RL.ravel(), right_cam=cam)
+    exy, est = oracle.stereo_matching(ol, orr, kps, pri, has, lunpx=lunpx, rectified=rectified, F_rl=F_RL.ravel(), right_cam=cam)
+    exact = model == "radtan"   # the fisheye model goes through tan(): the last bit of libm and the device may differ
+    assert (np.array_equal(st, est) if exact else (st != est).mean() < 0.002)
+    same = st == est
+    assert np.array_equal(rxy[same].view(np.uint32), exy[same].view(np.uint32))
+    nod, _ = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, lunpx=lunpx, rectified=rectified, F_rl=F_RL.ravel())[1], None
+    assert st.sum() > 0.5 * n
+    if rectified:
+        assert (nod != st).sum() > 20, "the lens model made no difference to the gate"
