@@ -511,9 +511,10 @@ def main():
     if ba:
         ba.set_counting(False)         # solves that complete after this instant do not count
         ba.refresh()
-        ba.stop()
+        ba.stop()                      # joins the worker threads: their in-flight batch runs to its end
     barrier()                          # the contract's closing barrier + device sync, outside the clock (it would wait for
                                        # the BA worker's in-flight batch, which is not front-end work)
+    el_closed = time.perf_counter() - t0   # ... the same interval closed by the device-wide sync (both conventions are reported)
     nbatches = a.steps * a.chunk
 
     # {frames, BA LM iterations, BA solves, BA jobs submitted, dropped}: the end-of-run reduction over RCCL
@@ -541,6 +542,9 @@ def main():
         "host_enqueue_ms_per_frame_batch": 1e3 * t_enq / nbatches,
         "keyframe_batches_per_frame_batch": nkf / nbatches,
         "timed_region_s": el_max,
+        "with_closing_device_sync": {"seconds": el_closed, "frames_per_sec": nbatches * a.seqs * world / el_closed if world == 1 else None,
+                                     "note": "the same K steps with the contract's barrier + device-wide synchronisation inside the clock: it "
+                                             "also waits for the local-BA worker's in-flight batch (whose solves are NOT counted) to drain"},
     }
     if ba and legacy_ba:
         out["local_ba"] = {"metric": "localBA_LM_iterations_per_sec", "value": ba_iters_all / el_max, "unit": "iters/s",
@@ -681,6 +685,19 @@ def main():
                            "limiter": "integer VALU issue, not HBM (profiles/*_klt_counters.md); the HBM fraction is reported "
                                       "because the contract asks for it, `valu` is the fraction that bounds the kernel",
                            "avg_launch_us": rl[dom]["avg_us"], "alg_bytes_per_launch": rl[dom]["alg_bytes_per_launch"]}
+        # the hipEvent pass above runs after the BA worker has stopped; inside the timed region the same kernel shares the
+        # device with the worker's batches: its average there comes from the committed rocprofv3 kernel trace of this command
+        try:
+            import csv as _csv
+            for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_stats.csv") and "noba" not in f):
+                for row in _csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+                    if row.get("Name") == dom:
+                        avg_ns = float(row["AverageNs"])
+                        out["roofline"]["in_region"] = {"avg_launch_us": avg_ns / 1e3, "frac": rl[dom]["alg_bytes_per_launch"] / (avg_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                                        "source": f"profiles/{fn} (rocprofv3 --kernel-trace --stats of this command, BA worker concurrent; "
+                                                                  "not measured in this run)"}
+        except Exception:
+            pass
         if "valu_frac" in rl[dom]:
             out["roofline"]["valu"] = {"achieved": rl[dom]["achieved_Tops"], "peak": VALU_PEAK_TOPS, "unit": "Tiop/s",
                                        "frac": rl[dom]["valu_frac"]}
