@@ -12,7 +12,8 @@ rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $ARGS > $O/kt.log 2>&1 || { tail -5 $O/kt.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $ARGS > $O/pmc_fetch.log 2>&1 || { tail -5 $O/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $ARGS > $O/pmc_write.log 2>&1 || { tail -5 $O/pmc_write.log; exit 1; }
-find $O -name "*.csv" | head -20
-# keep only what the summary needs (counter CSVs can be large)
-find $O -name "*agent_info*" -delete
+# summarised HERE: the per-dispatch counter CSVs are tens of MB and gpurun merges at most 64 MiB back
+mkdir -p $R/gpurun_out/prof_summary_$TAG
+python3 $R/scripts/summarize_prof.py $TAG $R/gpurun_out/prof_summary_$TAG > $R/gpurun_out/prof_summary_$TAG/summary.txt 2>&1
+find $O -name "*agent_info*" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete
 du -sh $O

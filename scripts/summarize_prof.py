@@ -40,7 +40,7 @@ def short(name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    out = os.path.join(ROOT, "profiles")
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")   # on the GPU box: a directory under gpurun_out/ (what gpurun merges back)
     os.makedirs(out, exist_ok=True)
     # gpurun merges every call's outputs into gpurun_out/: only the NEWEST file of a pass belongs to the current state
     newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]
