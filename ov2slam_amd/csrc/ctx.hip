@@ -64,6 +64,13 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->stage_host = c->stage_dev = nullptr;
     c->stage_cap = 0;
     c->stage_ev = nullptr;
+    {   // the tracking kernels' yield / resume (OV2_KLT_YIELD=after,groups switches it on; default 0,0 = off)
+        c->klt_epoch = 0; c->klt_ybuf = nullptr; c->klt_ybuf_bytes = 0;
+        c->klt_yield_after = 0; c->klt_yield_groups = 0;   // off: every variant measured slower than waiting for the stragglers (klt.hip, klt_rec)
+        const char *e = getenv("OV2_KLT_YIELD");
+        int a = 0, g = 0;
+        if (e && sscanf(e, "%d,%d", &a, &g) == 2 && a >= 0 && a <= 100 && g >= 0 && g <= 20) { c->klt_yield_after = g > 0 ? a : 0; c->klt_yield_groups = g; }
+    }
     c->stage_ev_pending = false;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
@@ -125,6 +132,7 @@ extern "C" void ov2_ctx_destroy(ov2_ctx *c)
     if (c->ba_copy_stream) { (void)hipStreamSynchronize(c->ba_copy_stream); (void)hipStreamDestroy(c->ba_copy_stream); }
     for (int i = 0; i < 2; ++i) if (c->ba_copy_ev[i]) (void)hipEventDestroy(c->ba_copy_ev[i]);
     if (c->ba_arena2) (void)hipFree(c->ba_arena2);
+    if (c->klt_ybuf) (void)hipFree(c->klt_ybuf);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     (void)hipEventDestroy(c->ev0);

@@ -30,6 +30,9 @@ struct klt_params {
     float err_th;    // nklt_err
     double fb_th;    // fmax_fbklt_dist promoted to double for the cv::norm comparison
     float min_eig_thr;
+    int y_pickup;            // k > 0: every k-th wave of the first launch takes one batch of stragglers itself; 0: none does
+    int y_after, y_groups;   // three-lane kernels: a level pass hands its last <= y_groups running keypoints over to the resume
+                             // launch once it has made y_after iterations (0 = never); see klt_rec
     int rule33;      // 1: VisualFrontEnd::kltTracking's "< 33 % good => drop every re-queued prior" (src/visual_front_end.cpp:228-233);
                      // 0: MapManager::stereoMatching re-queues the failures with the updated prior, no such rule (src/map_manager.cpp:533-537)
 };
@@ -593,11 +596,50 @@ __device__ __forceinline__ void klt3_store_region(const klt3_segs &S, int c, boo
 
 // One LKTrackerInvoker pass for the keypoint of this three-lane group; lane c owns window columns 3c .. 3c + 2.
 // `lane_ok` is false for the idle sixteenth lane of a DPP row (it computes along on zeros and never stores).
+// ---- divergence tail: yield and resume ----------------------------------------------------------------------------
+// A wave of 20 keypoints runs a level pass until its SLOWEST keypoint has converged: on a hard stream (large flow, poor
+// priors) a few keypoints iterate 15-30 times while 16-19 groups of the wave idle through every one of those iterations
+// at full issue cost.  So a pass that has made y_after iterations and is down to <= y_groups running keypoints stops: the
+// stragglers write their state (level, iteration count, position, previous step) to a list and leave the wave, which goes
+// on to the next level with the others.  A second, small launch (klt_resume_kernel) packs the stragglers of ALL waves 20
+// to a wave, rebuilds each one's template at its level (same integers) and continues the SAME iteration sequence from the
+// stored state, then the remaining levels and the backward pass.  Per-keypoint arithmetic is untouched, so results stay
+// bit-identical to the scalar oracle; what changes is which wave executes an iteration.
+// MEASURED (64 x 2048 keypoints, front-end alone, easy / hard stream in k frames/s; off = 208 / 121): stragglers to the resume
+// launch only, yield (6, 5): 184 / 109, (10, 3): 187 / 107 -- the first launch gets 38 us shorter, but the stragglers are the
+// longest chains of the call and a launch of ~330 of their waves cannot end before its slowest one (~70 us with most of the
+// device idle); letting the first launch's own waves take batches of stragglers as they finish (OV2_KLT_PICKUP = k: every
+// k-th wave, one compare-and-swap attempt each): 136 / 82 at best -- a wave that picks up a batch becomes a long chain
+// itself.  (On the way: a retry loop around that compare-and-swap held the launch for 5-20 ms -- thousands of waves finish
+// within microseconds of each other -- and a release / acquire fence pair per record at agent scope cost the same: it
+// writes back / invalidates the issuing XCD's whole L2.)  The waiting lanes are cheaper than any of this, so the switch
+// is OFF by default (ov2_klt_set_yield / OV2_KLT_YIELD turn it on); the tests run every setting against the oracle.
+struct klt_rec {
+    int i;               // keypoint
+    int info;            // bits 0-3 level, bit 4: backward pass, bit 5: list A (2-level call), bits 8-15: iterations made in the pass
+    float nx, ny;        // position of the pass (level scale), = nx_io / ny_io: what the pass would return if it ended here
+    float rx, ry;        // the loop's own running position (nx_io - half is NOT it: nx_io = fl(running + half) has been rounded)
+    float pdx, pdy;      // previous step (the oscillation test reads it)
+    float fx, fy;        // backward pass: the forward result
+    unsigned it, passes; // work so far
+    float err;           // backward pass: the forward minimum eigenvalue (gate already taken)
+};
+// In memory a record is KLT_REC_WORDS 64-bit words, each (epoch << 32) | one 32-bit field: every word validates itself, so
+// a record can be handed from a running wave to another one of the SAME launch with relaxed device-scope atomic stores /
+// loads and no fence -- on this device a release / acquire pair at agent scope writes back / invalidates the whole L2 of
+// the issuing XCD (measured: the launch went from 0.14 to 8.5 ms with a fence per record).  The buffer belongs to the
+// context and is only ever written here, with the call's serial number as epoch: a word of an older call never matches.
+#define KLT_REC_WORDS 13
+#define KLT_REC_STRIDE 16   // 64-bit words per record slot (128 bytes)
+static_assert(sizeof(klt_rec) == 4 * KLT_REC_WORDS, "one tagged word per 32-bit field");
+struct lk_res { bool here; int j0; float pdx, pdy, rx, ry; };   // this lane's group resumes IN this pass
+struct lk_yld { int after, groups; bool yielded; int j; float pdx, pdy, rx, ry; };
+
 template <int WIN>
 __device__ __forceinline__ int lk_level3(const level_ptrs &I, const level_ptrs &J, int pad, int level, int max_level,
                                          bool run, float kx, float ky, float &nx_io, float &ny_io, int &status,
                                          float &err, const klt_params &P, int c, bool lane_ok, unsigned &passes,
-                                         unsigned char *lj)
+                                         unsigned char *lj, const lk_res &R, lk_yld &Y)
 {
     static_assert(WIN == 9, "three lanes x three columns");
     constexpr int NPX = 3 * WIN, NQ = (NPX + 1) / 2;   // window pixels per lane, flat e = 3 * row + column; pairs of them
@@ -606,7 +648,8 @@ __device__ __forceinline__ int lk_level3(const level_ptrs &I, const level_ptrs &
     const float lscale = __builtin_ldexpf(1.f, -level);
     float px = kx * lscale, py = ky * lscale;
     float nx, ny;
-    if (level == max_level) { nx = nx_io * lscale; ny = ny_io * lscale; }
+    if (R.here) { nx = nx_io; ny = ny_io; }   // a resumed pass continues where it stopped
+    else if (level == max_level) { nx = nx_io * lscale; ny = ny_io * lscale; }
     else { nx = nx_io * 2.f; ny = ny_io * 2.f; }
     if (run) { nx_io = nx; ny_io = ny; }
 
@@ -762,10 +805,18 @@ __device__ __forceinline__ int lk_level3(const level_ptrs &I, const level_ptrs &
     D = __fdiv_rn(1.f, D);
 
     nx -= half; ny -= half;
-    float pdx = 0.f, pdy = 0.f;
+    if (R.here) { nx = R.rx; ny = R.ry; }   // bit for bit the value the loop held when it stopped
+    float pdx = R.here ? R.pdx : 0.f, pdy = R.here ? R.pdy : 0.f;
+    int jl = R.here ? R.j0 : 0;   // iterations the GROUP has made in this pass (a resumed group starts above zero)
     int iters = 0;
-    for (int j = 0; j < P.max_iter; ++j) {
+    for (int trip = 0; trip < P.max_iter; ++trip) {
         if (!__any(run)) break;
+        if (Y.after > 0 && trip >= Y.after) {   // wave-uniform: the pass is down to its stragglers -> they leave (see klt_rec)
+            if (__popcll(__ballot(run)) <= 3 * Y.groups) {
+                if (run) { Y.yielded = true; Y.j = jl; Y.pdx = pdx; Y.pdy = pdy; Y.rx = nx; Y.ry = ny; run = false; }
+                break;
+            }
+        }
         const int inx = (int)floorf(nx), iny = (int)floorf(ny);
         if (run && (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h)) {
             if (level == 0) status = 0;
@@ -838,15 +889,16 @@ __device__ __forceinline__ int lk_level3(const level_ptrs &I, const level_ptrs &
             nx_io = nx + half; ny_io = ny + half;
 #ifdef KLT_EXP_FIXED_ITERS   // timing experiments: every pass runs exactly this many iterations around the start position
             nx -= dx; ny -= dy;
-            if (j + 1 >= KLT_EXP_FIXED_ITERS) run = false;
+            if (trip + 1 >= KLT_EXP_FIXED_ITERS) run = false;
 #else
             if ((double)dx * dx + (double)dy * dy <= P.eps2) run = false;
-            else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+            else if (jl > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nx_io -= dx * 0.5f; ny_io -= dy * 0.5f;
                 run = false;
             }
 #endif
             pdx = dx; pdy = dy;
+            if (++jl >= P.max_iter) run = false;   // criteria.maxCount
         }
     }
     return iters;
@@ -861,8 +913,10 @@ __device__ __forceinline__ int lk_pass(const level_ptrs &I, const level_ptrs &J,
                                        const klt_params &P, int sub, bool lane_ok, unsigned &passes, unsigned char *smem, int slot)
 {
     if constexpr (GL == 3) {
+        const lk_res R0 = {false, 0, 0.f, 0.f, 0.f, 0.f};
+        lk_yld Y0 = {0, 0, false, 0, 0.f, 0.f, 0.f, 0.f};
         return lk_level3<WIN>(I, J, pad, level, max_level, run, kx, ky, nx_io, ny_io, status, err, P, sub, lane_ok, passes,
-                              smem + slot * klt3::RSZ);
+                              smem + slot * klt3::RSZ, R0, Y0);
     } else {
         constexpr int KPW = 64 / GL, WB = klt_lds<WIN>::WB, GB = klt_lds<WIN>::GB;
         return lk_level<WIN, GL>(I, J, pad, level, max_level, run, kx, ky, nx_io, ny_io, status, err, P, sub, passes,
@@ -906,6 +960,125 @@ __device__ __forceinline__ int fb_track(const ov2_pyr_view &pv, const ov2_pyr_vi
     }
     work = it | (passes << 16);
     return ok;
+}
+
+// fb_track for the three-lane mapping with the yield / resume protocol of klt_rec.  rin: the record this group resumes from
+// (null: a fresh keypoint).  Returns the status as fb_track does; `yielded` = the group left in the middle of a pass and
+// `rout` holds its state (nothing else of the keypoint may be written then).
+template <int WIN>
+__device__ __forceinline__ int fb_track3(const ov2_pyr_view &pv, const ov2_pyr_view &cv, int b, bool act, float kx, float ky,
+                                         float &fx, float &fy, const klt_params &P, int nlevels, int top_level, int sub,
+                                         bool lane_ok, unsigned &work, unsigned char *smem, int slot, int y_after, int y_groups,
+                                         const klt_rec *rin, klt_rec &rout, bool &yielded)
+{
+    int status = 1;
+    float err = 0.f;
+    unsigned it = rin ? rin->it : 0u, passes = rin ? rin->passes : 0u;
+    const bool rback = rin && (rin->info & 16);
+    const int rlevel = rin ? (rin->info & 15) : nlevels;
+    const int rj = rin ? ((rin->info >> 8) & 0xff) : 0;
+    yielded = false;
+    unsigned char *lds = smem + slot * klt3::RSZ;
+    if (rin && !rback) { fx = rin->nx; fy = rin->ny; }
+    for (int l = nlevels; l >= 0; --l) {
+        const level_ptrs I = level_of(pv, l, b), J = level_of(cv, l, b);
+        const bool run = act && !yielded && !rback && l <= rlevel;
+        const lk_res R = {rin && !rback && l == rlevel, rj, rin ? rin->pdx : 0.f, rin ? rin->pdy : 0.f, rin ? rin->rx : 0.f, rin ? rin->ry : 0.f};
+        lk_yld Y = {y_after, y_groups, false, 0, 0.f, 0.f, 0.f, 0.f};
+        it += lk_level3<WIN>(I, J, pv.pad, l, top_level, run, kx, ky, fx, fy, status, err, P, sub, lane_ok, passes, lds, R, Y);
+        if (Y.yielded) {
+            yielded = true;
+            rout.info = l | (Y.j << 8); rout.nx = fx; rout.ny = fy; rout.rx = Y.rx; rout.ry = Y.ry; rout.pdx = Y.pdx; rout.pdy = Y.pdy; rout.fx = 0.f; rout.fy = 0.f;
+            rout.err = 0.f;
+        }
+    }
+    const int W0 = cv.lv[0].w, H0 = cv.lv[0].h;
+    int ok;
+    if (rback) { ok = act; fx = rin->fx; fy = rin->fy; err = rin->err; }   // the gates were taken before the backward pass began
+    else ok = act && !yielded && status && !(err > P.err_th) && (1.f <= fx && fx < (float)W0 - 1.f && 1.f <= fy && fy < (float)H0 - 1.f);
+    int st2 = 1;
+    float e2 = 0.f, bx = rback ? rin->nx : kx, by = rback ? rin->ny : ky;
+    {
+        const level_ptrs I = level_of(cv, 0, b), J = level_of(pv, 0, b);
+        const lk_res R = {rback, rj, rin ? rin->pdx : 0.f, rin ? rin->pdy : 0.f, rin ? rin->rx : 0.f, rin ? rin->ry : 0.f};
+        lk_yld Y = {y_after, y_groups, false, 0, 0.f, 0.f, 0.f, 0.f};
+        it += lk_level3<WIN>(I, J, cv.pad, 0, 0, ok != 0, fx, fy, bx, by, st2, e2, P, sub, lane_ok, passes, lds, R, Y);
+        if (Y.yielded) {
+            yielded = true;
+            rout.info = 16 | (Y.j << 8); rout.nx = bx; rout.ny = by; rout.rx = Y.rx; rout.ry = Y.ry; rout.pdx = Y.pdx; rout.pdy = Y.pdy; rout.fx = fx; rout.fy = fy;
+            rout.err = err;
+        }
+    }
+    if (ok && !yielded) {
+        if (!st2) ok = 0;
+        else {
+            const float dx = kx - bx, dy = ky - by;
+            const double nrm = __dsqrt_rn((double)dx * dx + (double)dy * dy);  // cv::norm(Point2f) is double
+            if (nrm > P.fb_th) ok = 0;
+        }
+    }
+    rout.it = it; rout.passes = passes;
+    work = it | (passes << 16);
+    return ok;
+}
+
+// the keypoints that yielded in this wave go to the resume list (one atomic per wave that has any)
+// A record is PUBLISHED by its epoch word (the call's serial number), stored after a fence behind the other fields:
+// waves of the same launch pick records up while their producers are still running (klt_take_yielded).
+__device__ __forceinline__ void klt_push_yielded(bool push, const klt_rec &r, unsigned long long *__restrict__ ylist, unsigned *__restrict__ ycnt, int epoch)
+{
+    const unsigned long long ym = __ballot(push);
+    if (!ym) return;
+    const int lane = (int)threadIdx.x, leader = __ffsll((long long)ym) - 1;
+    int base = 0;
+    if (lane == leader) base = (int)atomicAdd(ycnt, (unsigned)__popcll(ym));
+    base = __shfl(base, leader);
+    if (push) {
+        unsigned long long *dst = ylist + (size_t)(base + __popcll(ym & ((1ull << lane) - 1ull))) * KLT_REC_STRIDE;
+        unsigned f[KLT_REC_WORDS];
+        __builtin_memcpy(f, &r, sizeof(f));
+        const unsigned long long tag = (unsigned long long)(unsigned)epoch << 32;
+#pragma unroll
+        for (int k = 0; k < KLT_REC_WORDS; ++k) (void)atomicExch(&dst[k], tag | f[k]);   // read-modify-write atomics meet at the device's coherence point
+    }
+}
+
+// reads the record at slot `idx`, waiting for every word of it to carry this call's epoch
+__device__ __forceinline__ klt_rec klt_read_rec(const unsigned long long *__restrict__ ylist, int idx, int epoch)
+{
+    const unsigned long long *src = ylist + (size_t)idx * KLT_REC_STRIDE;
+    unsigned f[KLT_REC_WORDS];
+#pragma unroll
+    for (int k = 0; k < KLT_REC_WORDS; ++k) {
+        unsigned long long v;
+        // a read-modify-write (OR with zero), not a load: a plain device-scope load is served by the issuing XCD's own L2, which
+        // keeps returning the line it fetched before the producer (on another XCD) wrote it -- measured: milliseconds of spinning
+        while ((unsigned)((v = atomicOr(const_cast<unsigned long long *>(&src[k]), 0ull)) >> 32) != (unsigned)epoch)
+            __builtin_amdgcn_s_sleep(1);   // its producer is a running wave of this launch: the word is on its way
+        f[k] = (unsigned)v;
+    }
+    klt_rec r;
+    __builtin_memcpy(&r, f, sizeof(f));
+    return r;
+}
+
+// A wave that has finished its own keypoints takes up to KPW published-or-reserved records off the list (one CAS per
+// wave); 0 = nothing there right now (records reserved later belong to the resume launch).  cnt[3] = records reserved,
+// cnt[4] = records taken.
+__device__ __forceinline__ int klt_take_yielded(unsigned *__restrict__ cnt, int kpw, int &first)
+{
+    int t = 0, nrec = 0;
+    if (threadIdx.x == 0) {
+        // ONE attempt: thousands of waves finish within microseconds of each other, and a retry loop on this one address
+        // turned into a compare-and-swap storm that held the launch for milliseconds (measured)
+        const unsigned taken = atomicOr(&cnt[4], 0u), avail = atomicOr(&cnt[3], 0u);
+        if (taken < avail) {
+            const unsigned want = min((unsigned)kpw, avail - taken);
+            if (atomicCAS(&cnt[4], taken, taken + want) == taken) { t = (int)taken; nrec = (int)want; }
+        }
+    }
+    first = __shfl(t, 0);
+    return __shfl(nrec, 0);
 }
 
 // Lanes per keypoint, chosen per call: 8 lanes (eight keypoints per wave) halve the wave-instructions per keypoint and
@@ -999,6 +1172,82 @@ __global__ __launch_bounds__(256) void klt_compact_kernel(int n, int pass, const
     if (lb) list_b[ob + rb] = f;
 }
 
+// what the first launch does with a finished keypoint (shared with the resume launch): result, status, work word, the
+// per-image tally of list A and the failures of list A appended to the re-tracking list
+__device__ __forceinline__ void klt_stage1_finish(bool mine, bool is_a, int i, int b, int n, int ok, float2 pr, unsigned work,
+                                                  float2 *__restrict__ out_xy, unsigned char *__restrict__ out_status,
+                                                  unsigned *__restrict__ counts, unsigned *__restrict__ iters,
+                                                  unsigned *__restrict__ cnt, int *__restrict__ list_c)
+{
+    if (mine) {
+        out_xy[i] = pr;   // tracked position, or the failed forward result that seeds the re-tracking (:217-219)
+        out_status[i] = (unsigned char)ok;
+        if (iters) iters[is_a ? i : n + i] = work;   // second half of the work-word array = full-pyramid passes
+        // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
+        // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
+        if (is_a) atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
+    }
+    // the failures of list A are what the second launch re-tracks: appended to its list here (one atomic per wave that
+    // has any; the order of the list does not matter, every keypoint is tracked on its own) -- a compaction launch less
+    // in the frame's chain
+    const bool retry = mine && is_a && !ok;
+    const unsigned long long rm = __ballot(retry);
+    if (rm) {
+        const int lane = (int)threadIdx.x, leader = __ffsll((long long)rm) - 1;
+        int base = 0;
+        if (lane == leader) base = (int)atomicAdd(&cnt[2], (unsigned)__popcll(rm));
+        base = __shfl(base, leader);
+        if (retry) list_c[base + __popcll(rm & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+// one wave continues the records [first, first + nrec) of the list: each its pass, the levels below it and the backward pass
+template <int WIN>
+__device__ __forceinline__ void klt_resume_wave(const ov2_pyr_view &pv, const ov2_pyr_view &cv, const klt_params &P, int n,
+                                                const float2 *__restrict__ kps, const int *__restrict__ img_idx,
+                                                float2 *__restrict__ out_xy, unsigned char *__restrict__ out_status,
+                                                unsigned *__restrict__ counts, unsigned *__restrict__ iters,
+                                                unsigned *__restrict__ cnt, int *__restrict__ list_c,
+                                                const unsigned long long *__restrict__ ylist, int first, int nrec, int epoch,
+                                                unsigned char *smem)
+{
+    using M = klt_map<3>;
+    const int slot = M::slot((int)threadIdx.x), sub = M::sub((int)threadIdx.x);
+    const bool lane_ok = M::lane_ok((int)threadIdx.x);
+    const bool act = slot < nrec && lane_ok;
+    const klt_rec rec = klt_read_rec(ylist, first + (slot < nrec ? slot : nrec - 1), epoch);
+    const int i = rec.i;
+    const bool is_a = (rec.info & 32) != 0;
+    const float2 kp = kps[i];
+    const int b = img_idx ? img_idx[i] : 0;
+    float2 pr = make_float2(rec.nx, rec.ny);
+    unsigned work = 0;
+    klt_rec dummy = {};
+    bool yielded = false;
+    // every level of the pyramid is walked (the groups of a wave resume at different ones); top_level beyond it: a level
+    // below a group's resume level always starts from twice the position of the level above
+    const int ok = fb_track3<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, pv.nlevels - 1, pv.nlevels, sub, lane_ok, work, smem, slot, 0, 0,
+                                  &rec, dummy, yielded);
+    klt_stage1_finish(act && sub == 0, is_a, i, b, n, ok, pr, work, out_xy, out_status, counts, iters, cnt, list_c);
+}
+
+// the stragglers the first launch left behind (klt_rec; most are taken by its own waves), 20 to a wave
+template <int WIN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WIN, 3)))) void klt_resume_kernel(ov2_pyr_view pv, ov2_pyr_view cv, klt_params P, int n,
+                                                        const float2 *__restrict__ kps, const int *__restrict__ img_idx,
+                                                        float2 *__restrict__ out_xy, unsigned char *__restrict__ out_status,
+                                                        unsigned *__restrict__ counts, unsigned *__restrict__ iters,
+                                                        unsigned *__restrict__ cnt, int *__restrict__ list_c,
+                                                        const unsigned long long *__restrict__ ylist, int epoch)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, 3>::BYTES];
+    constexpr int KLT_KPW = klt_map<3>::KPW;
+    const int first = (int)cnt[4] + (int)blockIdx.x * KLT_KPW, total = (int)cnt[3];   // what the first launch's waves did not take
+    if (first >= total) return;
+    klt_resume_wave<WIN>(pv, cv, P, n, kps, img_idx, out_xy, out_status, counts, iters, cnt, list_c, ylist, first,
+                         min(KLT_KPW, total - first), epoch, smem);
+}
+
 // first launch: list A = keypoints with a prior on 2 pyramid levels (nbpyrlvl = 1, src/visual_front_end.cpp:190),
 // list B = keypoints without prior on the full pyramid from their own position (:237-270, vpriors = vkps)
 template <int WIN, int KLT_GL>
@@ -1010,7 +1259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
                                                         unsigned *__restrict__ counts /* [batch][64] slots: low 16 bits n3d, high 16 good */,
                                                         unsigned *__restrict__ iters, const int *__restrict__ list_a,
                                                         const int *__restrict__ list_b, unsigned *__restrict__ cnt,
-                                                        int *__restrict__ list_c)
+                                                        int *__restrict__ list_c, unsigned long long *__restrict__ ylist, int epoch)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[klt_smem<WIN, KLT_GL>::BYTES];
     using M = klt_map<KLT_GL>;
@@ -1034,26 +1283,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KLT_WAVES(WI
     float2 pr = (is_a || !P.rule33) ? prior[i] : kp;
     unsigned work = 0;
     const int nl = is_a ? min(1, pv.nlevels - 1) : P.nlevels;
-    const int ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, lane_ok, work, smem, slot);
-    if (act && sub == 0) {
-        out_xy[i] = pr;   // tracked position, or the failed forward result that seeds the re-tracking (:217-219)
-        out_status[i] = (unsigned char)ok;
-        if (iters) iters[is_a ? i : n + i] = work;   // second half of the work-word array = full-pyramid passes
-        // one atomic per keypoint, spread over 64 slots per image: same-address atomics serialise at ~10-16 ns
-        // each (measured: they, not the tracking, bounded this kernel when every wave hit one counter)
-        if (is_a) atomicAdd(&counts[64 * b + (i & 63)], 1u + ((unsigned)ok << 16));
+    int ok;
+    bool yielded = false;
+    if constexpr (KLT_GL == 3) {
+        klt_rec rec = {};
+        ok = fb_track3<WIN>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, nl, sub, lane_ok, work, smem, slot, ylist ? P.y_after : 0,
+                            P.y_groups, nullptr, rec, yielded);
+        if (ylist) {   // wave-uniform
+            rec.i = i; rec.info |= is_a ? 32 : 0;
+            klt_push_yielded(act && sub == 0 && yielded, rec, ylist, &cnt[3], epoch);
+        }
+    } else {
+        ok = fb_track<WIN, KLT_GL>(pv, cv, b, act, kp.x, kp.y, pr.x, pr.y, P, nl, sub, lane_ok, work, smem, slot);
     }
-    // the failures of list A are what the second launch re-tracks: appended to its list here (one atomic per wave that
-    // has any; the order of the list does not matter, every keypoint is tracked on its own) -- a compaction launch less
-    // in the frame's chain
-    const bool retry = act && sub == 0 && is_a && !ok;
-    const unsigned long long rm = __ballot(retry);
-    if (rm) {
-        const int lane = (int)threadIdx.x, leader = __ffsll((long long)rm) - 1;
-        int base = 0;
-        if (lane == leader) base = (int)atomicAdd(&cnt[2], (unsigned)__popcll(rm));
-        base = __shfl(base, leader);
-        if (retry) list_c[base + __popcll(rm & ((1ull << lane) - 1ull))] = i;
+    klt_stage1_finish(act && sub == 0 && !yielded, is_a, i, b, n, ok, pr, work, out_xy, out_status, counts, iters, cnt, list_c);
+    if constexpr (KLT_GL == 3) {
+        // done with its own keypoints, the wave continues stragglers other waves have left -- ONE batch of at most 20: a wave
+        // that kept taking batches turned the launch's last few waves into the only workers of a long serial tail (measured:
+        // milliseconds); what is left when the launch ends goes to the resume launch, 20 to a wave across the whole device
+        if (ylist && P.y_pickup > 0 && ((int)blockIdx.x % P.y_pickup) == 0) {   // every y_pickup-th wave tries (the counters are one cache line)
+            int first;
+            const int nrec = klt_take_yielded(cnt, KLT_KPW, first);
+            if (nrec > 0) {
+                __syncthreads();   // the wave's LDS region is reused
+                klt_resume_wave<WIN>(pv, cv, P, n, kps, img_idx, out_xy, out_status, counts, iters, cnt, list_c, ylist, first, nrec, epoch, smem);
+            }
+        }
     }
 }
 
@@ -1165,6 +1420,8 @@ ov2_status make_params(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int 
     P->fb_th = (double)fb_th;
     P->min_eig_thr = 1e-4f;  // calcOpticalFlowPyrLK default minEigThreshold, not passed by the reference
     P->rule33 = 1;
+    P->y_after = c->klt_yield_after; P->y_groups = c->klt_yield_groups;
+    { static const int pk = [] { const char *e = getenv("OV2_KLT_PICKUP"); return e ? atoi(e) : 0; }(); P->y_pickup = pk; }
     return OV2_OK;
 }
 
@@ -1175,6 +1432,15 @@ extern "C" ov2_status ov2_klt_set_lanes(ov2_ctx *c, int lanes)
     if (!c) return OV2_ERR_INVALID;
     if (lanes != 0 && lanes != 3 && lanes != 8 && lanes != 16) return ov2_set_err(c, OV2_ERR_INVALID, "lanes per keypoint: 0 (auto), 3, 8 or 16");
     c->klt_lanes = lanes;
+    return OV2_OK;
+}
+
+extern "C" ov2_status ov2_klt_set_yield(ov2_ctx *c, int after, int groups)
+{
+    if (!c) return OV2_ERR_INVALID;
+    if (after < 0 || after > 100 || groups < 0 || groups > 20) return ov2_set_err(c, OV2_ERR_INVALID, "yield: 0 <= after <= 100, 0 <= groups <= 20");
+    c->klt_yield_after = groups > 0 ? after : 0;
+    c->klt_yield_groups = groups;
     return OV2_OK;
 }
 
@@ -1291,12 +1557,28 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
         for (int i = 0; i < 2; ++i) OV2_HIP(c, hipMemsetAsync(c->klt_counts[i], 0, c->klt_counts_words * sizeof(unsigned), c->stream));
     c->klt_counts_dirty = true;   // until this call's last kernel is enqueued
     void *scr = nullptr;
+    const bool use_yield = lanes == 3 && P.y_after > 0 && P.y_groups > 0;
+    const int epoch = ++c->klt_epoch;   // publishes this call's straggler records (the list's memory is reused from call to call)
     s = ov2_scratch(c, 3 * (size_t)n * sizeof(int) + 256, &scr);
     if (s != OV2_OK) return s;
     unsigned *counts = c->klt_counts[c->klt_counts_cur], *live_cnt = counts + (size_t)B * 64;
     unsigned *next_counts = c->klt_counts[c->klt_counts_cur ^ 1];
     const int next_words = (int)c->klt_counts_words;
     int *list_a = (int *)scr, *list_b = list_a + n, *list_c = list_b + n;
+    unsigned long long *ylist = nullptr;
+    if (use_yield) {   // the straggler records live in a buffer of the context that nothing else writes (see KLT_REC_WORDS)
+        const size_t need = (size_t)n * KLT_REC_STRIDE * sizeof(unsigned long long);
+        if (need > c->klt_ybuf_bytes) {
+            OV2_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->klt_ybuf) OV2_HIP(c, hipFree(c->klt_ybuf));
+            c->klt_ybuf = nullptr; c->klt_ybuf_bytes = 0;
+            const size_t want = need + need / 2;
+            OV2_HIP(c, hipMalloc(&c->klt_ybuf, want));
+            OV2_HIP(c, hipMemsetAsync(c->klt_ybuf, 0, want, c->stream));
+            c->klt_ybuf_bytes = want;
+        }
+        ylist = (unsigned long long *)c->klt_ybuf;
+    }
     const dim3 cgrid((n + 255) / 256);
 #define KLT_STAGES_GL(W, G)                                                                                     \
     do {                                                                                                        \
@@ -1306,7 +1588,13 @@ ov2_status ov2_klt_two_stage_dev(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr 
         OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_stage1_kernel<W, G>), dim3(tgrid.x + 1), dim3(64), 0, c->stream,   \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps),              \
                    reinterpret_cast<const float2 *>(d_prior), d_img_idx, reinterpret_cast<float2 *>(d_out_xy),  \
-                   d_out_status, counts, d_iters, list_a, list_b, live_cnt, list_c);                           \
+                   d_out_status, counts, d_iters, list_a, list_b, live_cnt, list_c, ylist, epoch);             \
+        if constexpr (G == 3) {                                                                                 \
+            if (use_yield)   /* the stragglers of the first launch, before the re-tracking launch reads its list and tallies */ \
+                OV2_LAUNCH(c, OV2_K_KLT_STAGE1, (klt_resume_kernel<W>), tgrid, dim3(64), 0, c->stream,          \
+                           prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_img_idx, \
+                           reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_iters, live_cnt, list_c, ylist, epoch); \
+        }                                                                                                       \
         OV2_LAUNCH(c, OV2_K_KLT_STAGE2, (klt_stage2_kernel<W, G>), tgrid, dim3(64), 0, c->stream,               \
                    prev->buf->view, cur->buf->view, P, n, reinterpret_cast<const float2 *>(d_kps), d_img_idx,   \
                    reinterpret_cast<float2 *>(d_out_xy), d_out_status, counts, d_p3p_req, d_iters, list_c,      \

@@ -378,3 +378,42 @@ def test_klt_three_lane_path_on_small_odd_images(ctx, oracle, w, h):
         assert st.mean() > 0.3
     finally:
         ctx.set_klt_lanes(0)
+
+
+@pytest.mark.parametrize("after,groups", [(0, 0), (1, 19), (1, 20), (2, 8), (6, 5), (30, 20)])
+def test_klt_yield_resume_is_bit_identical(ctx, oracle, stream, after, groups):
+    """ov2_klt_set_yield: the stragglers of a level pass leave their wave and a second launch continues each one's iteration
+    sequence (klt_rec in klt.hip).  Whatever the setting -- never, (1, 19/20) = nearly every keypoint yields at its second
+    iteration of EVERY pass incl. the backward one, (6, 5) -- positions, statuses and the 33 % flag equal the
+    oracle bit for bit: easy priors, priors 25 px off (33 % rule, failures re-queued), borders, and the stereo call."""
+    ctx.set_klt_yield(after, groups)
+    try:
+        trk = fe.FeatureTracker(ctx, 30, 0.01)
+        g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, 10)
+        kps = synth.grid_keypoints(6000, seed=after + 3)
+        gt = stream.flow(0, 10, kps)
+        for sigma, expect_p3p in ((1.0, False), (4.0, False), (25.0, True)):
+            pri, has = synth.make_priors(kps, gt, sigma=sigma, seed=groups)
+            out, st, p3p = trk.kltTracking(g0, g1, 9, 3, 30.0, 0.5, kps, pri, has)
+            eout, est, ep3p = oracle.klt_tracking_frame(o0, o1, kps, pri, has)
+            assert p3p == ep3p == expect_p3p
+            assert np.array_equal(st, est.astype(bool)), sigma
+            assert np.array_equal(out.view(np.uint32), eout.view(np.uint32)), sigma
+        # keypoints over every border, wild priors
+        rng = np.random.default_rng(7)
+        kb = np.stack([rng.uniform(-4, 756, 3000), rng.uniform(-4, 484, 3000)], 1).astype(np.float32)
+        pb = kb + rng.normal(0, 3.0, kb.shape).astype(np.float32)
+        hb = (rng.uniform(size=3000) < 0.6).astype(np.uint8)
+        out, st, p3p = trk.kltTracking(g0, g1, 9, 3, 30.0, 0.5, kb, pb, hb)
+        eout, est, ep3p = oracle.klt_tracking_frame(o0, o1, kb, pb, hb)
+        assert p3p == ep3p and np.array_equal(st, est.astype(bool)) and np.array_equal(out.view(np.uint32), eout.view(np.uint32))
+        # left -> right (no 33 % rule, failures re-queued with the updated prior)
+        gl, gr = fe.preprocess_image(ctx, stream.left(2)), fe.preprocess_image(ctx, stream.right(2))
+        ol, orr = oracle.Pyramid(oracle.clahe(stream.left(2))), oracle.Pyramid(oracle.clahe(stream.right(2)))
+        sg = stream.stereo_gt(kps).astype(np.float32)
+        spri, shas = synth.make_priors(kps, sg, sigma=3.0, seed=5)
+        rxy, rst = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, spri, shas, rectified=True)
+        exy, est2 = oracle.stereo_matching(ol, orr, kps, spri, shas, rectified=True)
+        assert np.array_equal(rst, est2) and np.array_equal(rxy.view(np.uint32), exy.view(np.uint32))
+    finally:
+        ctx.set_klt_yield(0, 0)
