@@ -143,10 +143,11 @@ ov2_status ov2_klt_set_lanes(ov2_ctx *ctx, int lanes);
 /* Tuning / test knob of the two-stage tracking calls with the three-lane mapping (ov2_klt_tracking_frame_dev, ov2_stereo_
  * matching*): a level pass that has made `after` LK iterations and is down to <= `groups` (of 20) running keypoints hands
  * those stragglers to a second, small launch that continues each one's iteration sequence from its stored state -- the
- * other keypoints of the wave no longer wait for them.  Per-keypoint arithmetic is unchanged: results are bit-identical
+ * other keypoints of the wave no longer wait for them; pickup = k > 0: every k-th wave of the first launch also takes one
+ * batch of stragglers itself when it has finished (0: none).  Per-keypoint arithmetic is unchanged: results are bit-identical
  * with any setting.  OFF by default = (0, 0): measured slower than letting the wave wait (numbers in csrc/klt.hip at klt_rec);
- * OV2_KLT_YIELD=after,groups in the environment switches it on for a process. */
-ov2_status ov2_klt_set_yield(ov2_ctx *ctx, int after, int groups);
+ * OV2_KLT_YIELD=after,groups (and OV2_KLT_PICKUP=k) in the environment switch it on for a process. */
+ov2_status ov2_klt_set_yield(ov2_ctx *ctx, int after, int groups, int pickup);
 
 /* ---- stereo matching (keyframe rate) -------------------------------------------------------------- */
 /* Replaces FeatureTracker::getLineMinSAD(iml, imr, pt, nwinsize, xprior, l1err, bgoleft) (include/feature_tracker.hpp:50,

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ov2_klt_tracking_frame_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                              C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ov2_klt_set_lanes": (C.c_int, [vp, C.c_int]),
-    "ov2_klt_set_yield": (C.c_int, [vp, C.c_int, C.c_int]),
+    "ov2_klt_set_yield": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "ov2_line_min_sad": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "ov2_line_min_sad_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "ov2_stereo_matching": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int,

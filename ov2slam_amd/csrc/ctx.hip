@@ -66,10 +66,12 @@ extern "C" ov2_status ov2_ctx_create_ex(int device, int high_priority, ov2_ctx *
     c->stage_ev = nullptr;
     {   // the tracking kernels' yield / resume (OV2_KLT_YIELD=after,groups switches it on; default 0,0 = off)
         c->klt_epoch = 0; c->klt_ybuf = nullptr; c->klt_ybuf_bytes = 0;
-        c->klt_yield_after = 0; c->klt_yield_groups = 0;   // off: every variant measured slower than waiting for the stragglers (klt.hip, klt_rec)
+        c->klt_yield_after = 0; c->klt_yield_groups = 0; c->klt_yield_pickup = 0;   // off: every variant measured slower than waiting for the stragglers (klt.hip, klt_rec)
         const char *e = getenv("OV2_KLT_YIELD");
         int a = 0, g = 0;
         if (e && sscanf(e, "%d,%d", &a, &g) == 2 && a >= 0 && a <= 100 && g >= 0 && g <= 20) { c->klt_yield_after = g > 0 ? a : 0; c->klt_yield_groups = g; }
+        const char *pk = getenv("OV2_KLT_PICKUP");
+        if (pk && atoi(pk) >= 0) c->klt_yield_pickup = atoi(pk);
     }
     c->stage_ev_pending = false;
     int prio_least = 0, prio_greatest = 0;

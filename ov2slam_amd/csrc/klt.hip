@@ -1420,8 +1420,7 @@ ov2_status make_params(ov2_ctx *c, const ov2_pyr *prev, const ov2_pyr *cur, int 
     P->fb_th = (double)fb_th;
     P->min_eig_thr = 1e-4f;  // calcOpticalFlowPyrLK default minEigThreshold, not passed by the reference
     P->rule33 = 1;
-    P->y_after = c->klt_yield_after; P->y_groups = c->klt_yield_groups;
-    { static const int pk = [] { const char *e = getenv("OV2_KLT_PICKUP"); return e ? atoi(e) : 0; }(); P->y_pickup = pk; }
+    P->y_after = c->klt_yield_after; P->y_groups = c->klt_yield_groups; P->y_pickup = c->klt_yield_pickup;
     return OV2_OK;
 }
 
@@ -1435,12 +1434,14 @@ extern "C" ov2_status ov2_klt_set_lanes(ov2_ctx *c, int lanes)
     return OV2_OK;
 }
 
-extern "C" ov2_status ov2_klt_set_yield(ov2_ctx *c, int after, int groups)
+extern "C" ov2_status ov2_klt_set_yield(ov2_ctx *c, int after, int groups, int pickup)
 {
     if (!c) return OV2_ERR_INVALID;
-    if (after < 0 || after > 100 || groups < 0 || groups > 20) return ov2_set_err(c, OV2_ERR_INVALID, "yield: 0 <= after <= 100, 0 <= groups <= 20");
+    if (after < 0 || after > 100 || groups < 0 || groups > 20 || pickup < 0)
+        return ov2_set_err(c, OV2_ERR_INVALID, "yield: 0 <= after <= 100, 0 <= groups <= 20, pickup >= 0");
     c->klt_yield_after = groups > 0 ? after : 0;
     c->klt_yield_groups = groups;
+    c->klt_yield_pickup = pickup;
     return OV2_OK;
 }
 

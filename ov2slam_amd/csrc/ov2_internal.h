@@ -97,7 +97,7 @@ struct ov2_ctx {
     hipEvent_t ba_copy_ev[2];            // [0] head uploaded (main stream), [1] measurements uploaded (copy stream)
     void *klt_ybuf; size_t klt_ybuf_bytes;   // straggler records of the tracking kernels (written only by them)
     int klt_epoch;                       // serial number of the two-stage tracking calls (publication word of the straggler records)
-    int klt_yield_after, klt_yield_groups;   // ov2_klt_set_yield (three-lane tracking kernels: klt_rec in klt.hip)
+    int klt_yield_after, klt_yield_groups, klt_yield_pickup;   // ov2_klt_set_yield (three-lane tracking kernels: klt_rec in klt.hip)
     int klt_lanes;                       // ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = forced lanes per keypoint
     // optional per-kernel hipEvent timing (bench.py roofline leg); off by default
     bool ktime_on;

@@ -44,9 +44,9 @@ class Context:
         """ov2_klt_set_lanes: 0 = by call size, 3 / 8 / 16 = lanes per keypoint in the tracking kernels"""
         _check(self.h, self.lib.ov2_klt_set_lanes(self.h, int(lanes)))
 
-    def set_klt_yield(self, after, groups):
+    def set_klt_yield(self, after, groups, pickup=0):
         """ov2_klt_set_yield: stragglers of a level pass leave their wave after `after` iterations once <= `groups` run"""
-        _check(self.h, self.lib.ov2_klt_set_yield(self.h, int(after), int(groups)))
+        _check(self.h, self.lib.ov2_klt_set_yield(self.h, int(after), int(groups), int(pickup)))
 
     def synchronize(self):
         _check(self.h, self.lib.ov2_ctx_synchronize(self.h))

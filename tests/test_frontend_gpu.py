@@ -380,13 +380,13 @@ def test_klt_three_lane_path_on_small_odd_images(ctx, oracle, w, h):
         ctx.set_klt_lanes(0)
 
 
-@pytest.mark.parametrize("after,groups", [(0, 0), (1, 19), (1, 20), (2, 8), (6, 5), (30, 20)])
-def test_klt_yield_resume_is_bit_identical(ctx, oracle, stream, after, groups):
+@pytest.mark.parametrize("after,groups,pickup", [(0, 0, 0), (1, 19, 0), (1, 20, 1), (2, 8, 3), (6, 5, 8), (30, 20, 1)])
+def test_klt_yield_resume_is_bit_identical(ctx, oracle, stream, after, groups, pickup):
     """ov2_klt_set_yield: the stragglers of a level pass leave their wave and a second launch continues each one's iteration
     sequence (klt_rec in klt.hip).  Whatever the setting -- never, (1, 19/20) = nearly every keypoint yields at its second
     iteration of EVERY pass incl. the backward one, (6, 5) -- positions, statuses and the 33 % flag equal the
-    oracle bit for bit: easy priors, priors 25 px off (33 % rule, failures re-queued), borders, and the stereo call."""
-    ctx.set_klt_yield(after, groups)
+    oracle bit for bit, with and without waves of the first launch taking stragglers themselves (pickup): easy priors, priors 25 px off (33 % rule, failures re-queued), borders, and the stereo call."""
+    ctx.set_klt_yield(after, groups, pickup)
     try:
         trk = fe.FeatureTracker(ctx, 30, 0.01)
         g0, g1, o0, o1 = _pyrs(ctx, oracle, stream, 0, 10)
