@@ -200,9 +200,23 @@ struct row_eval {
     bool depth_pos;
 };
 
+// R | t of a pose: from the workgroup's LDS table of its window's poses (EV_RT_STRIDE doubles per pose, filled by
+// pose_Rt) when there is one, else converted from the quaternion pose in global memory -- the same values either way
+#define EV_RT_STRIDE 13
+#define EV_RT_MAX 128
+__device__ __forceinline__ void fetch_Rt(const double *__restrict__ poses, const double *sRt, int p0, int gp, double R[9], double t[3])
+{
+    if (sRt) {
+        const double *q = sRt + (gp - p0) * EV_RT_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = q[i];
+        t[0] = q[9]; t[1] = q[10]; t[2] = q[11];
+    } else pose_Rt(poses + 7 * (size_t)gp, R, t);
+}
+
 template <bool JAC>
 __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const double *__restrict__ poses,
-                                const double *__restrict__ lms, int row, row_eval &o)
+                                const double *__restrict__ lms, int row, row_eval &o, const double *sRt = nullptr, int p0 = 0)
 {
     const int type = d.type[row], l = d.lm[row];
     const double inv_sigma = d.inv_sigma[row];
@@ -217,7 +231,7 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
         anchpt[2] = zanch;
         if (type != OV2_BA_RANCH_INV) {
             double twa[3];
-            pose_Rt(poses + 7 * d.anch[row], Rwa, twa);
+            fetch_Rt(poses, sRt, p0, d.anch[row], Rwa, twa);
             for (int r = 0; r < 3; ++r)
                 wpt[r] = (Rwa[3 * r] * anchpt[0] + Rwa[3 * r + 1] * anchpt[1] + Rwa[3 * r + 2] * anchpt[2]) + twa[r];
         }
@@ -231,7 +245,7 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
         for (int i = 0; i < 9; ++i) M[i] = wc.Rrl[i];
     } else {
         double Rwc[9], twc[3], lcam[3];
-        pose_Rt(poses + 7 * d.pose[row], Rwc, twc);
+        fetch_Rt(poses, sRt, p0, d.pose[row], Rwc, twc);
         const double dd[3] = {wpt[0] - twc[0], wpt[1] - twc[1], wpt[2] - twc[2]};
         for (int r = 0; r < 3; ++r) lcam[r] = Rwc[r] * dd[0] + Rwc[3 + r] * dd[1] + Rwc[6 + r] * dd[2];
         if (is_right) {
@@ -340,16 +354,32 @@ __device__ __forceinline__ bool win_runs(const ba_win &W, int mode)
 template <bool JAC, int E>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void ba_eval_kernel(ba_dev d, const double *__restrict__ poses,
                                                       const double *__restrict__ lms, int mode, double huber_a,
-                                                      double *__restrict__ part)
+                                                      double *__restrict__ part, const int *__restrict__ pose_off)
 {
     BA_WAVE_PRIO();
     __shared__ double sh[256];
+    __shared__ double sRt_buf[EV_RT_MAX * EV_RT_STRIDE];
     __shared__ int sw;
     if (threadIdx.x == 0) sw = win_of_vblock(d.vb_start, d.B, blockIdx.x);
     __syncthreads();
     const int w = sw;
     const ba_win &W = d.W[w];
     if (!win_runs(W, mode)) return;   // workgroup-uniform
+    // the window's poses as R | t, converted once per workgroup instead of twice per row (a row's pose and its landmark's
+    // anchor pose: two dependent 56-byte gathers and two quaternion normalisations per lane)
+    const int p0 = pose_off[w], np = pose_off[w + 1] - p0;
+    const double *sRt = (np <= EV_RT_MAX) ? sRt_buf : nullptr;
+    if (sRt) {
+        if ((int)threadIdx.x < np) {
+            double R[9], t[3];
+            pose_Rt(poses + 7 * (size_t)(p0 + (int)threadIdx.x), R, t);
+            double *q = sRt_buf + threadIdx.x * EV_RT_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) q[i] = R[i];
+            q[9] = t[0]; q[10] = t[1]; q[11] = t[2];
+        }
+        __syncthreads();
+    }
     const int row = W.row0 + ((int)blockIdx.x - W.vb0) * 256 + (int)threadIdx.x;
     const int use_loss = W.use_loss;
     double c = 0.0;
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         }
     } else if (row < W.row1) {
         row_eval ev;
-        eval_row<JAC>(d, d.wc[w], poses, lms, row, ev);
+        eval_row<JAC>(d, d.wc[w], poses, lms, row, ev, sRt, p0);
         double rho[3] = {ev.chi2, 1.0, 0.0};
         if (use_loss) huber(huber_a, ev.chi2, rho);
         c = 0.5 * rho[0];
@@ -1088,6 +1118,221 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(ba_dev d)
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K_CHOL, one workgroup per window with the panel update on the matrix cores.  Same left-looking blocked factorisation
+// as ba_chol_kernel (32-column panel in LDS, right-hand side as row m, diagonal block by one wave, rows below by
+// forward substitution, blocked backward substitution) -- what changes is the O(m^3) part: the update of a panel with
+// the columns before it, P -= L[j0.., 0..j0) L[j0..j0+32, 0..j0)^T, is a GEMM, and ba_chol_kernel spent it one LDS read
+// per fused multiply-add (every thread a row, 16 columns each).  Here every wave takes 16-row tiles of the panel (both
+// 16-column halves at once, sharing the row operand) and walks k in steps of four with v_mfma_f64_16x16x4_f64, both
+// operands straight from the factor in L2 (for a fixed k, 16 consecutive rows are 128 contiguous bytes): no LDS traffic
+// and no barrier inside the update.
+typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
+// 1 / d by v_rcp_f64 + two Newton steps (within an ulp of the correctly rounded quotient): an IEEE f64 division is a ~35
+// instruction sequence here, and the substitution loops of the factorisation made one per row and column
+__device__ __forceinline__ double chol_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+    x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+    return x;
+}
+
+#ifdef OV2_CHOL_PROF
+__device__ unsigned long long g_chol_prof[8];   // phase clocks (100 MHz ticks) of workgroup 0: update, diagonal, substitution, write-back, backward
+#define CHOL_TICK(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_chol_prof[slot] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define CHOL_TICK(slot) do { } while (0)
+#endif
+
+// sqrt(d) and 1 / sqrt(d) for a pivot (d > 0, far from the ends of the exponent range: a sum of squared jacobian entries plus
+// the LM diagonal): v_rsq_f64 + two Newton steps for the reciprocal root, the root as d * that with one correction.  The
+// pivot sits on the critical path of the one-wave diagonal block: sqrt() followed by a reciprocal was ~60 dependent
+// instructions per column, this is 14.
+__device__ __forceinline__ void chol_sqrt_rcp(double d, double &root, double &inv)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    y = __builtin_fma(y, __builtin_fma(-hd * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-hd * y, y, 0.5), y);
+    double r = d * y;
+    r = __builtin_fma(__builtin_fma(-r, r, d), 0.5 * y, r);
+    root = r;
+    inv = __builtin_fma(__builtin_fma(-r, y, 1.0), y, y);   // 1 / root (y is 1 / sqrt(d); one step onto the rounded root)
+}
+
+__global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
+{
+    BA_WAVE_PRIO();
+#ifdef OV2_CHOL_PROF
+    unsigned long long t_prev = wall_clock64();
+#endif
+    constexpr int NB = 32, PS = NB + 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ba_win &W = d.W[blockIdx.x];
+    if (!W.active || W.m == 0) return;
+    double *__restrict__ A = d.Spool + W.S_off;
+    double *__restrict__ rhs = d.rhs + (size_t)W.f0 * 6;
+    const int m = W.m;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+    const int M1 = m + 1;
+    double *P = lds;                                   // panel: rows x NB, stride PS
+    double *invd = lds + (((size_t)M1 * PS + 1) & ~(size_t)1);   // reciprocals of the panel's diagonal (NB)
+    volatile int *failp = reinterpret_cast<volatile int *>(invd + NB);
+    if (tid == 0) *failp = 0;
+    __syncthreads();
+    const int li = lane & 15, kq = lane >> 4;
+    for (int j0 = 0; j0 < m; j0 += NB) {
+        const int nb = min(NB, m - j0);
+        const int rows = M1 - j0;                      // panel rows j0 .. m (row m = right-hand side)
+        const int ntile = (rows + 15) >> 4;
+        // the two 16-column blocks of the panel as the MFMA's first operand: lane (li, kq) holds L[j0 + 16 h + li][k + kq]
+        const int ca = j0 + li, cb = j0 + 16 + li;
+        const bool ca_ok = li < nb, cb_ok = 16 + li < nb;
+        for (int t = wave; t < ntile; t += nwaves) {
+            const int r0 = j0 + 16 * t, rr = r0 + li;  // this lane's row of the tile (rr == m: the right-hand side row)
+            const double *rsrc = rr < m ? A + rr : rhs;
+            const size_t rstep = rr < m ? (size_t)m : 1;
+            const bool r_ok = rr <= m;
+            ov2_v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            // j0 is a multiple of 32: eight k-steps per trip, their 24 operand loads issued together (one L2 round trip per
+            // trip; issued step by step every matrix instruction waited for its own loads -- 53 us per panel at m = 354)
+            // (double-buffering the trips wants 48 operands + their 48 addresses live: 256 VGPRs and 636 bytes of scratch)
+            double bA[8], a0A[8], a1A[8];
+#define CHOL_FETCH(K, BB, A0, A1)                                                  \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                        \
+                const size_t kk = (size_t)((K) + 4 * u + kq);                      \
+                const double *col = A + kk * m;                                    \
+                BB[u] = r_ok ? rsrc[kk * rstep] : 0.0;                             \
+                A0[u] = ca_ok ? col[ca] : 0.0;                                     \
+                A1[u] = cb_ok ? col[cb] : 0.0;                                     \
+            }
+#define CHOL_MAC(BB, A0, A1)                                                       \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                        \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[u], BB[u], acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[u], BB[u], acc1, 0, 0, 0); \
+            }
+            for (int k = 0; k < j0; k += 32) {
+                CHOL_FETCH(k, bA, a0A, a1A)
+                CHOL_MAC(bA, a0A, a1A)
+            }
+#undef CHOL_FETCH
+#undef CHOL_MAC
+            // acc_h[q] = sum_k L[j0 + 16 h + kq + 4 q][k] L[rr][k]: the update of P[rr][16 h + kq + 4 q]
+            if (r_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = kq + 4 * q, c1 = 16 + kq + 4 * q;
+                    if (c0 < nb) P[(rr - j0) * PS + c0] = (rr < m ? A[(size_t)(j0 + c0) * m + rr] : rhs[j0 + c0]) - acc0[q];
+                    if (c1 < nb) P[(rr - j0) * PS + c1] = (rr < m ? A[(size_t)(j0 + c1) * m + rr] : rhs[j0 + c1]) - acc1[q];
+                }
+            }
+        }
+        __syncthreads();
+        CHOL_TICK(0);
+        // (a) the nb x nb diagonal block: ONE wave, lane i keeps row i in registers, pivots travel by v_readlane
+        if (tid < 64) {
+            double row[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) row[c] = (tid < nb && c < nb) ? P[tid * PS + c] : ((tid == c) ? 1.0 : 0.0);
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const double dcc = readlane_f64(row[c], c);
+                if (c < nb && !(dcc > 0.0)) bad = 1;
+                double dsq, inv;
+                chol_sqrt_rcp(dcc > 0.0 ? dcc : 1.0, dsq, inv);
+                if (tid == c) invd[c] = inv;
+                row[c] = (tid == c) ? dsq : row[c] * inv;
+#pragma unroll
+                for (int c2 = c + 1; c2 < NB; ++c2) {
+                    const double l = readlane_f64(row[c], c2);
+                    row[c2] = __builtin_fma(-row[c], l, row[c2]);      // rows above the diagonal collect garbage that is never read
+                }
+            }
+            if (tid < nb) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c <= tid && c < nb) P[tid * PS + c] = row[c];
+            }
+            if (bad && tid == 0) *failp = 1;
+        }
+        __syncthreads();
+        CHOL_TICK(1);
+        if (*failp) break;
+        // (b) rows below the block (and the rhs row): x L_D^T = P[i,:], forward substitution, one thread per row
+        for (int i = nb + tid; i < rows; i += nth) {
+            double x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? P[i * PS + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c < nb) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], P[c * PS + k], v);
+                    x[c] = v * invd[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) P[i * PS + c] = x[c];
+        }
+        __syncthreads();
+        CHOL_TICK(2);
+        for (int c = wave; c < nb; c += nwaves) {   // a column per wave: consecutive lanes, consecutive rows
+            double *__restrict__ colA = A + (size_t)(j0 + c) * m + j0;
+            for (int i = c + lane; i < rows; i += 64) {
+                if (j0 + i < m) colA[i] = P[i * PS + c];
+                else rhs[j0 + c] = P[i * PS + c];   // y = L^-1 b rides along as row m
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        CHOL_TICK(3);
+    }
+    if (*failp) {
+        if (tid == 0) W.chol_fail = 1;
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // backward substitution L^T z = y, as in ba_chol_kernel
+    {
+        double *zb = lds, *tpart = lds + m;
+        for (int i = tid; i < m; i += nth) zb[i] = rhs[i];
+        __syncthreads();
+        for (int j0 = ((m - 1) / NB) * NB; j0 >= 0; j0 -= NB) {
+            const int nb = min(NB, m - j0);
+            for (int c = wave; c < nb; c += nwaves) {
+                double sacc = 0.0;
+                for (int i = j0 + nb + lane; i < m; i += 64) sacc += A[(size_t)(j0 + c) * m + i] * zb[i];
+                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+                if (lane == 0) tpart[c] = sacc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                double y = (lane < nb) ? zb[j0 + lane] - tpart[lane] : 0.0;
+                double colD[NB];   // lane i: colD[j] = L[j0+j][j0+i], j >= i
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    colD[j] = (lane < nb && j < nb && j >= lane) ? A[(size_t)(j0 + lane) * m + j0 + j] : ((j == lane) ? 1.0 : 0.0);
+                const double dinv = chol_rcp(lane < nb ? A[(size_t)(j0 + lane) * m + j0 + lane] : 1.0);   // lane j: 1 / L[j0+j][j0+j]
+#pragma unroll
+                for (int j = NB - 1; j >= 0; --j) {
+                    const double zj = readlane_f64(y, j) * readlane_f64(dinv, j);
+                    if (lane == j) y = zj;
+                    else if (lane < j) y -= colD[j] * zj;
+                }
+                if (lane < nb) zb[j0 + lane] = y;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < m; i += nth) rhs[i] = zb[i];
+    }
+    CHOL_TICK(4);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K_CHOL, multi-workgroup form for m >= CHOL_MULTI_MIN: right-looking blocked Cholesky, two launches per 32-column
 // panel.  (A) every workgroup (one wave) factors the 32 x 32 diagonal block redundantly in registers -- 3 us, cheaper
 // than a third launch -- and solves x L_D^T = a for 64 rows below it (the right-hand side rides along as row m);
@@ -1096,11 +1341,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_kernel(ba_dev d)
 // v_mfma_f64_16x16x4_f64 per tile (operands straight from L2: lanes of one k read 16 consecutive doubles), plus the
 // rhs row.  Then one workgroup does the blocked backward substitution.  m = 480: 1.52 -> ~0.6 ms per factorisation
 // + solve against the one-workgroup kernel above; no upper limit on m any more.
-typedef double ov2_v4f64 __attribute__((ext_vector_type(4)));
 #define CHOL_NB 32
-#define CHOL_MULTI_MIN 320   // measured (3-iteration minimize): m = 480: 9.9 -> 5.9 ms against the one-workgroup kernel.  At
+#define CHOL_MULTI_MIN 400   // measured (3-iteration minimize): m = 480: 9.9 -> 5.9 ms against the one-workgroup kernel.  At
                              // m = 250 the 16 launches win 6 % on an idle GPU (3.28 -> 3.08 ms) but lose 9 % beside a busy
-                             // front-end (332 vs 363 LM iterations/s: every dispatch queues), so the single launch stays there
+                             // front-end (332 vs 363 LM iterations/s: every dispatch queues), so the single launch stays there.
+                             // Round 3, batches of 64 distinct windows with the one-workgroup kernel's panel update on the
+                             // matrix cores (ba_chol_mfma_kernel): m <= 354: 24.4 ms per batch against 25.5 (this path) and 26.2
+                             // (ba_chol_kernel); m ~ 440 (75 keyframes): 17.1 against 16.0 -- the crossover sits near 400
 
 __global__ __launch_bounds__(64) void ba_chol_panel_kernel(ba_dev d, double *__restrict__ Dpool, size_t dstride, int k0)
 {
@@ -1702,7 +1949,7 @@ struct ba_cells {
     // symmetric in V: S[hi, lo] -= V_hi V_lo', rhs -= V h -- one 64-byte (E = 1) / 176-byte (E = 3) record per cell
     // instead of W, W (E'E + D)^-1 and W (E'E + D)^-1 E'b (144 / 336 bytes), and both sides of a pair read the same array.
     double *V;
-    const int2 *qrow;         // pose-major position of an observing cell -> (first row, rows) of its run in the sorted rows
+    const int4 *qrow;         // pose-major position of an observing cell -> (first row, rows) of its run in the sorted rows, landmark block
 };
 
 __global__ __launch_bounds__(256) void bs_count_kernel(ba_dev d, int *__restrict__ ncell, int *__restrict__ npair)
@@ -1793,7 +2040,7 @@ __global__ __launch_bounds__(256) void bs_rank_kernel(const int *__restrict__ pc
 // observing cell -> its run of rows, stored at the cell's pose-major position (what the gather walks to form F'Fa)
 __global__ __launch_bounds__(256) void bs_qrow_kernel(ba_dev d, const int *__restrict__ cell_f, const int *__restrict__ cell_row,
                                                       const int *__restrict__ cell_lm, const int *__restrict__ cell_rank, int n,
-                                                      int2 *__restrict__ qrow)
+                                                      int4 *__restrict__ qrow)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
@@ -1803,7 +2050,7 @@ __global__ __launch_bounds__(256) void bs_qrow_kernel(ba_dev d, const int *__res
         const int r1 = d.row_ptr[cell_lm[c] + 1], fk = cell_f[c];
         while (r0 + cnt < r1 && d.fk[r0 + cnt] == fk) ++cnt;
     }
-    qrow[cell_rank[c]] = make_int2(r0, cnt);
+    qrow[cell_rank[c]] = make_int4(r0, cnt, cell_lm[c], 0);
 }
 
 // pair entries: cell ids -> pose-major positions, bit 31 = "this cell is the landmark's anchor cell"
@@ -2015,6 +2262,11 @@ __device__ __forceinline__ void bs_diag_block(const ba_dev &d, const ba_cells &C
 // plus F'Fa when one of the two cells is the landmark's anchor cell.  Lanes stride over the pair's entries; an entry
 // names the two cells by their pose-major positions, which grow with the landmark inside both poses' runs, so
 // consecutive entries read nearly consecutive records.
+// (Measured alternative, round 3: lane = 16 g + s with g = one 3 x 3 quarter of the block and s = one of 16 entry slots -- nine
+// accumulators and 116 VGPRs instead of 36 and 170, nine DPP row sums instead of 36 cross-wave totals.  705 us per launch
+// against 549 for this form on 64 distinct 50-keyframe windows, 732 / 888 us with two / four entries per lane in flight:
+// every entry is then fetched by four lanes, and the kernel is bound by the number of scattered (lane, load) addresses the
+// texture path resolves, not by VALU work, registers or latency.)
 template <int E>
 __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C, int n_pairs,
                                               const u64 *__restrict__ pair_key, const int *__restrict__ seg_start,
@@ -2062,8 +2314,8 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
             // Formed here from the one or two 48-byte rows of the run, lane-parallel like the rest of the entry (nothing
             // materialised per cell: the 288-byte F'Fa records were the largest store of the whole Schur complement).
             if (!(dbg & 4) && (eh < 0 || el < 0)) {
-                const int2 rr = C.qrow[el < 0 ? qh : ql];
-                const double *wp = d.wpt + (size_t)d.eb[rr.x] * 3;   // the rows of a cell belong to one landmark
+                const int4 rr = C.qrow[el < 0 ? qh : ql];
+                const double *wp = d.wpt + (size_t)rr.z * 3;   // the rows of a cell belong to one landmark
                 for (int k = 0; k < rr.y; ++k) {
                     double Uu[12], H[12], L[12];
                     load_U(d, (size_t)(rr.x + k), wp, Uu);
@@ -2529,7 +2781,7 @@ ov2_status build_program(ba_solver &S)
         OV2_HIP(c, hipcub::DeviceScan::ExclusiveSum(nullptr, t4, (int *)nullptr, (int *)nullptr, P_tot + 1, st));
         size_t tbytes = std::max(std::max(t1, t2), t4);
         {   // the structure lives in its own block, sized now that the counts are known and kept across solves
-            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + 8 + (size_t)(e == 1 ? cell_rec<1>::STRIDE : cell_rec<3>::STRIDE) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
+            const size_t need2 = (size_t)C_tot * (6 * 4 + 2 * 8 + 16 + (size_t)(e == 1 ? cell_rec<1>::STRIDE : cell_rec<3>::STRIDE) * 8) + (size_t)P_tot * (2 * 8 + 6 * 4) +
                                  (size_t)pair_cap * 12 + (size_t)d.n_f * 4 + tbytes + 64 * 256;
             if (need2 > c->ba_arena2_cap) {
                 OV2_HIP(c, hipStreamSynchronize(st));
@@ -2544,7 +2796,7 @@ ov2_status build_program(ba_solver &S)
         size_t off2 = 0;
         AL3(cell_f, C_tot); AL3(cell_row, C_tot); AL3(cell_lm, C_tot); AL3(cell_rank, C_tot);
         AL3(Cc.V, (size_t)C_tot * (e == 1 ? cell_rec<1>::STRIDE : cell_rec<3>::STRIDE));
-        int2 *qrow;
+        int4 *qrow;
         AL3(qrow, C_tot);
         AL3(pcell_ptr, d.n_f + 1); AL3(pcell_ent, C_tot); AL3(ckey, C_tot); AL3(ckey2, C_tot);
         AL3(pkey, P_tot); AL3(pkey2, P_tot); AL3(pent, 2 * (size_t)P_tot); AL3(pent_sorted, P_tot); AL3(head, P_tot + 1); AL3(rank, P_tot + 1);
@@ -2630,11 +2882,11 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     auto eval = [&](bool jac, const double *xp, const double *xl, int mode) {
         double *pc = d.part + 3 * (size_t)(d.n_e + d.n_f);
         if (jac) {
-            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
-            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc, S.raw.pose_off);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<true, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc, S.raw.pose_off);
         } else {
-            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
-            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc);
+            if (e == 1) BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 1>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc, S.raw.pose_off);
+            else BA_LAUNCH(S, K_EVAL, (ba_eval_kernel<false, 3>), g_rows, dim3(256), 0, st, d, xp, xl, mode, o->huber_delta, pc, S.raw.pose_off);
         }
     };
     auto colnorm = [&](int mode) {
@@ -2690,6 +2942,11 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
                 }
                 BA_LAUNCH(S, K_CHOL, ba_chol_backward_kernel, dim3(B), dim3(256), (size_t)(m + CHOL_NB + 2) * 8, st, d, S.chold, S.chold_stride);
             } else {
+                static const int chol_mfma = getenv("OV2_CHOL_MFMA") ? atoi(getenv("OV2_CHOL_MFMA")) : 1;
+                const size_t ldsm = ((size_t)(m + 1) * 33 + 32 + 8) * 8;
+                if (chol_mfma && ldsm <= 158 * 1024) {
+                    BA_LAUNCH(S, K_CHOL, ba_chol_mfma_kernel, g_win, dim3(CHOL_THREADS), ldsm, st, d);
+                } else {
                 // one workgroup per window; panel width by LDS budget: (m+1) x (NB+1) + NB x 64 doubles <= 158 KiB
                 const size_t lds32 = ((size_t)(m + 1) * 33 + 32 * 64 + 4) * 8, lds16 = ((size_t)(m + 1) * 17 + 16 * 64 + 4) * 8,
                              lds8 = ((size_t)(m + 1) * 9 + 8 * 64 + 4) * 8;
@@ -2697,6 +2954,7 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
                 else if (lds16 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<16>, g_win, dim3(CHOL_THREADS), lds16, st, d);
                 else if (lds8 <= 158 * 1024) BA_LAUNCH(S, K_CHOL, ba_chol_kernel<8>, g_win, dim3(CHOL_THREADS), lds8, st, d);
                 else return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "reduced camera system of %d unknowns exceeds the one-workgroup Cholesky", m);
+                }
             }
         }
         {
@@ -2756,6 +3014,16 @@ ov2_status fetch_windows(ba_solver &S)
 }
 
 }  // namespace
+
+#ifdef OV2_CHOL_PROF
+extern "C" int ov2_debug_chol_prof(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_prof), sizeof(z)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_chol_prof), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 
 extern "C" void ov2_ba_default_options(ov2_ba_options *o, float robust_mono_th)
 {

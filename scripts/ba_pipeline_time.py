@@ -24,8 +24,12 @@ def main():
         m.save_state()
     o = local_ba.default_options()
     best = None
+    prof = getattr(ctx.lib, "ov2_debug_chol_prof", None) if os.environ.get("OV2_CHOL_PROF") else None   # -DOV2_CHOL_PROF builds only
     for rep in range(reps):
         ctx.synchronize()
+        if prof is not None:
+            buf = (C.c_ulonglong * 8)()
+            prof(buf, 1)
         t0 = time.perf_counter()
         DM.restore_state_batch(ctx, maps)
         views = DM.setup_batch(ctx, maps, calib_l=wins[0].calib_l)
@@ -38,6 +42,10 @@ def main():
         ctx.synchronize()
         t3 = time.perf_counter()
         cur = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
+        if prof is not None:
+            prof(buf, 0)
+            print("   Cholesky phases of window 0 (us): update %.0f, diagonal %.0f, substitution %.0f, write-back %.0f, backward %.0f"
+                  % tuple(v / 100.0 for v in list(buf)[:5]), flush=True)
         if rep and (best is None or cur[0] < best[0]):
             best = cur
     n1 = [r.n_log_robust - 1 for r in rcs]
