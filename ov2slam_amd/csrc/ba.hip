@@ -832,6 +832,11 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
 // is the column norms) and F'b (the gradient).  No atomics (the per-pose sums were the most contended addresses of the
 // whole solve), fixed summation order => bitwise reproducible.  The Schur complement reuses F'F and F'b in every LM
 // round until the next accepted step instead of re-deriving them from the rows.
+// (Measured alternative, round 3: a pose-major copy of (G | residual), one 64-byte record per entry, written by the jacobian
+// evaluation and read contiguously here and by the F'Fa terms of the gather.  This kernel 265 -> 181 us, but the evaluation
+// 211 -> 320 us per launch (two scattered 64-byte stores per row, 1 GB per full evaluation of 8 M rows) and the gather 552 ->
+// 708 us: 27.9 ms per batch of 64 windows against 24.4.  The rows of a batch are 640 MB, far beyond L2 and MALL; every extra
+// copy is paid at HBM rate.)
 __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int *__restrict__ pose_ptr,
                                                              const int *__restrict__ pose_ent, int mode)
 {
