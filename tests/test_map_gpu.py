@@ -423,3 +423,42 @@ def test_batch_of_distinct_windows_setup_solve_update_and_restore(ctx):
     views = DM.setup_batch(ctx, maps, calib_l=synth_ba.K_L)
     rcs2 = _solve_on_device(ctx, maps, views, probs[0], True)
     assert [[(i.cost, i.radius, i.step_is_successful) for i in r.log[:r.n_log]] for r in rcs2] == logs
+
+
+def test_batch_with_aborted_and_empty_maps(ctx):
+    """edge cases of the batched keyframe job: a map that aborts (too few 3D keypoints in the new keyframe, src/optimizer.cpp:61-63)
+    and an EMPTY map (no keyframe, no observation) ride in the same batch as two real windows -- their windows reach the
+    solver with no blocks, the update leaves their tables untouched, and the real windows come out exactly as they do in a
+    batch of their own; B = 0 is a no-op; a map twice in a batch / an update without a set-up are refused"""
+    shapes = [(10, 500), (3, 20), (14, 900)]
+    probs = [synth_ba.make_window(k, l, inv_depth=True, seed=11 * k + l, outlier_frac=0.05) for k, l in shapes]
+    maps = [DM.DeviceMap.from_problem(ctx, P, isobs="newest") for P in probs]
+    empty = DM.DeviceMap(ctx, 4, 4, 4)
+    empty.newkf = 0
+    maps.insert(2, empty)
+    alone = [DM.DeviceMap.from_problem(ctx, probs[i], isobs="newest") for i in (0, 2)]
+    before = [DM.canonical_state(m.download()) for m in maps]
+
+    L = ctx.lib
+    assert L.ov2_map_local_ba_setup_batch(ctx.h, 0, None, None, 25, 1, 1, None, None) == 0
+    assert L.ov2_map_local_ba_update_batch(ctx.h, 0, None, None, None, None) == 0
+    with pytest.raises(Exception):   # no set-up ran on these maps yet
+        DM.update_batch(ctx, maps, (DM.SetupC * len(maps))(), want_lists=False)
+    with pytest.raises(Exception):
+        DM.setup_batch(ctx, [maps[0], maps[0]], calib_l=synth_ba.K_L)
+
+    views = DM.setup_batch(ctx, maps, calib_l=synth_ba.K_L)
+    assert [bool(v.aborted) for v in views] == [False, True, True, False]
+    rcs = _solve_on_device(ctx, maps, views, probs[0], True)
+    assert rcs[1].n_log == 0 and rcs[2].n_log == 0 and rcs[0].n_log > 1 and rcs[3].n_log > 1
+    upd = DM.update_batch(ctx, maps, views, cur_kfid=[m.newkf for m in maps])
+    after = [DM.canonical_state(m.download()) for m in maps]
+    assert after[1] == before[1] and after[2] == before[2] and after[2] == ({}, {}, {})
+    assert all(len(upd[i][k]) == 0 for i in (1, 2) for k in upd[i])
+    assert after[0] != before[0] and after[3] != before[3]
+
+    v2 = DM.setup_batch(ctx, alone, calib_l=synth_ba.K_L)
+    _solve_on_device(ctx, alone, v2, probs[0], True)
+    DM.update_batch(ctx, alone, v2, cur_kfid=[m.newkf for m in alone], want_lists=False)
+    assert DM.canonical_state(alone[0].download()) == after[0]
+    assert DM.canonical_state(alone[1].download()) == after[3]
