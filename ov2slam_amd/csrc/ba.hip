@@ -1165,6 +1165,9 @@ __device__ __forceinline__ void chol_sqrt_rcp(double d, double &root, double &in
     inv = __builtin_fma(__builtin_fma(-r, y, 1.0), y, y);   // 1 / root (y is 1 / sqrt(d); one step onto the rounded root)
 }
 
+#ifndef CHOL_TRIP
+#define CHOL_TRIP 8   // k-steps per trip of the panel update (4 columns each): 32 = the panel width divides every j0
+#endif
 __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
 {
     BA_WAVE_PRIO();
@@ -1200,28 +1203,25 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
             const bool r_ok = rr <= m;
             ov2_v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             // j0 is a multiple of 32: eight k-steps per trip, their 24 operand loads issued together (one L2 round trip per
-            // trip; issued step by step every matrix instruction waited for its own loads -- 53 us per panel at m = 354)
-            // (double-buffering the trips wants 48 operands + their 48 addresses live: 256 VGPRs and 636 bytes of scratch)
-            double bA[8], a0A[8], a1A[8];
-#define CHOL_FETCH(K, BB, A0, A1)                                                  \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                        \
-                const size_t kk = (size_t)((K) + 4 * u + kq);                      \
-                const double *col = A + kk * m;                                    \
-                BB[u] = r_ok ? rsrc[kk * rstep] : 0.0;                             \
-                A0[u] = ca_ok ? col[ca] : 0.0;                                     \
-                A1[u] = cb_ok ? col[cb] : 0.0;                                     \
+            // trip; issued step by step every matrix instruction waited for its own loads -- 53 us per panel at m = 354).
+            // Measured and not kept: double-buffered trips (48 operands + 48 addresses live: 256 VGPRs, 636 B of scratch);
+            // two tiles per wave and trip sharing the column operands (32 loads instead of 2 x 24: update phase 694 -> 765 us)
+            for (int k = 0; k < j0; k += 4 * CHOL_TRIP) {
+                double b[CHOL_TRIP], a0[CHOL_TRIP], a1[CHOL_TRIP];
+#pragma unroll
+                for (int u = 0; u < CHOL_TRIP; ++u) {
+                    const size_t kk = (size_t)(k + 4 * u + kq);
+                    const double *col = A + kk * m;
+                    b[u] = r_ok ? rsrc[kk * rstep] : 0.0;
+                    a0[u] = ca_ok ? col[ca] : 0.0;
+                    a1[u] = cb_ok ? col[cb] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < CHOL_TRIP; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u], acc1, 0, 0, 0);
+                }
             }
-#define CHOL_MAC(BB, A0, A1)                                                       \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                        \
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[u], BB[u], acc0, 0, 0, 0); \
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[u], BB[u], acc1, 0, 0, 0); \
-            }
-            for (int k = 0; k < j0; k += 32) {
-                CHOL_FETCH(k, bA, a0A, a1A)
-                CHOL_MAC(bA, a0A, a1A)
-            }
-#undef CHOL_FETCH
-#undef CHOL_MAC
             // acc_h[q] = sum_k L[j0 + 16 h + kq + 4 q][k] L[rr][k]: the update of P[rr][16 h + kq + 4 q]
             if (r_ok) {
 #pragma unroll
@@ -1237,27 +1237,29 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
         // (a) the nb x nb diagonal block: ONE wave, lane i keeps row i in registers, pivots travel by v_readlane
         if (tid < 64) {
             double row[NB];
+            int tl = tid;   // opaque: the 32 identity-padding constants (tl == c ? 1 : 0) are otherwise hoisted out of the panel
+            asm volatile("" : "+v"(tl));   // loop and held in 64 VGPRs for the whole kernel (spills)
 #pragma unroll
-            for (int c = 0; c < NB; ++c) row[c] = (tid < nb && c < nb) ? P[tid * PS + c] : ((tid == c) ? 1.0 : 0.0);
+            for (int c = 0; c < NB; ++c) row[c] = (tl < nb && c < nb) ? P[tl * PS + c] : ((tl == c) ? 1.0 : 0.0);
             int bad = 0;
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 const double dcc = readlane_f64(row[c], c);
-                if (c < nb && !(dcc > 0.0)) bad = 1;
+                if (!(dcc > 0.0)) bad = 1;   // (columns beyond a short last panel are identity columns: 1 > 0)
                 double dsq, inv;
                 chol_sqrt_rcp(dcc > 0.0 ? dcc : 1.0, dsq, inv);
-                if (tid == c) invd[c] = inv;
-                row[c] = (tid == c) ? dsq : row[c] * inv;
+                if (tl == c) invd[c] = inv;
+                row[c] = (tl == c) ? dsq : row[c] * inv;
 #pragma unroll
                 for (int c2 = c + 1; c2 < NB; ++c2) {
                     const double l = readlane_f64(row[c], c2);
                     row[c2] = __builtin_fma(-row[c], l, row[c2]);      // rows above the diagonal collect garbage that is never read
                 }
             }
-            if (tid < nb) {
+            if (tl < nb) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c)
-                    if (c <= tid && c < nb) P[tid * PS + c] = row[c];
+                    if (c <= tl) P[tl * PS + c] = row[c];
             }
             if (bad && tid == 0) *failp = 1;
         }
@@ -1268,10 +1270,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
         for (int i = nb + tid; i < rows; i += nth) {
             double x[NB];
 #pragma unroll
-            for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? P[i * PS + c] : 0.0;
+            for (int c = 0; c < NB; ++c) x[c] = P[i * PS + c];
+            // The test "column inside a short last panel" is made on a value the compiler cannot see through, once per column:
+            // written as `c < nb` it is 32 wave-uniform conditions kept live across the whole unrolled body (more scalar
+            // registers than there are: spilled to scratch through VGPR lanes), and without any test the 496 reads of L_D are
+            // invariant in the row loop and hoisted out of it (4 KB of spills per lane)
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
-                if (c < nb) {
+                int nbv = nb;
+                asm volatile("" : "+v"(nbv));
+                if (c < nbv) {
                     double v = x[c];
 #pragma unroll
                     for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], P[c * PS + k], v);
@@ -1319,8 +1327,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
                 double y = (lane < nb) ? zb[j0 + lane] - tpart[lane] : 0.0;
                 double colD[NB];   // lane i: colD[j] = L[j0+j][j0+i], j >= i
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    colD[j] = (lane < nb && j < nb && j >= lane) ? A[(size_t)(j0 + lane) * m + j0 + j] : ((j == lane) ? 1.0 : 0.0);
+                for (int j = 0; j < NB; ++j)   // (the diagonal goes through dinv, entries above it are never used)
+                    colD[j] = (lane < nb && j < nb && j > lane) ? A[(size_t)(j0 + lane) * m + j0 + j] : 0.0;
                 const double dinv = chol_rcp(lane < nb ? A[(size_t)(j0 + lane) * m + j0 + lane] : 1.0);   // lane j: 1 / L[j0+j][j0+j]
 #pragma unroll
                 for (int j = NB - 1; j >= 0; --j) {
