@@ -151,6 +151,27 @@ void Frame::removeKeypointById(int lmid)
     mapkps_.erase(it);
 }
 
+void Frame::updateKeypointDesc(int lmid, const Desc &d)
+{   // src/frame.cpp:356-366
+    auto it = mapkps_.find(lmid);
+    if (it == mapkps_.end()) return;
+    it->second.desc_ = d; it->second.has_desc_ = true;
+}
+
+bool Frame::updateKeypointId(int prevlmid, int newlmid, bool is3d)
+{   // src/frame.cpp:380-402
+    if (mapkps_.count(newlmid)) return false;
+    auto it = mapkps_.find(prevlmid);
+    if (it == mapkps_.end()) return false;
+    Keypoint upkp = it->second;
+    upkp.lmid_ = newlmid;
+    upkp.is_retracked_ = true;
+    upkp.is3d_ = is3d;
+    removeKeypointById(prevlmid);
+    addKeypoint(upkp);
+    return true;
+}
+
 void Frame::removeStereoKeypointById(int lmid)
 {
     auto it = mapkps_.find(lmid);
@@ -344,6 +365,60 @@ bool Frame::isInRightImage(const Point2f &pt) const
 }
 
 // ---------------------------------------------------------------------------------------------- MapPoint / MapManager
+static inline float hamming32(const Desc &a, const Desc &b)   // cv::norm(a, b, cv::NORM_HAMMING) of two 1 x 32 CV_8U rows
+{
+    int d = 0;
+    for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return (float)d;
+}
+
+void MapPoint::removeKfObs(int kfid)
+{   // src/map_point.cpp:106-160
+    if (!set_kfids_.count(kfid)) return;
+    set_kfids_.erase(kfid);
+    if (set_kfids_.empty()) {
+        has_desc_ = false; map_kf_desc_.clear(); map_desc_dist_.clear();
+        return;
+    }
+    if (kfid == kfid_) kfid_ = *set_kfids_.begin();   // the anchor moves to the oldest observer left
+    // the most representative descriptor among those left (:129-159)
+    float mindist = (has_desc_ ? 32 : 0) * 8.f;      // desc_.cols * 8
+    int minid = -1;
+    auto itdesc = map_kf_desc_.find(kfid);
+    if (itdesc != map_kf_desc_.end()) {
+        for (const auto &kf_d : map_kf_desc_) {
+            if (kf_d.first == kfid) continue;
+            const float dist = hamming32(itdesc->second, kf_d.second);
+            float &descdist = map_desc_dist_.find(kf_d.first)->second;
+            descdist -= dist;
+            if (descdist < mindist) { mindist = descdist; minid = kf_d.first; }
+        }
+        map_kf_desc_.erase(kfid);
+        map_desc_dist_.erase(kfid);
+        if (minid > 0) desc_ = map_kf_desc_.at(minid);   // (`> 0`, not `>= 0`: keyframe 0 never becomes the representative here -- as in the reference)
+    }
+}
+
+void MapPoint::addDesc(int kfid, const Desc &d)
+{   // src/map_point.cpp:162-211
+    if (map_kf_desc_.count(kfid)) return;
+    map_kf_desc_.emplace(kfid, d);
+    map_desc_dist_.emplace(kfid, 0.f);
+    float &newdescdist = map_desc_dist_.find(kfid)->second;
+    if (map_kf_desc_.size() == 1) { desc_ = d; has_desc_ = true; return; }
+    float mindist = (has_desc_ ? 32 : 0) * 8.f;
+    int minid = -1;
+    for (const auto &kf_d : map_kf_desc_) {   // includes the new one (distance 0 to itself), as the reference's loop does
+        const float dist = hamming32(d, kf_d.second);
+        map_desc_dist_.at(kf_d.first) += dist;
+        if (dist < mindist) { mindist = dist; minid = kf_d.first; }
+        newdescdist += dist;
+    }
+    if (newdescdist < mindist) minid = kfid;
+    desc_ = map_kf_desc_.at(minid);   // (minid == -1 only when desc_ was empty with descriptors present: the reference throws there too)
+    has_desc_ = true;
+}
+
 bool MapPoint::isBad()
 {   // src/map_point.cpp:215-234
     if (set_kfids_.size() < 2) {
@@ -421,19 +496,69 @@ void MapManager::removeObsFromCurFrameById(int lmid)
 }
 
 void MapManager::updateFrameCovisibility(Frame &frame)
-{   // src/map_manager.cpp updateFrameCovisibility: count co-observed landmarks per keyframe
-    std::map<int, int> cov;
-    for (const auto &kv : frame.mapkps_) {
-        auto plm = getMapPoint(kv.first);
-        if (!plm) continue;
+{   // src/map_manager.cpp:117-192: co-observation counts per keyframe + the local map (3D points of the covisible keyframes
+    // that this frame does not observe) for Mapper::matchingToLocalMap
+    std::map<int, int> map_covkfs;
+    std::unordered_set<int> set_local_mapids;
+    for (const auto &kp : frame.getKeypoints()) {
+        auto plm = getMapPoint(kp.lmid_);
+        if (!plm) {
+            removeMapPointObs(kp.lmid_, frame.kfid_);
+            removeObsFromCurFrameById(kp.lmid_);
+            continue;
+        }
         for (int kfid : plm->getKfObsSet())
-            if (kfid != frame.kfid_) cov[kfid]++;
+            if (kfid != frame.kfid_) map_covkfs[kfid] += 1;
     }
-    frame.map_covkfs_ = cov;
-    for (const auto &kv : cov) {
-        auto pkf = getKeyframe(kv.first);
-        if (pkf) pkf->map_covkfs_[frame.kfid_] = kv.second;
+    std::set<int> set_badkfids;
+    for (const auto &kfid_cov : map_covkfs) {
+        auto pkf = getKeyframe(kfid_cov.first);
+        if (pkf) {
+            pkf->map_covkfs_[frame.kfid_] = kfid_cov.second;
+            for (const auto &kp : pkf->getKeypoints3d())
+                if (!frame.isObservingKp(kp.lmid_)) set_local_mapids.insert(kp.lmid_);
+        } else set_badkfids.insert(kfid_cov.first);
     }
+    for (int kfid : set_badkfids) map_covkfs.erase(kfid);
+    frame.map_covkfs_.swap(map_covkfs);
+    if (set_local_mapids.size() > 0.5 * frame.set_local_mapids_.size()) frame.set_local_mapids_.swap(set_local_mapids);
+    else frame.set_local_mapids_.insert(set_local_mapids.begin(), set_local_mapids.end());
+}
+
+void MapManager::setMapPointObs(int lmid)
+{   // src/map_manager.cpp:1053-1090
+    auto plm = getMapPoint(lmid);
+    if (!plm) return;
+    plm->isobs_ = true;
+    touchMapPoint(lmid);
+}
+
+void MapManager::mergeMapPoints(int prevlmid, int newlmid)
+{   // src/map_manager.cpp:801-882: the observations and descriptors of prevlmid go to newlmid, prevlmid leaves the map
+    auto pprev = getMapPoint(prevlmid), pnew = getMapPoint(newlmid);
+    if (!pprev || !pnew || !pnew->is3d_) return;
+    const std::set<int> setnewkfids = pnew->getKfObsSet(), setprevkfids = pprev->getKfObsSet();
+    const std::unordered_map<int, Desc> map_prev_kf_desc = pprev->map_kf_desc_;
+    for (int pkfid : setprevkfids) {
+        auto pkf = getKeyframe(pkfid);
+        if (!pkf) continue;
+        if (pkf->updateKeypointId(prevlmid, newlmid, pnew->is3d_)) {
+            pnew->addKfObs(pkfid);
+            for (int nkfid : setnewkfids) {
+                auto pcokf = getKeyframe(nkfid);
+                if (pcokf) { pkf->addCovisibleKf(nkfid); pcokf->addCovisibleKf(pkfid); }
+            }
+            if (dev_ && dev_kfs_.count(pkfid)) {   // the mirror holds this keyframe: its row (pkfid, prevlmid) becomes (pkfid, newlmid)
+                dev_rm_kf_.push_back(pkfid); dev_rm_lm_.push_back(prevlmid);
+                dev_add_obs_.emplace_back(pkfid, newlmid);
+            }
+        }
+    }
+    for (const auto &kfid_desc : map_prev_kf_desc) pnew->addDesc(kfid_desc.first, kfid_desc.second);
+    if (pcurframe_ && pcurframe_->isObservingKp(prevlmid) && pcurframe_->updateKeypointId(prevlmid, newlmid, pnew->is3d_)) setMapPointObs(newlmid);
+    map_plms_.erase(prevlmid);
+    touchMapPoint(prevlmid);   // gone: the mirror's row dies with the next flush
+    touchMapPoint(newlmid);
 }
 
 // ---------------------------------------------------------------------------------------------- device map mirror
@@ -464,12 +589,14 @@ ov2_status MapManager::addKeyframeToDevice(const Frame &kf)
         st.push_back(kp.is_stereo_ ? 1 : 0);
     }
     const SE3 T = kf.getTwc();
+    dev_kfs_.insert(kf.kfid_);
     return ov2_map_add_keyframe(dev_, kf.kfid_, T.v.data(), (int)n, lmid.data(), un.data(), run.data(), st.data(), scale.data());
 }
 
 ov2_status MapManager::attachDevice(ov2_ctx *ctx, int max_kf, int max_lm, int max_obs)
 {
     if (dev_) { ov2_map_destroy(dev_); dev_ = nullptr; }
+    dev_kfs_.clear(); dev_add_obs_.clear();
     ov2_status s = ov2_map_create(ctx, max_kf, max_lm, max_obs, &dev_);
     if (s != OV2_OK) return s;
     std::vector<int32_t> lmid; std::vector<double> xyz; std::vector<uint8_t> st;
@@ -492,6 +619,26 @@ ov2_status MapManager::flushDevice()
     if (!dev_rm_kf_.empty()) {
         if ((s = ov2_map_remove_obs(dev_, (int)dev_rm_kf_.size(), dev_rm_kf_.data(), dev_rm_lm_.data())) != OV2_OK) return s;
         dev_rm_kf_.clear(); dev_rm_lm_.clear();
+    }
+    if (!dev_add_obs_.empty()) {   // after the removals: a merged observation (kf, prev) -> (kf, new) is a dead row + an appended one
+        std::map<int, std::vector<int>> by_kf;
+        for (const auto &e : dev_add_obs_) by_kf[e.first].push_back(e.second);
+        dev_add_obs_.clear();
+        for (const auto &kv : by_kf) {
+            auto pkf = getKeyframe(kv.first);
+            if (!pkf) continue;
+            std::vector<int32_t> lmid, scale; std::vector<double> un, run; std::vector<uint8_t> st;
+            for (int l : kv.second) {
+                const Keypoint kp = pkf->getKeypointById(l);
+                if (kp.lmid_ != l) continue;   // removed again since
+                lmid.push_back(l); scale.push_back(kp.scale_);
+                un.push_back(kp.unpx_.x); un.push_back(kp.unpx_.y); run.push_back(kp.runpx_.x); run.push_back(kp.runpx_.y);
+                st.push_back(kp.is_stereo_ ? 1 : 0);
+            }
+            const SE3 T = pkf->getTwc();
+            if (!lmid.empty() && (s = ov2_map_add_keyframe(dev_, kv.first, T.v.data(), (int)lmid.size(), lmid.data(), un.data(), run.data(), st.data(),
+                                                           scale.data())) != OV2_OK) return s;
+        }
     }
     if (!dev_st_kf_.empty()) {
         std::vector<uint8_t> off(dev_st_kf_.size(), 0);

@@ -57,10 +57,23 @@ struct CameraCalibration {   // the part of src/camera_calibration.cpp that the 
     Point2f undistortImagePoint(const Point2f &pt) const;
     // :254-282 -> cv::projectPoints with zero rvec / tvec (radial-tangential) / cv::fisheye::distortPoints
     Point2f projectCamToImageDist(const Vec3 &pc) const;
+    bool fillCamModel(ov2_cam_model *m) const   // the lens model as the kernels take it; false = no distortion
+    {
+        *m = ov2_cam_model();
+        m->K[0] = fx_; m->K[1] = fy_; m->K[2] = cx_; m->K[3] = cy_;
+        m->model = D_.empty() ? 0 : (model_ == Fisheye ? 2 : 1);
+        m->n_coeffs = (int32_t)(D_.size() < 5 ? D_.size() : 5);
+        for (int k = 0; k < m->n_coeffs; ++k) m->D[k] = D_[k];
+        return m->model != 0;
+    }
 };
+
+typedef std::array<uint8_t, 32> Desc;   // one BRIEF-32 descriptor (the 1 x 32 CV_8U cv::Mat of the reference)
 
 struct Keypoint {   // include/frame.hpp:46-76
     int lmid_ = -1;
+    Desc desc_{};
+    bool has_desc_ = false;   // !desc_.empty()
     Point2f px_, unpx_;
     int scale_ = 0;
     float angle_ = -1.f;
@@ -80,6 +93,7 @@ public:
     SE3 Twc_, Tcw_;
     std::shared_ptr<CameraCalibration> pcalib_leftcam_, pcalib_rightcam_;
     std::map<int, int> map_covkfs_;
+    std::unordered_set<int> set_local_mapids_;   // include/frame.hpp:209: map points of the covisible keyframes this frame does not observe
 
     // keypoint grid (include/frame.hpp:214-221, src/frame.cpp:40-45): cells of ncellsize_ px, ids per cell in insertion
     // order.  initGrid() plays the part of the reference constructors; a Frame without it keeps no grid.
@@ -103,6 +117,10 @@ public:
     Keypoint getKeypointById(int lmid) const;   // returns Keypoint with lmid_ = -1 if absent (src/frame.cpp)
     std::map<int, int> getCovisibleKfMap() const { return map_covkfs_; }
     void removeCovisibleKf(int kfid) { map_covkfs_.erase(kfid); }
+    void addCovisibleKf(int kfid) { if (kfid != kfid_) map_covkfs_[kfid] += 1; }   // src/frame.cpp:664-677
+    bool isObservingKp(int lmid) const { return mapkps_.count(lmid) != 0; }       // :502-506
+    void updateKeypointDesc(int lmid, const Desc &d);                              // :356-366
+    bool updateKeypointId(int prevlmid, int newlmid, bool is3d);                   // :380-402
     void decreaseCovisibleKf(int kfid)   // src/frame.cpp:689-705
     {
         if (kfid == kfid_) return;
@@ -121,6 +139,19 @@ public:
 class MapPoint {   // include/map_point.hpp:37-97
 public:
     MapPoint(int lmid, int kfid, bool bobs = true) : lmid_(lmid), isobs_(bobs), kfid_(kfid) { set_kfids_.insert(kfid); }
+    MapPoint(int lmid, int kfid, const Desc &desc, bool bobs = true) : lmid_(lmid), isobs_(bobs), kfid_(kfid)   // src/map_point.cpp:40-51
+    {
+        set_kfids_.insert(kfid);
+        map_kf_desc_.emplace(kfid, desc); map_desc_dist_.emplace(kfid, 0.f);
+        desc_ = desc; has_desc_ = true;
+    }
+    // descriptors (include/map_point.hpp:84-88): one per observing keyframe, the sum of its Hamming distances to the others,
+    // and the representative one (desc_).  Same containers as the reference: their iteration order decides ties.
+    Desc desc_{};
+    bool has_desc_ = false;
+    std::unordered_map<int, Desc> map_kf_desc_;
+    std::unordered_map<int, float> map_desc_dist_;
+    void addDesc(int kfid, const Desc &d);   // src/map_point.cpp:162-211
     int lmid_;
     bool isobs_;
     bool is3d_ = false;
@@ -132,11 +163,7 @@ public:
     Vec3 getPoint() const { return ptxyz_; }
     std::set<int> getKfObsSet() const { return set_kfids_; }
     void addKfObs(int kfid) { set_kfids_.insert(kfid); }
-    void removeKfObs(int kfid)   // src/map_point.cpp:106-126 (descriptor bookkeeping aside): the anchor moves to the oldest observer left
-    {
-        if (!set_kfids_.erase(kfid) || set_kfids_.empty()) return;
-        if (kfid == kfid_) kfid_ = *set_kfids_.begin();
-    }
+    void removeKfObs(int kfid);   // src/map_point.cpp:106-160: the anchor moves to the oldest observer left, the descriptor of kfid goes
     bool isBad();   // src/map_point.cpp:215-234
 };
 
@@ -151,7 +178,9 @@ public:
     void removeMapPointObs(int lmid, int kfid);
     void removeMapPoint(int lmid);
     void removeObsFromCurFrameById(int lmid);
-    void updateFrameCovisibility(Frame &frame);   // src/map_manager.cpp: co-observation counts
+    void updateFrameCovisibility(Frame &frame);   // src/map_manager.cpp:117-192: co-observation counts + the frame's local map
+    void mergeMapPoints(int prevlmid, int newlmid);   // :801-882
+    void setMapPointObs(int lmid);                    // :1053-1090 (the isobs_ flag; the point cloud colour is not mirrored)
     // src/map_manager.cpp:367-611, statement by statement: priors (3D point reprojected into the right camera :398-413;
     // rectified rigs: getLineMinSAD on the coarsest level :419-436 = ov2_line_min_sad; otherwise the inverse-distance
     // weighted depth of the 3D neighbours :438-483), 3D keypoints whose map point is gone lose their observation (:414),
@@ -173,6 +202,8 @@ public:
     void touchStereoOff(int kfid, int lmid) { if (dev_) { dev_st_kf_.push_back(kfid); dev_st_lm_.push_back(lmid); } }
     ov2_map *dev_ = nullptr;
     std::vector<int32_t> dev_lm_dirty_, dev_pose_dirty_, dev_rm_kf_, dev_rm_lm_, dev_st_kf_, dev_st_lm_;
+    std::vector<std::pair<int, int>> dev_add_obs_;   // (kfid, lmid): observations a merge gave to keyframes the mirror already holds
+    std::set<int> dev_kfs_;                          // keyframes pushed to the mirror
 };
 
 struct SlamParams {   // the subset of include/slam_params.hpp the path reads (YAML keys of the same name)
@@ -189,6 +220,8 @@ struct SlamParams {   // the subset of include/slam_params.hpp the path reads (Y
     // keyframe creation / selection (src/slam_params.cpp:95-125, YAML keys of the same name)
     int nmaxdist_ = 35, nbmaxkps_ = 308;            // nbmaxkps_ = ceil(w / nmaxdist) * ceil(h / nmaxdist) (:107-110)
     bool use_fast_ = false, use_singlescale_detector_ = true, use_brief_ = false, doepipolar_ = false;
+    bool bdo_track_localmap_ = true;                               // src/slam_params.cpp:133
+    float fmax_desc_dist_ = 0.2f, fmax_proj_pxdist_ = 2.f;         // :135-136
     double dmaxquality_ = 0.001;
     int nfast_th_ = 10;
     float finit_parallax_ = 20.f, fmax_reproj_err_ = 3.f;

@@ -525,6 +525,111 @@ int ov2h_slam_landmarks(void *p, int cap, int *lmid, double *xyz)
 
 void ov2h_slam_destroy(void *p) { delete (SlamManager *)p; }
 
+// keyframe descriptors + Mapper::matchingToLocalMap: pattern = the 256 x 4 int8 BRIEF test table (NULL keeps the current one)
+void ov2h_slam_set_brief(void *p, const int8_t *pattern, int use_brief, int track_localmap, float fmax_desc_dist, float fmax_proj_pxdist)
+{
+    SlamManager *S = (SlamManager *)p;
+    if (pattern) S->setBriefPattern(pattern);
+    S->pslamstate_->use_brief_ = use_brief != 0;
+    S->pslamstate_->bdo_track_localmap_ = track_localmap != 0;
+    if (fmax_desc_dist > 0.f) S->pslamstate_->fmax_desc_dist_ = fmax_desc_dist;
+    if (fmax_proj_pxdist > 0.f) S->pslamstate_->fmax_proj_pxdist_ = fmax_proj_pxdist;
+}
+
+// out[3] of the last frame (keyframes only): keypoints described, local map points offered to matchToMap, merges
+void ov2h_slam_kf_stats(void *p, double *out)
+{
+    const SlamStats &s = ((SlamManager *)p)->last_;
+    out[0] = s.n_described; out[1] = s.n_local; out[2] = s.n_matched;
+}
+
+void *ov2h_slam_device_handle(void *p) { return ((SlamManager *)p)->pmap_->dev_; }
+int ov2h_slam_flush_device(void *p) { return (int)((SlamManager *)p)->pmap_->flushDevice(); }
+
+// Invariants of the host map after any sequence of frames.  out[6]: keypoints of keyframes whose map point is missing,
+// keypoints whose map point does not list the keyframe, observers a map point lists that do not hold it (or are gone),
+// covisibility entries that differ from the count of co-observed map points, 3D map points without a descriptor although
+// use_brief_ is on, map points with descriptors from keyframes that do not observe them.  returns their sum
+int ov2h_slam_check_map(void *p, int *out)
+{
+    SlamManager *S = (SlamManager *)p;
+    MapManager &M = *S->pmap_;
+    int v[6] = {0, 0, 0, 0, 0, 0};
+    for (const auto &kf : M.map_pkfs_) {
+        std::map<int, int> cov;
+        for (const auto &kv : kf.second->mapkps_) {
+            auto plm = M.getMapPoint(kv.first);
+            if (!plm) { ++v[0]; continue; }
+            if (!plm->set_kfids_.count(kf.first)) ++v[1];
+            for (int o : plm->set_kfids_) if (o != kf.first && M.getKeyframe(o)) cov[o]++;
+        }
+        for (const auto &c : cov) { auto it = kf.second->map_covkfs_.find(c.first); if (it == kf.second->map_covkfs_.end() || it->second != c.second) ++v[3]; }
+        for (const auto &c : kf.second->map_covkfs_) if (!cov.count(c.first) && M.getKeyframe(c.first)) ++v[3];
+    }
+    for (const auto &lm : M.map_plms_) {
+        for (int kfid : lm.second->set_kfids_) {
+            auto pkf = M.getKeyframe(kfid);
+            if (!pkf || !pkf->mapkps_.count(lm.first)) ++v[2];
+        }
+        if (S->pslamstate_->use_brief_ && lm.second->is3d_ && !lm.second->has_desc_) ++v[4];
+        for (const auto &d : lm.second->map_kf_desc_) if (!lm.second->set_kfids_.count(d.first)) ++v[5];
+    }
+    int tot = 0;
+    for (int i = 0; i < 6; ++i) { if (out) out[i] = v[i]; tot += v[i]; }
+    return tot;
+}
+
+// the host map as flat arrays (capacity caps; counts come back in n[3] = keyframes, landmarks, observations):
+// keyframes (id, Twc), landmarks (id, xyz, state bits: 1 alive | 2 is3d | 4 isobs), observations (kfid, lmid, stereo)
+void ov2h_slam_export_map(void *p, int cap_kf, int cap_lm, int cap_obs, int *n, int *kf_id, double *kf_pose, int *lm_id, double *lm_xyz,
+                          uint8_t *lm_state, int *obs_kf, int *obs_lm, uint8_t *obs_stereo)
+{
+    MapManager &M = *((SlamManager *)p)->pmap_;
+    int nk = 0, nl = 0, no = 0;
+    std::map<int, std::shared_ptr<Frame>> kfs(M.map_pkfs_.begin(), M.map_pkfs_.end());
+    for (const auto &kf : kfs) {
+        if (nk < cap_kf) { kf_id[nk] = kf.first; const SE3 T = kf.second->getTwc(); for (int i = 0; i < 7; ++i) kf_pose[7 * nk + i] = T.v[i]; }
+        ++nk;
+        std::map<int, Keypoint> kps(kf.second->mapkps_.begin(), kf.second->mapkps_.end());
+        for (const auto &kv : kps) {
+            if (no < cap_obs) { obs_kf[no] = kf.first; obs_lm[no] = kv.first; obs_stereo[no] = kv.second.is_stereo_ ? 1 : 0; }
+            ++no;
+        }
+    }
+    std::map<int, std::shared_ptr<MapPoint>> lms(M.map_plms_.begin(), M.map_plms_.end());
+    for (const auto &lm : lms) {
+        if (nl < cap_lm) {
+            lm_id[nl] = lm.first; const Vec3 q = lm.second->getPoint(); lm_xyz[3 * nl] = q.x; lm_xyz[3 * nl + 1] = q.y; lm_xyz[3 * nl + 2] = q.z;
+            lm_state[nl] = (uint8_t)(1 | (lm.second->is3d_ ? 2 : 0) | (lm.second->isobs_ ? 4 : 0));
+        }
+        ++nl;
+    }
+    n[0] = nk; n[1] = nl; n[2] = no;
+}
+
+// ---- MapPoint descriptor bookkeeping alone (tests: against a restatement of src/map_point.cpp:106-211) ----
+void *ov2h_mp_new(int lmid, int kfid, const uint8_t *desc)
+{
+    if (!desc) return new MapPoint(lmid, kfid, true);
+    Desc d; std::copy(desc, desc + 32, d.begin());
+    return new MapPoint(lmid, kfid, d, true);
+}
+void ov2h_mp_add_obs(void *p, int kfid) { ((MapPoint *)p)->addKfObs(kfid); }
+void ov2h_mp_add_desc(void *p, int kfid, const uint8_t *desc) { Desc d; std::copy(desc, desc + 32, d.begin()); ((MapPoint *)p)->addDesc(kfid, d); }
+void ov2h_mp_remove_obs(void *p, int kfid) { ((MapPoint *)p)->removeKfObs(kfid); }
+// out_i[4] = has_desc, anchor kfid, observers, descriptors; desc[32] = the representative one; per descriptor (cap): kfid + summed distance
+int ov2h_mp_state(void *p, int *out_i, uint8_t *desc, int cap, int *kfids, float *dists)
+{
+    MapPoint &m = *(MapPoint *)p;
+    out_i[0] = m.has_desc_ ? 1 : 0; out_i[1] = m.kfid_; out_i[2] = (int)m.set_kfids_.size(); out_i[3] = (int)m.map_kf_desc_.size();
+    std::copy(m.desc_.begin(), m.desc_.end(), desc);
+    std::map<int, float> d(m.map_desc_dist_.begin(), m.map_desc_dist_.end());
+    int n = 0;
+    for (const auto &kv : d) { if (n < cap) { kfids[n] = kv.first; dists[n] = kv.second; } ++n; }
+    return n;
+}
+void ov2h_mp_free(void *p) { delete (MapPoint *)p; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // Estimator threads of `nseq` SLAM instances (reference src/estimator.cpp:32-98 run(): wait for a keyframe ->
 // applyLocalBA -> next), served by ONE native thread with its own HIP context: it takes every sequence that has a
@@ -939,6 +1044,106 @@ void ov2h_ba_worker_destroy(void *p)
     for (void *d : w->owned_d) ov2_dev_free(w->ctx, d);
     ov2_ctx_destroy(w->ctx);
     delete w;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Native per-frame driver of the bench streams: what SlamManager::run's loop does per image for B lock-step sequences
+// (preprocessImage -> kltTracking -> ceresPnP; on a keyframe: right pyramid -> stereoMatching -> detector, then the
+// keyframe goes to the Estimator workers) over device-resident inputs, enqueued from C++ so that small streams (one
+// 308-keypoint sequence) are not bound by the interpreter's ~15 us per ctypes call.  Every pointer is a device pointer
+// owned by the caller; nothing is synchronised here.
+struct ov2h_feloop_cfg {
+    int32_t L, B, n, win, nlvl, use_clahe, tiles_x, tiles_y;
+    float clahe_clip, err_th, fb_th, eps;
+    int32_t max_iter, detect, det_cell, det_ncur, det_cap, pnp;
+    void *const *left, *const *right;                   // L batches of images (ov2_images*)
+    const float *const *kps, *const *pri, *const *st_pri;   // per cycle position: n x 2
+    const uint8_t *const *has, *const *st_has;
+    const int32_t *img_idx;
+    float *out_xy; uint8_t *out_st; int32_t *p3p;
+    // per-frame pose refinement (one problem per sequence, re-solved from T0 every frame)
+    const int32_t *pnp_off; const double *pnp_unpx, *pnp_wpts, *pnp_K, *pnp_T0; double *pnp_T;
+    uint8_t *pnp_outl, *pnp_rem; int32_t *pnp_ok; uint64_t pnp_T_bytes;
+    // keyframe detector
+    double *det_thresh; const float *det_cur; const int32_t *det_img; int32_t *det_nout; float *det_out;
+};
+
+struct FeLoopNative {
+    ov2_ctx *ctx = nullptr;
+    ov2h_feloop_cfg c{};
+    std::vector<void *> left, right;
+    std::vector<const float *> kps, pri, st_pri;
+    std::vector<const uint8_t *> has, st_has;
+    ov2_pyr *prev = nullptr;
+    long step_no = 0;
+};
+
+void *ov2h_feloop_create(void *ctx, const ov2h_feloop_cfg *cfg)
+{
+    if (!ctx || !cfg || cfg->L <= 0) return nullptr;
+    FeLoopNative *f = new FeLoopNative();
+    f->ctx = (ov2_ctx *)ctx; f->c = *cfg;
+    const int L = cfg->L;
+    f->left.assign(cfg->left, cfg->left + L); f->right.assign(cfg->right, cfg->right + L);
+    f->kps.assign(cfg->kps, cfg->kps + L); f->pri.assign(cfg->pri, cfg->pri + L); f->st_pri.assign(cfg->st_pri, cfg->st_pri + L);
+    f->has.assign(cfg->has, cfg->has + L); f->st_has.assign(cfg->st_has, cfg->st_has + L);
+    return f;
+}
+
+// runs `steps` frames; a keyframe every kf_every-th frame submits a job to each of the n_pipes Estimator pipelines.
+// returns 0 or the first failing status; *n_kf = keyframes in this call
+int ov2h_feloop_run(void *h, int steps, int kf_every, void *const *pipes, int n_pipes, int *n_kf)
+{
+    FeLoopNative *f = (FeLoopNative *)h;
+    const ov2h_feloop_cfg &c = f->c;
+    ov2_ctx *ctx = f->ctx;
+    int kfs = 0;
+    for (int it = 0; it < steps; ++it) {
+        const int p = (int)(f->step_no % c.L);
+        ov2_pyr *cur = nullptr;
+        ov2_status s = ov2_pyramid_build_images(ctx, (const ov2_images *)f->left[p], c.win, c.nlvl, c.use_clahe, c.clahe_clip, c.tiles_x,
+                                                c.tiles_y, &cur);
+        if (s != OV2_OK) return (int)s;
+        if (f->prev) {
+            s = ov2_klt_tracking_frame_dev(ctx, f->prev, cur, c.win, c.nlvl, c.max_iter, c.eps, c.err_th, c.fb_th, c.n, f->kps[p], f->pri[p],
+                                           f->has[p], c.img_idx, c.out_xy, c.out_st, c.p3p, nullptr);
+            ov2_pyr_release(f->prev);
+            f->prev = nullptr;
+            if (s != OV2_OK) { ov2_pyr_release(cur); return (int)s; }
+            if (c.pnp) {
+                if ((s = ov2_memcpy_d2d(ctx, c.pnp_T, c.pnp_T0, (size_t)c.pnp_T_bytes)) != OV2_OK ||
+                    (s = ov2_pnp_solve_batch_dev(ctx, c.B, c.pnp_off, c.pnp_unpx, c.pnp_wpts, nullptr, c.pnp_K, c.pnp_T, 5, 5.9915f, 1, 1,
+                                                 c.pnp_outl, c.pnp_rem, c.pnp_ok, nullptr)) != OV2_OK) { ov2_pyr_release(cur); return (int)s; }
+            }
+        }
+        f->prev = cur;
+        const bool is_kf = kf_every > 0 && (f->step_no % kf_every) == 0;
+        if (is_kf) {
+            ov2_pyr *rp = nullptr;
+            if ((s = ov2_pyramid_build_images(ctx, (const ov2_images *)f->right[p], c.win, c.nlvl, c.use_clahe, c.clahe_clip, c.tiles_x,
+                                              c.tiles_y, &rp)) != OV2_OK) return (int)s;
+            s = ov2_stereo_matching_dev(ctx, cur, rp, c.win, c.nlvl, c.max_iter, c.eps, c.err_th, c.fb_th, c.n, f->kps[p], f->st_pri[p],
+                                        f->st_has[p], c.img_idx, nullptr, 1, nullptr, nullptr, c.out_xy, c.out_st, nullptr);
+            ov2_pyr_release(rp);
+            if (s != OV2_OK) return (int)s;
+            if (c.detect && (s = ov2_detect_grid_batch_dev(ctx, cur, c.det_cell, OV2_DETECT_MINEIG, c.det_thresh, c.det_ncur, c.det_cur, c.det_img,
+                                                           nullptr, nullptr, 1, c.det_nout, c.det_out, c.det_cap)) != OV2_OK) return (int)s;
+            for (int k = 0; k < n_pipes; ++k) ov2h_ba_pipeline_submit_all(pipes[k]);
+            ++kfs;
+        }
+        ++f->step_no;
+    }
+    if (n_kf) *n_kf = kfs;
+    return 0;
+}
+
+void ov2h_feloop_destroy(void *h)
+{
+    FeLoopNative *f = (FeLoopNative *)h;
+    if (!f) return;
+    if (f->prev) ov2_pyr_release(f->prev);
+    delete f;
 }
 
 }  // extern "C"

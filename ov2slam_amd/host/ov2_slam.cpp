@@ -126,6 +126,7 @@ ov2_status SlamManager::addNewStereoImages(double time, const uint8_t *im0, cons
     last_ = SlamStats();
     last_.frame = frame_id_;
     ov2_status st = OV2_OK;
+    imraw_ = im0; imw_ = w; imh_ = h; imstride_ = stride; raw_pyr_ = Pyramid();
     const bool is_kf_req = visualTracking(im0, w, h, stride, time, &st);
     if (st != OV2_OK) return st;
     if (is_kf_req) {
@@ -264,13 +265,48 @@ void SlamManager::prepareFrame()
     }
 }
 
+ov2_status SlamManager::describeBRIEF(const std::vector<Point2f> &vpts, std::vector<Desc> &vdescs, std::vector<uint8_t> &valid)
+{   // src/feature_extractor.cpp:224-285 on the RAW left image (src/map_manager.cpp:300, 325): ov2_describe_brief on a level-0
+    // pyramid of it, built once per keyframe
+    vdescs.assign(vpts.size(), Desc{}); valid.assign(vpts.size(), 0);
+    if (vpts.empty()) return OV2_OK;
+    if (brief_pattern_.size() != 1024) return OV2_ERR_INVALID;   // use_brief_ without setBriefPattern
+    ov2_status s;
+    if (raw_pyr_.empty()) {
+        ov2_pyr *pr = nullptr;
+        if ((s = ov2_pyramid_build(ctx_, imraw_, imw_, imh_, imstride_, pslamstate_->nklt_win_size_, 0, 0, 0.f, 1, 1, &pr)) != OV2_OK) return s;
+        raw_pyr_ = Pyramid(pr);
+    }
+    static_assert(sizeof(Desc) == 32, "Desc must be 32 packed bytes");
+    return ov2_describe_brief(ctx_, raw_pyr_.h, 0, (int)vpts.size(), &vpts[0].x, brief_pattern_.data(), vdescs[0].data(), valid.data());
+}
+
+ov2_status SlamManager::describeKeypoints(const std::vector<Keypoint> &vkps, const std::vector<Point2f> &vpts)
+{   // src/map_manager.cpp:343-362: the tracked keypoints get the descriptor of THIS keyframe; their map points collect it
+    std::vector<Desc> vdescs; std::vector<uint8_t> valid;
+    const ov2_status s = describeBRIEF(vpts, vdescs, valid);
+    if (s != OV2_OK) return s;
+    for (size_t i = 0; i < vkps.size(); ++i) {
+        if (!valid[i]) continue;
+        pcurframe_->updateKeypointDesc(vkps[i].lmid_, vdescs[i]);
+        auto plm = pmap_->getMapPoint(vkps[i].lmid_);
+        if (plm) plm->addDesc(pcurframe_->kfid_, vdescs[i]);   // (the reference's map_plms_.at() throws for a missing point)
+        ++last_.n_described;
+    }
+    return OV2_OK;
+}
+
 ov2_status SlamManager::extractKeypoints()
-{   // src/map_manager.cpp:286-340 (BRIEF description of the keypoints is out of scope here: use_brief_ = 0)
+{   // src/map_manager.cpp:286-340
     std::vector<Keypoint> vkps = pcurframe_->getKeypoints();
     // the detector's result does not depend on the order of the existing keypoints (discs + occupied cells); ids ascending
     std::sort(vkps.begin(), vkps.end(), [](const Keypoint &a, const Keypoint &b) { return a.lmid_ < b.lmid_; });
     std::vector<Point2f> vpts;
     for (const auto &kp : vkps) vpts.push_back(kp.px_);
+    if (pslamstate_->use_brief_) {
+        const ov2_status sd = describeKeypoints(vkps, vpts);
+        if (sd != OV2_OK) return sd;
+    }
     const int nb2detect = pslamstate_->nbmaxkps_ - (int)pcurframe_->noccupcells_;
     if (nb2detect <= 0) return OV2_OK;
     const CameraCalibration &c = *pcurframe_->pcalib_leftcam_;
@@ -281,8 +317,30 @@ ov2_status SlamManager::extractKeypoints()
     else return OV2_ERR_UNSUPPORTED;   // detectGFTT
     if (pfeatextract_->last_status_ != OV2_OK) return pfeatextract_->last_status_;
     last_.n_new = (int)vnewpts.size();
-    if (!vnewpts.empty()) addKeypointsToFrame(vnewpts, *pcurframe_);
+    if (vnewpts.empty()) return OV2_OK;
+    if (pslamstate_->use_brief_) {
+        std::vector<Desc> vdescs; std::vector<uint8_t> valid;
+        const ov2_status sd = describeBRIEF(vnewpts, vdescs, valid);
+        if (sd != OV2_OK) return sd;
+        addKeypointsToFrame(vnewpts, vdescs, valid, *pcurframe_);
+    } else addKeypointsToFrame(vnewpts, *pcurframe_);
     return OV2_OK;
+}
+
+void SlamManager::addKeypointsToFrame(const std::vector<Point2f> &vpts, const std::vector<Desc> &vdescs, const std::vector<uint8_t> &valid,
+                                      Frame &frame)
+{   // src/map_manager.cpp:229-255 + addMapPoint(desc) :664-688
+    for (size_t i = 0; i < vpts.size(); ++i) {
+        Keypoint kp;
+        kp.lmid_ = nlmid_;
+        frame.computeKeypoint(vpts[i], kp);
+        if (valid[i]) { kp.desc_ = vdescs[i]; kp.has_desc_ = true; ++last_.n_described; }
+        frame.addKeypoint(kp);
+        pmap_->map_plms_.emplace(nlmid_, valid[i] ? std::make_shared<MapPoint>(nlmid_, nkfid_, vdescs[i], true)
+                                                  : std::make_shared<MapPoint>(nlmid_, nkfid_, true));
+        pmap_->touchMapPoint(nlmid_);
+        nlmid_++;
+    }
 }
 
 void SlamManager::addKeypointsToFrame(const std::vector<Point2f> &vpts, Frame &frame)
@@ -325,7 +383,7 @@ ov2_status SlamManager::mapperRun(const Keyframe &kf)
     // every matched keypoint is 3D after its first keyframe; the mono-only path is not built here.
     pmap_->updateFrameCovisibility(*pnewkf);                     // :160
     pcurframe_->map_covkfs_ = pnewkf->map_covkfs_;               // :163
-    if (S.use_brief_) return OV2_ERR_UNSUPPORTED;                // matchingToLocalMap needs the BRIEF table of opencv_contrib
+    if (S.use_brief_ && kf.kfid_ > 0 && S.bdo_track_localmap_ && (s = matchingToLocalMap(*pnewkf)) != OV2_OK) return s;   // :153-162
     last_.n_lm3d = 0;
     for (const auto &kv : pmap_->map_plms_) last_.n_lm3d += kv.second->is3d_;
     // Estimator::addNewKf -> applyLocalBA (src/estimator.cpp:67-98)
@@ -340,6 +398,119 @@ ov2_status SlamManager::mapperRun(const Keyframe &kf)
         last_.ba_cost1 = r.l2_done ? r.l2_final_cost : r.final_cost;
     }
     return s;
+}
+
+ov2_status SlamManager::matchingToLocalMap(Frame &frame)
+{   // src/mapper.cpp:469-554 (bnewkfavailable_ = false: one call processes a keyframe to the end); the merges run here, before
+    // the local BA, where the reference detaches a thread that takes optim_mutex_
+    const size_t nmax_localplms = (size_t)pslamstate_->nbmaxkps_ * 10;
+    auto cov_map = frame.getCovisibleKfMap();
+    if (cov_map.empty()) return OV2_OK;   // (the reference dereferences begin() of an empty map here)
+    if (frame.set_local_mapids_.size() < nmax_localplms) {
+        int kfid = cov_map.begin()->first;
+        auto pkf = pmap_->getKeyframe(kfid);
+        while (!pkf && kfid > 0) { kfid--; pkf = pmap_->getKeyframe(kfid); }
+        if (pkf) frame.set_local_mapids_.insert(pkf->set_local_mapids_.begin(), pkf->set_local_mapids_.end());
+        // "another round" (:499-516) asks for getKeyframe(pkf->kfid_) -- the SAME keyframe -- and inserts its ids again: no effect
+    }
+    last_.n_local = (int)frame.set_local_mapids_.size();
+    std::map<int, int> map_previd_newid;
+    const ov2_status s = matchToMap(frame, pslamstate_->fmax_proj_pxdist_, pslamstate_->fmax_desc_dist_, frame.set_local_mapids_, map_previd_newid);
+    if (s != OV2_OK) return s;
+    last_.n_matched = (int)map_previd_newid.size();
+    for (const auto &ids : map_previd_newid) pmap_->mergeMapPoints(ids.first, ids.second);   // Mapper::mergeMatches (:556-574)
+    return OV2_OK;
+}
+
+ov2_status SlamManager::matchToMap(const Frame &frame, float fmaxprojerr, float fdistratio, std::unordered_set<int> &set_local_lmids,
+                                   std::map<int, int> &map_previd_newid)
+{   // src/mapper.cpp:576-774 on flat arrays (ov2_match_input): this function lists what the reference's loops look at -- the frame's
+    // keypoints with the descriptor sets / observers / pixels of their map points, the local map points that pass the
+    // tests made before the projection (:613-624), the keyframe poses -- and ov2_match_to_map does the rest
+    if (set_local_lmids.empty()) return OV2_OK;
+    // keypoints: every keypoint of the frame (kp.lmid_ >= 0 always here), in grid order so that the cells list them contiguously
+    std::vector<int> kp_lmid; std::unordered_map<int, int> kp_index;
+    std::vector<int32_t> grid_ptr(1, 0), grid_kp;
+    for (const auto &cell : frame.vgridkps_) {
+        for (int lmid : cell) {
+            auto it = frame.mapkps_.find(lmid);
+            if (it == frame.mapkps_.end()) continue;
+            kp_index.emplace(lmid, (int)kp_lmid.size());
+            grid_kp.push_back((int32_t)kp_lmid.size());
+            kp_lmid.push_back(lmid);
+        }
+        grid_ptr.push_back((int32_t)grid_kp.size());
+    }
+    const int n_kp = (int)kp_lmid.size();
+    if (n_kp == 0) return OV2_OK;
+    int max_kf = frame.kfid_;
+    std::vector<float> kp_px(2 * (size_t)n_kp), kp_kf_px;
+    std::vector<int32_t> kp_desc_ptr(1, 0), kp_kf_ptr(1, 0), kp_kfids;
+    std::vector<uint8_t> kp_descs;
+    for (int k = 0; k < n_kp; ++k) {
+        const Keypoint &kp = frame.mapkps_.at(kp_lmid[k]);
+        kp_px[2 * k] = kp.px_.x; kp_px[2 * k + 1] = kp.px_.y;
+        auto pkplm = pmap_->getMapPoint(kp.lmid_);
+        if (pkplm && pkplm->has_desc_) {   // (a keypoint whose map point is gone or has no descriptor offers nothing: :676-685)
+            for (const auto &kd : pkplm->map_kf_desc_) kp_descs.insert(kp_descs.end(), kd.second.begin(), kd.second.end());
+            for (int kfid : pkplm->getKfObsSet()) {
+                auto pcokf = pmap_->getKeyframe(kfid);
+                const Keypoint cokp = pcokf ? pcokf->getKeypointById(kp.lmid_) : Keypoint();
+                if (cokp.lmid_ != kp.lmid_) continue;   // (:706-713 removes such a stale observation; it cannot arise through this class)
+                kp_kfids.push_back(kfid); kp_kf_px.push_back(cokp.px_.x); kp_kf_px.push_back(cokp.px_.y);
+                max_kf = std::max(max_kf, kfid);
+            }
+        }
+        kp_desc_ptr.push_back((int32_t)(kp_descs.size() / 32));
+        kp_kf_ptr.push_back((int32_t)kp_kfids.size());
+    }
+    // candidates, in the iteration order of the set (it decides ties between candidates of one keypoint: :754-771)
+    std::vector<int> cand_lmid;
+    std::vector<double> cand_wpt;
+    std::vector<int32_t> cand_desc_ptr(1, 0), cand_kf_ptr(1, 0), cand_kfids;
+    std::vector<uint8_t> cand_descs;
+    for (const int lmid : set_local_lmids) {
+        if (frame.isObservingKp(lmid)) continue;
+        auto plm = pmap_->getMapPoint(lmid);
+        if (!plm || !plm->is3d_ || !plm->has_desc_) continue;
+        const Vec3 w = plm->getPoint();
+        cand_lmid.push_back(lmid);
+        cand_wpt.push_back(w.x); cand_wpt.push_back(w.y); cand_wpt.push_back(w.z);
+        for (const auto &kd : plm->map_kf_desc_) cand_descs.insert(cand_descs.end(), kd.second.begin(), kd.second.end());
+        for (int kfid : plm->getKfObsSet()) { cand_kfids.push_back(kfid); max_kf = std::max(max_kf, kfid); }
+        cand_desc_ptr.push_back((int32_t)(cand_descs.size() / 32));
+        cand_kf_ptr.push_back((int32_t)cand_kfids.size());
+    }
+    if (cand_lmid.empty()) return OV2_OK;
+    std::vector<double> kf_Twc(7 * (size_t)(max_kf + 1), 0.0);
+    for (int k = 0; k <= max_kf; ++k) {
+        auto pkf = pmap_->getKeyframe(k);
+        const SE3 T = pkf ? pkf->getTwc() : SE3();
+        for (int i = 0; i < 7; ++i) kf_Twc[7 * (size_t)k + i] = T.v[i];
+    }
+    const CameraCalibration &c = *frame.pcalib_leftcam_;
+    ov2_match_input in;
+    memset(&in, 0, sizeof(in));
+    const SE3 Twc = frame.getTwc();
+    for (int i = 0; i < 7; ++i) in.Twc[i] = Twc.v[i];
+    in.K[0] = c.fx_; in.K[1] = c.fy_; in.K[2] = c.cx_; in.K[3] = c.cy_;
+    in.img_w = c.img_w_; in.img_h = c.img_h_; in.cell = (int32_t)frame.ncellsize_; in.nb3dkps = (int32_t)frame.nb3dkps_;
+    in.n_kp = n_kp; in.kp_px = kp_px.data(); in.kp_desc_ptr = kp_desc_ptr.data(); in.kp_descs = kp_descs.data();
+    in.kp_kf_ptr = kp_kf_ptr.data(); in.kp_kfids = kp_kfids.data(); in.kp_kf_px = kp_kf_px.data();
+    in.grid_ptr = grid_ptr.data(); in.grid_kp = grid_kp.data();
+    in.n_cand = (int32_t)cand_lmid.size(); in.cand_wpt = cand_wpt.data(); in.cand_desc_ptr = cand_desc_ptr.data(); in.cand_descs = cand_descs.data();
+    in.cand_kf_ptr = cand_kf_ptr.data(); in.cand_kfids = cand_kfids.data();
+    in.n_kf = max_kf + 1; in.kf_Twc = kf_Twc.data();
+    ov2_cam_model cam;
+    const bool dist = c.fillCamModel(&cam);
+    in.cam = dist ? &cam : nullptr;
+    std::vector<int32_t> match_cand((size_t)n_kp, -1);
+    std::vector<float> match_dist((size_t)n_kp, 0.f);
+    const ov2_status s = ov2_match_to_map(ctx_, &in, fmaxprojerr, fdistratio, match_cand.data(), match_dist.data());
+    if (s != OV2_OK) return s;
+    for (int k = 0; k < n_kp; ++k)
+        if (match_cand[k] >= 0) map_previd_newid.emplace(kp_lmid[k], cand_lmid[match_cand[k]]);
+    return OV2_OK;
 }
 
 ov2_status SlamManager::triangulateStereo(Frame &frame)

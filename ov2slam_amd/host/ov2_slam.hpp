@@ -50,6 +50,7 @@ struct Keyframe {   // include/mapper.hpp:39-85: what the front-end hands to the
 struct SlamStats {   // per frame, for tests / profiles
     int frame = 0, tracked = 0, n3d = 0, is_kf = 0, n_new = 0, n_stereo = 0, n_lm3d = 0;
     int ba_done = 0, ba_res = 0, ba_it_robust = 0, ba_it_l2 = 0, ba_outliers = 0;
+    int n_described = 0, n_local = 0, n_matched = 0;   // keyframe: keypoints with a descriptor, local map points offered, merges
     double ba_cost0 = 0., ba_cost1 = 0.;
 };
 
@@ -60,6 +61,11 @@ public:
     // one stereo frame through visualTracking and, when it asks for a keyframe, Mapper::run + Estimator::applyLocalBA
     ov2_status addNewStereoImages(double time, const uint8_t *im0, const uint8_t *im1, int w, int h, int stride);
     SE3 pose() const { return pcurframe_->getTwc(); }
+    // the 256 test pairs of BRIEF-32 (y1, x1, y2, x2 per test, int8: opencv_contrib's generated_32.i, absent from the reference
+    // tree, so the caller supplies it) -- with use_brief_ the keyframe path describes its keypoints and runs
+    // Mapper::matchingToLocalMap (src/mapper.cpp:469-554)
+    void setBriefPattern(const int8_t *pattern256x4) { brief_pattern_.assign(pattern256x4, pattern256x4 + 1024); }
+    std::vector<int8_t> brief_pattern_;
 
     ov2_ctx *ctx_;
     std::shared_ptr<SlamParams> pslamstate_;
@@ -86,6 +92,14 @@ private:
     void prepareFrame();
     ov2_status extractKeypoints();
     void addKeypointsToFrame(const std::vector<Point2f> &vpts, Frame &frame);
+    void addKeypointsToFrame(const std::vector<Point2f> &vpts, const std::vector<Desc> &vdescs, const std::vector<uint8_t> &valid, Frame &frame);
+    ov2_status describeBRIEF(const std::vector<Point2f> &vpts, std::vector<Desc> &vdescs, std::vector<uint8_t> &valid);   // src/feature_extractor.cpp:224-285
+    ov2_status describeKeypoints(const std::vector<Keypoint> &vkps, const std::vector<Point2f> &vpts);                   // src/map_manager.cpp:343-362
+    ov2_status matchingToLocalMap(Frame &frame);                                                        // src/mapper.cpp:469-554
+    ov2_status matchToMap(const Frame &frame, float fmaxprojerr, float fdistratio, std::unordered_set<int> &set_local_lmids,
+                          std::map<int, int> &map_previd_newid);                                        // :576-774 -> ov2_match_to_map
+    Pyramid raw_pyr_;        // level 0 of the raw left image (describeBRIEF works on imraw, src/map_manager.cpp:300, 325)
+    const uint8_t *imraw_ = nullptr; int imw_ = 0, imh_ = 0, imstride_ = 0;
     void addKeyframe();
     ov2_status mapperRun(const Keyframe &kf);                                                          // src/mapper.cpp:38-189
     ov2_status triangulateStereo(Frame &frame);                                                        // :346-461

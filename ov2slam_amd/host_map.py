@@ -58,6 +58,32 @@ def lib():
         L.ov2h_ba_worker_destroy.argtypes = [C.c_void_p]
         L.ov2h_ba_worker_destroy.restype = None
         L.ov2h_ba_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, ip, dp, C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.ov2h_slam_set_brief.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.ov2h_slam_set_brief.restype = None
+        L.ov2h_slam_kf_stats.argtypes = [C.c_void_p, dp]
+        L.ov2h_slam_kf_stats.restype = None
+        L.ov2h_slam_device_handle.argtypes = [C.c_void_p]
+        L.ov2h_slam_device_handle.restype = C.c_void_p
+        L.ov2h_slam_flush_device.argtypes = [C.c_void_p]
+        L.ov2h_slam_check_map.argtypes = [C.c_void_p, ip]
+        L.ov2h_slam_export_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp, ip, dp, u8, ip, ip, u8]
+        L.ov2h_slam_export_map.restype = None
+        L.ov2h_mp_new.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ov2h_mp_new.restype = C.c_void_p
+        L.ov2h_mp_add_obs.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_mp_add_obs.restype = None
+        L.ov2h_mp_add_desc.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ov2h_mp_add_desc.restype = None
+        L.ov2h_mp_remove_obs.argtypes = [C.c_void_p, C.c_int]
+        L.ov2h_mp_remove_obs.restype = None
+        L.ov2h_mp_state.argtypes = [C.c_void_p, ip, u8, C.c_int, ip, C.POINTER(C.c_float)]
+        L.ov2h_mp_free.argtypes = [C.c_void_p]
+        L.ov2h_mp_free.restype = None
+        L.ov2h_feloop_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.ov2h_feloop_create.restype = C.c_void_p
+        L.ov2h_feloop_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, ip]
+        L.ov2h_feloop_destroy.argtypes = [C.c_void_p]
+        L.ov2h_feloop_destroy.restype = None
         L.ov2h_ba_pipeline_create.restype = C.c_void_p
         for fn in (L.ov2h_ba_pipeline_submit_all, L.ov2h_ba_pipeline_destroy):
             fn.argtypes, fn.restype = [C.c_void_p], None
@@ -371,7 +397,50 @@ class CppSlam:
         lib().ov2h_slam_stats(self.h_, _dp(s))
         self.traj.append(T)
         self.stats.append(dict(zip(self.STAT_KEYS, s.tolist())))
+        if getattr(self, "kf_stats", None) is not None and self.stats[-1]["kf"]:
+            k = np.zeros(3)
+            lib().ov2h_slam_kf_stats(self.h_, _dp(k))
+            self.kf_stats.append(dict(frame=int(self.stats[-1]["frame"]), described=int(k[0]), local=int(k[1]), matched=int(k[2])))
         return T
+
+    def set_brief(self, pattern, use_brief=True, track_localmap=True, fmax_desc_dist=0.0, fmax_proj_pxdist=0.0):
+        """use_brief / bdo_track_localmap of the YAML: keyframes describe their keypoints (BRIEF-32 with the caller's 256 x 4 int8
+        test table -- opencv_contrib's is not in the reference tree) and run Mapper::matchingToLocalMap + mergeMapPoints"""
+        pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8).reshape(256, 4)
+        lib().ov2h_slam_set_brief(self.h_, None if pat is None else pat.ctypes.data, int(bool(use_brief)), int(bool(track_localmap)),
+                                  float(fmax_desc_dist), float(fmax_proj_pxdist))
+        self.kf_stats = []
+
+    def check_map(self):
+        """(violations of the host map's invariants, total) -- see ov2h_slam_check_map"""
+        v = np.zeros(6, np.int32)
+        tot = lib().ov2h_slam_check_map(self.h_, v.ctypes.data_as(C.POINTER(C.c_int)))
+        return dict(zip(("kp_without_mp", "kp_not_listed", "observer_without_kp", "covisibility", "mp3d_without_desc", "desc_without_observer"),
+                        v.tolist())), int(tot)
+
+    def export_map(self, cap_kf=4096, cap_lm=1 << 18, cap_obs=1 << 20):
+        """the host map keyed by ids: ({kfid: pose}, {lmid: (xyz, state bits)}, {(kfid, lmid): stereo})"""
+        ip, u8 = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+        n = np.zeros(3, np.int32)
+        kf_id, kf_pose = np.zeros(cap_kf, np.int32), np.zeros((cap_kf, 7))
+        lm_id, lm_xyz, lm_st = np.zeros(cap_lm, np.int32), np.zeros((cap_lm, 3)), np.zeros(cap_lm, np.uint8)
+        ok, ol, os_ = np.zeros(cap_obs, np.int32), np.zeros(cap_obs, np.int32), np.zeros(cap_obs, np.uint8)
+        lib().ov2h_slam_export_map(self.h_, cap_kf, cap_lm, cap_obs, n.ctypes.data_as(ip), kf_id.ctypes.data_as(ip), _dp(kf_pose),
+                                   lm_id.ctypes.data_as(ip), _dp(lm_xyz), lm_st.ctypes.data_as(u8), ok.ctypes.data_as(ip),
+                                   ol.ctypes.data_as(ip), os_.ctypes.data_as(u8))
+        assert n[0] <= cap_kf and n[1] <= cap_lm and n[2] <= cap_obs
+        kfs = {int(k): tuple(p) for k, p in zip(kf_id[:n[0]], kf_pose[:n[0]])}
+        lms = {int(l): (tuple(x), int(s)) for l, x, s in zip(lm_id[:n[1]], lm_xyz[:n[1]], lm_st[:n[1]])}
+        obs = {(int(k), int(l)): int(s) for k, l, s in zip(ok[:n[2]], ol[:n[2]], os_[:n[2]])}
+        return kfs, lms, obs
+
+    def device_handle(self):
+        return lib().ov2h_slam_device_handle(self.h_)
+
+    def flush_device(self):
+        st = lib().ov2h_slam_flush_device(self.h_)
+        if st != 0:
+            raise RuntimeError(f"MapManager::flushDevice failed ({st})")
 
     def landmarks(self, cap=1 << 16):
         ids, xyz = np.zeros(cap, np.int32), np.zeros((cap, 3))
@@ -423,6 +492,68 @@ class EstimatorPipeline:
     def close(self):
         if getattr(self, "h", None):
             lib().ov2h_ba_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class _FeLoopCfg(C.Structure):   # ov2h_feloop_cfg (host/ov2_host_capi.cpp)
+    _fields_ = [(k, C.c_int32) for k in ("L", "B", "n", "win", "nlvl", "use_clahe", "tiles_x", "tiles_y")] + \
+               [(k, C.c_float) for k in ("clahe_clip", "err_th", "fb_th", "eps")] + \
+               [(k, C.c_int32) for k in ("max_iter", "detect", "det_cell", "det_ncur", "det_cap", "pnp")] + \
+               [(k, C.c_void_p) for k in ("left", "right", "kps", "pri", "st_pri", "has", "st_has", "img_idx", "out_xy", "out_st", "p3p",
+                                          "pnp_off", "pnp_unpx", "pnp_wpts", "pnp_K", "pnp_T0", "pnp_T", "pnp_outl", "pnp_rem", "pnp_ok")] + \
+               [("pnp_T_bytes", C.c_uint64)] + \
+               [(k, C.c_void_p) for k in ("det_thresh", "det_cur", "det_img", "det_nout", "det_out")]
+
+
+class FrameLoop:
+    """native per-frame driver of a bench Workload (bench.py): the same sequence of ABI calls as Workload.step -- pyramid,
+    kltTracking, ceresPnP; right pyramid, stereoMatching, detector and a job for every Estimator pipeline on keyframes --
+    enqueued from C++ (ov2h_feloop_run), so that small streams are not bound by ~15 us of interpreter per call.  Holds
+    references to the workload's device arrays; everything stays asynchronous."""
+
+    def __init__(self, ctx, wl, win, nlvl, tiles, pipelines=()):
+        self.ctx, self.wl = ctx, wl
+        L = wl.L
+        arr = lambda xs: (C.c_void_p * L)(*xs)
+        self._keep = dict(left=arr([i.h_ for i in wl.left]), right=arr([i.h_ for i in wl.right]),
+                          kps=arr([a.ptr for a in wl.kps]), pri=arr([a.ptr for a in wl.pri]), st_pri=arr([a.ptr for a in wl.st_pri]),
+                          has=arr([a.ptr for a in wl.has]), st_has=arr([a.ptr for a in wl.st_has]))
+        c = _FeLoopCfg()
+        c.L, c.B, c.n, c.win, c.nlvl, c.use_clahe, c.tiles_x, c.tiles_y = L, wl.B, wl.n, win, nlvl, 1, tiles[0], tiles[1]
+        c.clahe_clip, c.err_th, c.fb_th, c.eps, c.max_iter = 3.0, 30.0, 0.5, wl.trk.fmax_px_precision, wl.trk.nmax_iter
+        c.detect, c.det_cell, c.det_ncur, c.det_cap = int(bool(wl.detect)), wl.det_cell, wl.det_ncur, wl.det_cap
+        for k, v in self._keep.items():
+            setattr(c, k, C.cast(v, C.c_void_p))
+        c.img_idx, c.out_xy, c.out_st, c.p3p = wl.img_idx.ptr, wl.out_xy.ptr, wl.out_st.ptr, wl.p3p.ptr
+        c.det_thresh, c.det_cur, c.det_img = wl.d_det_thresh.ptr, wl.d_det_cur.ptr, wl.d_det_img.ptr
+        c.det_nout, c.det_out = wl.d_det_nout.ptr, wl.d_det_out.ptr
+        if wl.pnp:
+            q = wl.pnp
+            c.pnp = 1
+            c.pnp_off, c.pnp_unpx, c.pnp_wpts, c.pnp_K = q["off"].ptr, q["unpx"].ptr, q["wpts"].ptr, q["K"].ptr
+            c.pnp_T0, c.pnp_T, c.pnp_T_bytes = q["T0"].ptr, q["T"].ptr, q["T"].nbytes
+            c.pnp_outl, c.pnp_rem, c.pnp_ok = q["outl"].ptr, q["rem"].ptr, q["ok"].ptr
+        self.cfg = c
+        self.pipes = (C.c_void_p * max(1, len(pipelines)))(*[p.h for p in pipelines])
+        self.n_pipes = len(pipelines)
+        self.h = lib().ov2h_feloop_create(ctx.h, C.addressof(c))
+        if not self.h:
+            raise RuntimeError("ov2h_feloop_create failed")
+
+    def run(self, steps, kf_every):
+        """enqueue `steps` frames; returns the number of keyframes among them"""
+        nk = C.c_int(0)
+        st = lib().ov2h_feloop_run(self.h, int(steps), int(kf_every), self.pipes, self.n_pipes, C.byref(nk))
+        if st != 0:
+            raise RuntimeError(f"ov2h_feloop_run: status {st}: {self.ctx.lib.ov2_last_error(self.ctx.h).decode()}")
+        return nk.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ov2h_feloop_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -16,14 +16,22 @@ ctx = fe.Context(0)
 out = {"frames": n, "scene": "textured plane, 752x480 rectified stereo, ~2 cm / frame", "keypoints_per_frame": "<= 308 (cell 35)"}
 
 
-def run_cpp(policy, device_map):
+def run_cpp(policy, device_map, brief=False):
     cl = host_map.CppSlam(ctx, sc.K4, sc.BASELINE, sc.W, sc.H, policy=policy, device_map=device_map)
-    per = []
+    if brief:   # use_brief + bdo_track_localmap (the reference's YAML defaults); the BRIEF test table is a stand-in for opencv_contrib's
+        from ov2slam_amd import mapper
+        cl.set_brief(mapper.random_brief_pattern(3))
+    per, extra = [], {}
     try:
         for t in range(n):
             t1 = time.perf_counter()
             cl.step(0.05 * t, L[t], R[t])
             per.append(time.perf_counter() - t1)
+        if brief:
+            inv, _ = cl.check_map()
+            extra = dict(map_matching=dict(keyframes=len(cl.kf_stats), described_per_keyframe_mean=float(np.mean([k["described"] for k in cl.kf_stats])),
+                                           local_map_points_offered_mean=float(np.mean([k["local"] for k in cl.kf_stats])),
+                                           merges_total=int(sum(k["matched"] for k in cl.kf_stats)), map_invariant_violations=inv))
     finally:
         cl.close()
     per = np.array(per)
@@ -32,11 +40,12 @@ def run_cpp(policy, device_map):
     return dict(ms_per_frame_mean=1e3 * float(per[warm].mean()), ms_per_frame_median=1e3 * float(np.median(per[warm])),
                 ms_per_non_keyframe_median=1e3 * float(np.median(per[warm & ~kf])), ms_per_keyframe_median=1e3 * float(np.median(per[warm & kf])),
                 keyframes=int(kf.sum()), local_bas=int(sum(int(s["ba"]) for s in cl.stats)),
-                tracked_mean=float(np.mean([s["tracked"] for s in cl.stats[1:]])), ate_rmse_m=slam_loop.ate_rmse(cl.traj, gt)), cl
+                tracked_mean=float(np.mean([s["tracked"] for s in cl.stats[1:]])), ate_rmse_m=slam_loop.ate_rmse(cl.traj, gt), **extra), cl
 
 
 out["cpp_slam_loop_policy"], c1 = run_cpp("slam_loop", False)
 out["cpp_reference_policies"], c2 = run_cpp(None, True)
+out["cpp_reference_policies_with_brief_and_local_map_matching"], c3 = run_cpp(None, True, brief=True)
 pl = slam_loop.SlamLoop(slam_loop.HipBackend(ctx), sc.K4, sc.BASELINE, sc.W, sc.H)
 per = []
 for t in range(n):

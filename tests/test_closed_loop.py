@@ -97,3 +97,53 @@ def test_cpp_loop_with_the_reference_policies_follows_ground_truth(ctx, scene):
     assert sum(int(s["kf"]) for s in cl.stats) >= 3 and sum(int(s["ba"]) for s in cl.stats) >= 2
     assert all(s["tracked"] > 150 for s in cl.stats[1:])
     assert len(ids) > 200 and np.median(np.abs(xyz @ scene.nrm - scene.d)) < 0.05
+
+
+class _DevHandle:
+    """a borrowed ov2_map* with DeviceMap's download()"""
+
+    def __init__(self, ctx, h):
+        from ov2slam_amd import device_map as DM
+        self.ctx, self.L, self.h = ctx, ctx.lib, h
+        self._p = DM.DeviceMap._p
+        self.download = lambda: DM.DeviceMap.download(self)
+
+
+@pytest.mark.gpu
+def test_cpp_loop_with_brief_matches_lost_points_back_into_the_map(ctx, scene):
+    """use_brief / bdo_track_localmap (on in every parameter file of the reference): keyframes describe their keypoints (BRIEF
+    with a caller-supplied test table) and Mapper::matchingToLocalMap merges re-detected points into the map points they
+    duplicate (MapManager::mergeMapPoints).  A grey band painted over two frames makes the tracker lose a stripe of
+    keypoints; the next keyframes re-detect the stripe, and the old map points -- still in the local map of the covisible
+    keyframes -- must take the new observations over.  Checked: merges happen, the host map keeps its invariants (every
+    observation two-sided, descriptors only from observers), the device mirror equals the host map after the edits
+    (a merged observation = a dead row + an appended one), and the trajectory stays on the ground truth."""
+    from ov2slam_amd import device_map as DM, host_map, mapper
+    n = 40
+    cl = host_map.CppSlam(ctx, synth_scene.K4, synth_scene.BASELINE, synth_scene.W, synth_scene.H, policy="slam_loop", kf_every=5,
+                          ba_window=0, device_map=True)
+    cl.set_brief(mapper.random_brief_pattern(3))
+    try:
+        for t in range(n):
+            il, ir = scene.left(t).copy(), scene.right(t).copy()
+            if t in (11, 12, 13):
+                il[:, 300:460] = 128
+            cl.step(0.05 * t, il, ir)
+        inv, total = cl.check_map()
+        host = cl.export_map()
+        cl.flush_device()
+        dev = DM.canonical_state(_DevHandle(ctx, cl.device_handle()).download())
+    finally:
+        cl.close()
+    ks = cl.kf_stats
+    assert len(ks) == 8 and all(k["described"] > 100 for k in ks) and all(k["local"] > 0 for k in ks[2:])
+    assert sum(k["matched"] for k in ks) >= 10, ks
+    assert inv["kp_without_mp"] == inv["kp_not_listed"] == inv["observer_without_kp"] == inv["desc_without_observer"] == 0, inv
+    gt = [scene.pose(t) for t in range(n)]
+    assert slam_loop.ate_rmse(cl.traj, gt) < 0.01
+    kf_h, lm_h, ob_h = host
+    kf_d, lm_d, ob_d = dev
+    assert sorted(kf_h) == sorted(kf_d) and all(np.allclose(kf_h[k], kf_d[k], atol=1e-12) for k in kf_h)
+    assert sorted(lm_h) == sorted(lm_d)
+    assert set(ob_h) == set(ob_d)
+    assert all(bool(ob_h[o]) == bool(ob_d[o]) for o in ob_h)

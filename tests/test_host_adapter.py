@@ -413,3 +413,159 @@ def test_camera_distortion_models(model, D):
     # no coefficients: identity / plain pinhole
     hm.set_distortion(0, "pinhole", [])
     assert np.array_equal(hm.undistort(0, 100.25, 50.5), np.array([100.25, 50.5], np.float32))
+
+
+@pytest.mark.gpu
+def test_native_frame_loop_equals_the_interpreter_loop():
+    """ov2h_feloop_run (the bench's native per-frame driver) issues the same ABI calls as bench.Workload.step: after the
+    same number of frames the tracked positions, status bytes, PnP poses and detector output are identical"""
+    import bench
+    from ov2slam_amd import frontend as fe, host_map, synth
+    ctx = fe.Context(0)
+    try:
+        outs = []
+        for native in (False, True):
+            wl = bench.Workload(ctx, fe, synth, 2, 308, 4, seed=synth.SEED_IMG + 5, det_cell=35)
+            wl.enable_pnp(seed=99)
+            steps, kf_every = 11, 4
+            if native:
+                loop = host_map.FrameLoop(ctx, wl, bench.WIN, bench.NLVL, fe.clahe_tiles(bench.W, bench.H))
+                assert loop.run(steps, kf_every) == 3
+                loop.close()
+            else:
+                assert sum(bool(wl.step(kf_every)) for _ in range(steps)) == 3
+                wl.prev.release(); wl.prev = None
+            ctx.synchronize()
+            outs.append((wl.out_xy.get().copy(), wl.out_st.get().copy(), wl.pnp["T"].get().copy(), wl.d_det_nout.get().copy(),
+                         wl.d_det_out.get().copy(), wl.d_det_thresh.get().copy()))
+            del wl
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        assert outs[0][1].mean() > 0.9 and outs[0][3].min() > 0
+    finally:
+        ctx.close()
+
+
+class _MapPointRef:
+    """MapPoint's observer / descriptor bookkeeping restated from src/map_point.cpp:106-211 on python dicts.  The reference walks
+    std::unordered_maps whose order decides ties between equal distances; this model records every tie it meets instead, so the
+    test can accept any of the tied winners."""
+
+    def __init__(self, kfid, desc):
+        self.kfs, self.anchor = {kfid}, kfid
+        self.descs, self.dist = {}, {}
+        self.rep, self.ties = None, set()
+        if desc is not None:
+            self.descs[kfid], self.dist[kfid], self.rep = desc, 0.0, desc
+
+    @staticmethod
+    def ham(a, b):
+        return float(np.unpackbits(a ^ b).sum())
+
+    def _pick(self, cands):   # cands: (value, kfid) compared with strict '<' in some iteration order: any minimal one can win
+        best = min(v for v, _ in cands)
+        return {k for v, k in cands if v == best}, best
+
+    def add_desc(self, kfid, d):
+        if kfid in self.descs:
+            return
+        self.descs[kfid], self.dist[kfid] = d, 0.0
+        if len(self.descs) == 1:
+            self.rep, self.ties = d, {kfid}
+            return
+        mindist = 256.0 if self.rep is not None else 0.0
+        cands = []
+        for k, dk in self.descs.items():
+            dist = self.ham(d, dk)
+            self.dist[k] += dist
+            if k != kfid:
+                self.dist[kfid] += dist
+            cands.append((dist, k))
+        win, best = self._pick([c for c in cands if c[0] < mindist]) if any(c[0] < mindist for c in cands) else (set(), mindist)
+        # the loop includes the new descriptor itself at distance 0, so `best` is 0 and the new one leads unless a twin exists
+        if self.dist[kfid] < best:
+            win = {kfid}
+        self.ties = win
+        self.rep = None   # resolved by the caller from the C++ answer (must be one of `ties`)
+
+    def remove_obs(self, kfid):
+        if kfid not in self.kfs:
+            return
+        self.kfs.discard(kfid)
+        if not self.kfs:
+            self.rep, self.descs, self.dist, self.ties = None, {}, {}, set()
+            return
+        if kfid == self.anchor:
+            self.anchor = min(self.kfs)
+        self.ties = None   # None = "unchanged"
+        if kfid in self.descs:
+            mindist = 256.0 if self.rep is not None else 0.0
+            cands = []
+            for k, dk in self.descs.items():
+                if k == kfid:
+                    continue
+                self.dist[k] -= self.ham(self.descs[kfid], dk)
+                if self.dist[k] < mindist:
+                    cands.append((self.dist[k], k))
+            del self.descs[kfid], self.dist[kfid]
+            if cands:
+                win, _ = self._pick(cands)
+                # minid > 0: keyframe 0 is never taken; with ties the winner depends on the walk, so 0 among them = "either"
+                self.ties = {k for k in win if k > 0} | ({None} if 0 in win else set())
+
+
+def test_map_point_descriptor_bookkeeping_follows_the_reference():
+    """MapPoint::addDesc / removeKfObs of the host mirror (anchor hand-over, per-keyframe descriptors, summed distances,
+    representative descriptor) against the restatement above, over random add / remove sequences incl. twins and ties"""
+    import ctypes as C
+    from ov2slam_amd import host_map
+    L = host_map.lib()
+    rng = np.random.default_rng(12)
+    ip, u8p, fp = C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+
+    def state(m):
+        oi, desc, k, f = np.zeros(4, np.int32), np.zeros(32, np.uint8), np.zeros(64, np.int32), np.zeros(64, np.float32)
+        n = L.ov2h_mp_state(m, oi.ctypes.data_as(ip), desc.ctypes.data_as(u8p), 64, k.ctypes.data_as(ip), f.ctypes.data_as(fp))
+        return oi, desc, dict(zip(k[:n].tolist(), f[:n].tolist()))
+
+    changed = 0
+    for trial in range(60):
+        pool = [rng.integers(0, 256, 32, dtype=np.uint8) for _ in range(4)]   # few distinct descriptors: twins and ties occur
+        mk = lambda: (pool[rng.integers(4)] ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 2, 32, dtype=np.uint8) * rng.integers(0, 4))).astype(np.uint8)
+        k0 = int(rng.integers(0, 3))
+        d0 = mk() if rng.uniform() < 0.8 else None
+        m = L.ov2h_mp_new(7, k0, None if d0 is None else d0.ctypes.data)
+        ref = _MapPointRef(k0, d0)
+        rep = d0
+        try:
+            for step in range(25):
+                if rng.uniform() < 0.6 or len(ref.kfs) < 2:
+                    kf = int(rng.integers(0, 12))
+                    d = mk()
+                    L.ov2h_mp_add_obs(m, kf)
+                    ref.kfs.add(kf)
+                    if rng.uniform() < 0.85:
+                        L.ov2h_mp_add_desc(m, kf, d.ctypes.data)
+                        ref.add_desc(kf, d)
+                else:
+                    kf = int(rng.choice(sorted(ref.kfs)))
+                    L.ov2h_mp_remove_obs(m, kf)
+                    ref.remove_obs(kf)
+                oi, desc, dist = state(m)
+                assert oi[2] == len(ref.kfs) and oi[3] == len(ref.descs), (trial, step)
+                if ref.kfs:
+                    assert oi[1] == ref.anchor, (trial, step)
+                assert sorted(dist) == sorted(ref.dist) and all(abs(dist[k] - ref.dist[k]) < 1e-3 for k in dist), (trial, step)
+                if not ref.descs:
+                    continue   # (after the last observer left the reference releases desc_; with observers but no descriptor it keeps the old one)
+                if ref.ties is None or not ref.ties:
+                    assert rep is not None and np.array_equal(desc, rep), (trial, step)   # unchanged
+                else:
+                    ok = [np.array_equal(desc, ref.descs[k]) for k in ref.ties if k is not None and k in ref.descs]
+                    assert any(ok) or (None in ref.ties and np.array_equal(desc, rep)), (trial, step, ref.ties)
+                    changed += 1
+                rep = desc.copy()
+                ref.rep = rep
+        finally:
+            L.ov2h_mp_free(m)
+    assert changed > 100
