@@ -160,3 +160,29 @@ def test_stereo_gate_undistorts_the_right_pixel(ctx, oracle, stream, pair, model
     assert st.sum() > 0.5 * n
     if rectified:
         assert (nod != st).sum() > 20, "the lens model made no difference to the gate"
+
+
+def test_stereo_matching_edge_cases(ctx, oracle, stream, pair):
+    """an empty call; a call in which no keypoint has a 2-level prior (everything goes to the full pyramid); keypoints on
+    the image border and priors far outside the image: status / positions still identical to the oracle, nothing faults"""
+    gl, gr, ol, orr = pair
+    trk = fe.FeatureTracker(ctx, 30, 0.01)
+    out, st = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros(0, np.uint8))
+    assert out.shape == (0, 2) and st.shape == (0,)
+    W, H = 752, 480
+    kps = np.array([[0, 0], [W - 1, 0], [0, H - 1], [W - 1, H - 1], [4.5, 4.5], [W - 5.5, H - 5.5], [1, 240], [750, 240],
+                    [376, 1], [376, 478], [30.25, 30.75], [700.5, 20.5]], np.float32)
+    kps = np.concatenate([kps, synth.grid_keypoints(300, seed=77)]).astype(np.float32)
+    n = len(kps)
+    gt = stream.stereo_gt(kps).astype(np.float32)
+    cases = {"no_priors": (kps.copy(), np.zeros(n, np.uint8)),
+             "wild_priors": (gt + np.float32(1e4) * (np.arange(n)[:, None] % 3 - 1).astype(np.float32), np.ones(n, np.uint8)),
+             "true_priors": (gt, np.ones(n, np.uint8))}
+    for name, (pri, has) in cases.items():
+        for rect in (True, False):
+            out, st = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, pri, has, lunpx=kps, rectified=rect, F_rl=F_RL)
+            eo, es = oracle.stereo_matching(ol, orr, kps, pri, has, 9, 3, 30.0, 0.5, 30, 0.01, lunpx=kps, rectified=rect, F_rl=F_RL)
+            assert np.array_equal(st, es.astype(bool)), (name, rect)
+            assert np.array_equal(out[st].view(np.uint32), eo[st].view(np.uint32)), (name, rect)
+    out, st = trk.stereoMatching(gl, gr, 9, 3, 30.0, 0.5, kps, cases["true_priors"][0], cases["true_priors"][1], lunpx=kps, rectified=True)
+    assert st[12:].mean() > 0.8 and not st[:4].any()   # the four corners cannot be tracked (window leaves the image)
