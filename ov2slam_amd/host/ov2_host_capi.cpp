@@ -769,7 +769,7 @@ struct BaWorkerNative {
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> lk(mu);
-            last_status = s;
+            if (last_status == 0) last_status = s;   // sticky: a later good batch must not hide a failed one from stats()
             if (counted && counting && s == OV2_OK) {   // ... and finished inside it
                 ++batches;
                 for (size_t k = 0; k < nb; ++k) {
@@ -874,7 +874,7 @@ struct BaPipelineNative {
             if (s == OV2_OK) s = ov2_ctx_synchronize(ctx);
             const auto t3 = now();
             std::lock_guard<std::mutex> lk(mu);
-            last_status = s;
+            if (last_status == 0) last_status = s;   // sticky: a later good batch must not hide a failed one from stats()
             if (counted && counting && s == OV2_OK) {   // ... and finished inside it
                 ++batches;
                 int slowest = 0;
