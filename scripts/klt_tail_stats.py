@@ -20,6 +20,16 @@ for name, gap, sig in (("headline", 3, 1.0), ("hard", 9, 3.0)):
         if k:
             w = wl.work.get()[: wl.n]            # stage 1 (the long launch)
             its.append((w & 0xffff).astype(np.int64)); passes.append((w >> 16).astype(np.int64))
+    # would last frame's work predict this frame's?  group frame k's keypoints by their work in frame k - 1
+    for G in (20,):
+        r = []
+        for k in range(1, len(its)):
+            lv = (passes[k] > 0) & (passes[k - 1] > 0)
+            order = np.argsort(its[k - 1][lv], kind="stable")
+            v = its[k][lv][order]
+            v = v[: len(v) // G * G].reshape(-1, G)
+            r.append(v.max(1).mean() / v.mean())
+        print(f"   {name}: waves of {G} formed by the PREVIOUS frame's work: slowest / mean = {np.mean(r):.2f}")
     it, ps = np.concatenate(its), np.concatenate(passes)
     live = ps > 0
     print(f"{name}: {live.mean():.3f} of the keypoints tracked in stage 1; iterations per keypoint mean {it[live].mean():.2f}, "
