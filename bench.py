@@ -817,6 +817,19 @@ def main():
                     out["euroc_like"]["cpu_baseline"] = {"kind": "port", "by_threads": legs,
                                                          "note": "oracle/ C port of the OpenCV path on the same 308-keypoint stream (CLAHE + pyramid + "
                                                                  "two-stage KLT per frame, right pyramid + stereo KLT per keyframe; no PnP / BA)"}
+                    try:   # ... and the local BA of the same EuRoC-sized window on one host thread
+                        pe = eba.flat_problems(1)
+                        t3 = time.perf_counter()
+                        nso, itso = 0, 0
+                        while time.perf_counter() - t3 < 3.0:
+                            Rc = O.ba_solve(pe[0].copy())
+                            itso += sum(Rc.summary()["iterations"]); nso += 1
+                        dtb = time.perf_counter() - t3
+                        out["euroc_like"]["cpu_baseline"]["local_ba"] = {
+                            "solves_per_sec": nso / dtb, "lm_iterations_per_sec": itso / dtb, "cores": 1, "kind": "port",
+                            "sample": f"{nso} solves of the 1-sequence leg's window ({pe[0].n_res} residual blocks; solve stage only) in {dtb:.1f} s"}
+                    except Exception as e2:
+                        out["euroc_like"]["cpu_baseline"]["local_ba"] = {"error": repr(e2)}
                 del ew, eba
             except Exception as e:   # a side report: never lose the bench line to it
                 out["euroc_like"][f"{nseq}_seq"] = {"error": repr(e)}
