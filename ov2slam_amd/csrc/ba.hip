@@ -800,17 +800,36 @@ __device__ __forceinline__ void invert_ete(const double *ete, double *ie)
     }
 }
 
-// column norms + gradient of the landmark (E) columns: 16 lanes per landmark, no atomics
+// sum over the GW (8 | 16) lanes of a landmark group, result in all of them
+template <int GW>
+__device__ __forceinline__ double grp_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    if (GW == 16) v += dpp_f64<0x140>(v);   // row_mirror
+    return v;
+}
+
+#ifndef BS_LM_GW
+#define BS_LM_GW 8   // lanes per landmark in the landmark-major kernels (column norms, elimination, back-substitution): 12 rows / 7
+                     // cells per landmark are typical (six stereo observers + the anchor); with 16 lanes a wave carried four landmarks
+                     // and ~6 KB of traffic through its ~10 us of dependent loads (bs_landmark 311 -> 248 us with 8)
+#endif
+#define BS_LM_PER_WG (256 / BS_LM_GW)
+
+// column norms + gradient of the landmark (E) columns: GW lanes per landmark, no atomics
+template <int GW>
 __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
 {
     BA_WAVE_PRIO();
-    const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int l = blockIdx.x * (256 / GW) + (int)(threadIdx.x / GW), sub = threadIdx.x % GW;
     const bool live = l < d.n_e && win_runs(d.W[d.win_of_e[l]], mode);
     const int e = d.e;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     double se[3] = {0, 0, 0}, ge[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
     if (live) for (int c = 0; c < e; ++c) sc[c] = d.scale[l * e + c];
-    for (int base = r0; base < r1; base += 16) {
+    for (int base = r0; base < r1; base += GW) {
         const int r = base + sub;
         if (r < r1) {
             const double *Je = d.Je + (size_t)r * 2 * e;
@@ -821,7 +840,7 @@ __global__ __launch_bounds__(256) void ba_colnorm16_kernel(ba_dev d, int mode)
             }
         }
     }
-    for (int c = 0; c < e; ++c) { se[c] = row_sum(se[c]); ge[c] = row_sum(ge[c]); }
+    for (int c = 0; c < e; ++c) { se[c] = grp_sum<GW>(se[c]); ge[c] = grp_sum<GW>(ge[c]); }
     if (live && sub == 0)
         for (int c = 0; c < e; ++c) { d.sqn[l * e + c] = se[c]; d.grad[l * e + c] = ge[c]; }
 }
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int
 }
 
 // back-substitution + model cost change, 16 lanes per landmark
-template <int E>
+template <int E, int GW>
 __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__restrict__ part)
 {
     BA_WAVE_PRIO();
@@ -893,49 +912,64 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
         const int gi = blockIdx.x * 256 + threadIdx.x;
         if (gi < d.m) d.step[d.n_e * d.e + gi] = -d.rhs[gi];
     }
-    const int l = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int l = blockIdx.x * (256 / GW) + (int)(threadIdx.x / GW), sub = threadIdx.x % GW;
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
     double acc[E], se[E], wp[3];
     for (int i = 0; i < E; ++i) { acc[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
     for (int i = 0; i < 3; ++i) wp[i] = live ? d.wpt[(size_t)l * 3 + i] : 0.0;
-    for (int base = r0; base < r1; base += 16) {
+    // One row of the landmark: its jacobian entries scaled (je), residual (b) and p = F_row * step_poses, the part of J * step
+    // that comes from the row's pose and anchor-pose blocks.  The kernel needs p twice (E' (r + F z) for the landmark step,
+    // then J * step for the model cost): the first two trips of a group keep (je, b, p) in registers, so the second sweep
+    // re-reads nothing for landmarks of up to 2 GW rows -- before, it gathered the 24 (z, scale) values per row and the
+    // 48-byte block again (the kernel was bound by the number of gather instructions, not by bytes).
+    struct rowv { double je[2 * E], b0, b1, p0, p1; };
+    auto load_row = [&](int r, rowv &v) {
+        const double *Je = d.Je + (size_t)r * 2 * E;
+        double Uu[12];
+        load_U(d, (size_t)r, wp, Uu);
+        for (int i = 0; i < E; ++i) { v.je[i] = Je[i] * se[i]; v.je[E + i] = Je[E + i] * se[i]; }
+        v.b0 = d.res[2 * r]; v.b1 = d.res[2 * r + 1];
+        double p0 = 0.0, p1 = 0.0;
+        const int fk = d.fk[r], fa = d.fa[r];
+        if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; p0 -= (Uu[c] * sk) * z; p1 -= (Uu[6 + c] * sk) * z; }
+        if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c], sa = sf[fa * 6 + c]; p0 += (Uu[c] * sa) * z; p1 += (Uu[6 + c] * sa) * z; }
+        v.p0 = p0; v.p1 = p1;
+    };
+    auto sweep1 = [&](const rowv &v) {
+        const double sj0 = v.b0 + v.p0, sj1 = v.b1 + v.p1;
+        for (int i = 0; i < E; ++i) acc[i] += v.je[i] * sj0 + v.je[E + i] * sj1;
+    };
+    rowv c0, c1;
+    const bool in0 = r0 + sub < r1, in1 = r0 + GW + sub < r1;
+    if (in0) { load_row(r0 + sub, c0); sweep1(c0); }
+    if (in1) { load_row(r0 + GW + sub, c1); sweep1(c1); }
+    for (int base = r0 + 2 * GW; base < r1; base += GW) {
         const int r = base + sub;
-        if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E;
-            double Uu[12];
-            load_U(d, (size_t)r, wp, Uu);
-            double sj0 = d.res[2 * r], sj1 = d.res[2 * r + 1];
-            const int fk = d.fk[r], fa = d.fa[r];
-            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; sj0 -= (Uu[c] * sk) * z; sj1 -= (Uu[6 + c] * sk) * z; }
-            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c], sa = sf[fa * 6 + c]; sj0 += (Uu[c] * sa) * z; sj1 += (Uu[6 + c] * sa) * z; }
-            for (int i = 0; i < E; ++i) acc[i] += (Je[i] * se[i]) * sj0 + (Je[E + i] * se[i]) * sj1;
-        }
+        if (r < r1) { rowv v; load_row(r, v); sweep1(v); }
     }
     double y[E];
-    for (int i = 0; i < E; ++i) acc[i] = row_sum(acc[i]);
+    for (int i = 0; i < E; ++i) acc[i] = grp_sum<GW>(acc[i]);
     for (int i = 0; i < E; ++i) {
         double s = 0;
         for (int j = 0; j < E; ++j) s += (live ? d.iete[(size_t)l * E * E + i * E + j] : 0.0) * acc[j];
         y[i] = s;
     }
     double mc = 0.0;
-    for (int base = r0; base < r1; base += 16) {
+    auto sweep2 = [&](const rowv &v) {
+        double m0 = 0.0, m1 = 0.0;
+        for (int i = 0; i < E; ++i) { m0 -= v.je[i] * y[i]; m1 -= v.je[E + i] * y[i]; }
+        m0 += v.p0; m1 += v.p1;
+        mc += m0 * (v.b0 + m0 / 2.0) + m1 * (v.b1 + m1 / 2.0);
+    };
+    if (in0) sweep2(c0);
+    if (in1) sweep2(c1);
+    for (int base = r0 + 2 * GW; base < r1; base += GW) {
         const int r = base + sub;
-        if (r < r1) {
-            const double *Je = d.Je + (size_t)r * 2 * E;
-            double Uu[12];
-            load_U(d, (size_t)r, wp, Uu);
-            double m0 = 0.0, m1 = 0.0;
-            for (int i = 0; i < E; ++i) { m0 -= (Je[i] * se[i]) * y[i]; m1 -= (Je[E + i] * se[i]) * y[i]; }
-            const int fk = d.fk[r], fa = d.fa[r];
-            if (fk >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fk * 6 + c], sk = sf[fk * 6 + c]; m0 -= (Uu[c] * sk) * z; m1 -= (Uu[6 + c] * sk) * z; }
-            if (fa >= 0) for (int c = 0; c < 6; ++c) { const double z = d.rhs[fa * 6 + c], sa = sf[fa * 6 + c]; m0 += (Uu[c] * sa) * z; m1 += (Uu[6 + c] * sa) * z; }
-            mc += m0 * (d.res[2 * r] + m0 / 2.0) + m1 * (d.res[2 * r + 1] + m1 / 2.0);
-        }
+        if (r < r1) { rowv v; load_row(r, v); sweep2(v); }
     }
-    mc = row_sum(mc);
+    mc = grp_sum<GW>(mc);
     if (live && sub == 0) {
         for (int i = 0; i < E; ++i) d.step[l * E + i] = -y[i];
         part[l] = mc;
@@ -2090,12 +2124,12 @@ __global__ __launch_bounds__(256) void bs_pent_sorted_kernel(const u64 *__restri
 // (+ F'Fa for the cells that observe an anchored landmark), written at the cell's pose-major position so that the
 // gathers of (2) read contiguous memory.  F'F and F'b are not formed here: they only change with the jacobian
 // (ba_pose_normal_kernel).
-template <int E>
+template <int E, int GW>
 __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
 {
     BA_WAVE_PRIO();
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    const int l = blockIdx.x * 16 + grp;
+    const int grp = threadIdx.x / GW, sub = threadIdx.x % GW;
+    const int l = blockIdx.x * (256 / GW) + grp;
     const bool live = l < d.n_e && d.W[d.win_of_e[l]].active;
     const int r0 = live ? d.row_ptr[l] : 0, r1 = live ? d.row_ptr[l + 1] : 0;
     // the cell list of the landmark is fetched WITH its rows, and the first cell of every lane is walked before the
@@ -2136,7 +2170,13 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     const bool own0 = sub < nobs;
     int rank0 = 0;
     if (own0) { rank0 = C.cell_rank[c0 + sub]; cell_W(sub, W0); }
-    for (int base = r0; base < r1; base += 16) {
+    // one sweep over the rows for E'E, E'b AND the anchor cell's W (every row of an anchored landmark carries the anchor
+    // block -U): the rows were read a second time for it before
+    const int fa_cell = has_anchor ? C.cell_f[c0 + nc - 1] : 0;
+    double Wa[6 * E], sa[6];
+    for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
+    for (int i = 0; i < 6; ++i) sa[i] = has_anchor ? sf[fa_cell * 6 + i] : 0.0;
+    for (int base = r0; base < r1; base += GW) {
         const int r = base + sub;
         if (r < r1) {
             double Je[2 * E];
@@ -2147,10 +2187,17 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
                 for (int j = 0; j < E; ++j) ete[i * E + j] += Je[i] * Je[j] + Je[E + i] * Je[E + j];
                 g[i] += Je[i] * b0 + Je[E + i] * b1;
             }
+            if (has_anchor && d.fa[r] >= 0) {
+                double Ja[12];
+                load_U(d, (size_t)r, wp, Ja);
+                for (int i = 0; i < 6; ++i) { Ja[i] = -(Ja[i] * sa[i]); Ja[6 + i] = -(Ja[6 + i] * sa[i]); }
+                for (int i = 0; i < 6; ++i)
+                    for (int k = 0; k < E; ++k) Wa[i * E + k] += Ja[i] * Je[k] + Ja[6 + i] * Je[E + k];
+            }
         }
     }
-    for (int i = 0; i < E * E; ++i) ete[i] = row_sum(ete[i]);
-    for (int i = 0; i < E; ++i) g[i] = row_sum(g[i]);
+    for (int i = 0; i < E * E; ++i) ete[i] = grp_sum<GW>(ete[i]);
+    for (int i = 0; i < E; ++i) g[i] = grp_sum<GW>(g[i]);
     if (live) for (int i = 0; i < E; ++i) { const double dv = d.lmd[l * E + i]; ete[i * E + i] += dv * dv; }
     else for (int i = 0; i < E; ++i) ete[i * E + i] = 1.0;
     double ie[E * E], ieg[E];
@@ -2205,29 +2252,13 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     // observing cells: ONE LANE PER CELL.  (F'Fa, the coupling of an observing pose with the landmark's anchor pose, is not
     // materialised: the gather forms it from the same rows.)
     if (own0) store_cell(rank0, W0);
-    for (int c = sub + 16; c < nobs; c += 16) {   // landmarks with more than 16 observing cells
+    for (int c = sub + GW; c < nobs; c += GW) {   // landmarks with more observing cells than the group has lanes
         double Wk[6 * E];
         cell_W(c, Wk);
         store_cell(C.cell_rank[c0 + c], Wk);
     }
     if (has_anchor) {   // W of the anchor cell: summed over all rows by the group (anchor block of a row = -U)
-        const int fa = C.cell_f[c0 + nc - 1];
-        double Wa[6 * E], sa[6];
-        for (int i = 0; i < 6 * E; ++i) Wa[i] = 0.0;
-        for (int i = 0; i < 6; ++i) sa[i] = sf[fa * 6 + i];
-        for (int base = r0; base < r1; base += 16) {
-            const int r = base + sub;
-            if (r < r1 && d.fa[r] >= 0) {
-                double Ja[12], Je[2 * E];
-                load_U(d, (size_t)r, wp, Ja);
-                load_d2<2 * E>(d.Je + (size_t)r * 2 * E, Je);
-                for (int i = 0; i < 6; ++i) { Ja[i] = -(Ja[i] * sa[i]); Ja[6 + i] = -(Ja[6 + i] * sa[i]); }
-                for (int k = 0; k < E; ++k) { Je[k] *= se[k]; Je[E + k] *= se[k]; }
-                for (int i = 0; i < 6; ++i)
-                    for (int k = 0; k < E; ++k) Wa[i * E + k] += Ja[i] * Je[k] + Ja[6 + i] * Je[E + k];
-            }
-        }
-        for (int i = 0; i < 6 * E; ++i) Wa[i] = row_sum(Wa[i]);
+        for (int i = 0; i < 6 * E; ++i) Wa[i] = grp_sum<GW>(Wa[i]);
         if (sub == 0) store_cell(C.cell_rank[c0 + nc - 1], Wa);
     }
 }
@@ -2905,7 +2936,7 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
     // copies whole windows (after a first solve the buffers still hold its last, possibly rejected, candidate)
     if (S.n_pose) OV2_HIP(c, hipMemcpyAsync(S.cp, S.xp, 7 * (size_t)S.n_pose * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (S.n_lm) OV2_HIP(c, hipMemcpyAsync(S.cl, S.xl, (size_t)e * S.n_lm * sizeof(double), hipMemcpyDeviceToDevice, st));
-    const dim3 g_rows(S.vblocks), g_lm((d.n_e + 15) / 16), g_win(B);
+    const dim3 g_rows(S.vblocks), g_lm((d.n_e + BS_LM_PER_WG - 1) / BS_LM_PER_WG), g_win(B);
     auto eval = [&](bool jac, const double *xp, const double *xl, int mode) {
         double *pc = d.part + 3 * (size_t)(d.n_e + d.n_f);
         if (jac) {
@@ -2917,7 +2948,7 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
         }
     };
     auto colnorm = [&](int mode) {
-        BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel, g_lm, dim3(256), 0, st, d, mode);
+        BA_LAUNCH(S, K_COLNORM, ba_colnorm16_kernel<BS_LM_GW>, g_lm, dim3(256), 0, st, d, mode);
         if (d.n_f > 0) BA_LAUNCH(S, K_COLNORM, ba_pose_normal_kernel, dim3(d.n_f), dim3(256), 0, st, d, S.pose_ptr, S.pose_ent, mode);
     };
     const int nb = d.n_e + d.n_f;
@@ -2943,12 +2974,12 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
         {
             const long long gblocks = (long long)d.n_f + (((S.pair_cap + 3) / 4 + 7) / 8) * 8;   // pair blocks: a multiple of 8 (XCD renumbering)
             if (e == 1) {
-                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<1>, g_lm, dim3(256), 0, st, d, S.cells);
+                BA_LAUNCH(S, K_SCHUR, (bs_landmark_kernel<1, BS_LM_GW>), g_lm, dim3(256), 0, st, d, S.cells);
                 if (gblocks > 0)
                     BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<1>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr,
                               S.n_pairs, S.pair_key, S.seg_start, S.pair_ent, S.fb, dbg_gather);
             } else {
-                BA_LAUNCH(S, K_SCHUR, bs_landmark_kernel<3>, g_lm, dim3(256), 0, st, d, S.cells);
+                BA_LAUNCH(S, K_SCHUR, (bs_landmark_kernel<3, BS_LM_GW>), g_lm, dim3(256), 0, st, d, S.cells);
                 if (gblocks > 0)
                     BA_LAUNCH(S, K_SCHUR, bs_gather_kernel<3>, dim3((unsigned)gblocks), dim3(256), 0, st, d, S.cells, S.pcell_ptr,
                               S.n_pairs, S.pair_key, S.seg_start, S.pair_ent, S.fb, dbg_gather);
@@ -2985,9 +3016,9 @@ ov2_status enqueue_minimize(ba_solver &S, int max_rounds)
             }
         }
         {
-            const int bgrid = std::max((d.n_e + 15) / 16, (d.m + 255) / 256);
-            if (e == 1) BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<1>, dim3(bgrid), dim3(256), 0, st, d, part_model);
-            else BA_LAUNCH(S, K_BACKSUB, ba_backsub16_kernel<3>, dim3(bgrid), dim3(256), 0, st, d, part_model);
+            const int bgrid = std::max((d.n_e + BS_LM_PER_WG - 1) / BS_LM_PER_WG, (d.m + 255) / 256);
+            if (e == 1) BA_LAUNCH(S, K_BACKSUB, (ba_backsub16_kernel<1, BS_LM_GW>), dim3(bgrid), dim3(256), 0, st, d, part_model);
+            else BA_LAUNCH(S, K_BACKSUB, (ba_backsub16_kernel<3, BS_LM_GW>), dim3(bgrid), dim3(256), 0, st, d, part_model);
         }
         BA_LAUNCH(S, K_REDUCE, ba_winreduce_kernel<WR_MODEL>, g_win, dim3(256), 0, st, d, lo, S.xp, part_cost, part_step, part_norm,
                   part_model, 0, 0.0, 0);
