@@ -49,6 +49,7 @@ namespace {
 enum { K_EVAL = OV2_K_BA_FIRST, K_COLNORM, K_SCALE, K_LMDIAG, K_SINIT, K_SCHUR, K_CHOL, K_BACKSUB, K_PLUS, K_FLAG,
        K_REDUCE, K_MISC };
 
+#define WPT_S 4
 struct ba_wconst { double Kl[4], Kr[4], Rrl[9], trl[3]; };   // per window: calibrations + right<-left extrinsic
 
 // Device-side record of one window: its ranges in the batch-wide arrays and the state of Ceres' TrustRegionMinimizer
@@ -98,7 +99,8 @@ struct ba_dev {
     // per row: residual, landmark block and the 2 x 3 block G of the robustified, UNSCALED jacobian; the 2 x 6 pose block of
     // a row is U = [-G | G x p] (p = the landmark's world point, kept once per landmark block in wpt): 48 bytes per row
     // instead of 96.  The anchor-pose block of an anchored inverse-depth row is -U, zero for every other type.
-    double *res, *Je, *G, *wpt;
+    double *res, *Je, *G, *wpt;    // wpt: WPT_S doubles per landmark block (x, y, z, 0): two 16-byte loads / stores
+    const int *ent_lm;             // per pose -> rows entry: landmark block of its row (what ba_pose_normal needs beside the row)
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
     double *rhs, *iete, *ieg;
@@ -439,7 +441,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             for (int cc = 0; cc < 3; ++cc) G2[cc] = make_double2(ev.G[2 * cc], ev.G[2 * cc + 1]);
             if (d.type[row] != OV2_BA_RANCH_INV) {   // every such row of a landmark holds the same point (same anchor, same depth)
                 const int eb = d.eb[row];
-                for (int k = 0; k < 3; ++k) d.wpt[(size_t)eb * 3 + k] = ev.wp[k];
+                double2 *W2 = reinterpret_cast<double2 *>(d.wpt + (size_t)eb * WPT_S);
+                W2[0] = make_double2(ev.wp[0], ev.wp[1]); W2[1] = make_double2(ev.wp[2], 0.0);
             }
         }
     }
@@ -763,6 +766,14 @@ __device__ __forceinline__ void load_d2(const double *__restrict__ p, double *ou
     for (int i = 0; i < N / 2; ++i) { const double2 v = q[i]; out[2 * i] = v.x; out[2 * i + 1] = v.y; }
 }
 
+// world point of landmark block e (two 16-byte loads)
+__device__ __forceinline__ void load_wpt(const ba_dev &d, size_t e, double *p)
+{
+    const double2 *q = reinterpret_cast<const double2 *>(d.wpt + e * WPT_S);
+    const double2 a = q[0], b = q[1];
+    p[0] = a.x; p[1] = a.y; p[2] = b.x;
+}
+
 // the 2 x 6 pose block of row r: U = [-G | G x p], p = world point of the row's landmark block
 __device__ __forceinline__ void load_U(const ba_dev &d, size_t r, const double *__restrict__ p, double *U)
 {
@@ -870,8 +881,9 @@ __global__ __launch_bounds__(256) void ba_pose_normal_kernel(ba_dev d, const int
     for (int c = 0; c < 6; ++c) sf[c] = d.scale[d.n_e * d.e + f * 6 + c];
     for (int k = pose_ptr[f] + tid; k < pose_ptr[f + 1]; k += 256) {
         const int ent = pose_ent[k], r = ent >> 1;
-        double J[12], bb[2];
-        load_U(d, (size_t)r, d.wpt + (size_t)d.eb[r] * 3, J);
+        double J[12], bb[2], wpk[3];
+        load_wpt(d, (size_t)d.ent_lm[k], wpk);
+        load_U(d, (size_t)r, wpk, J);
         load_d2<2>(d.res + 2 * (size_t)r, bb);
         // the pose's block of this row, Jacobi-scaled; as the row's anchor pose (entry bit 0) the block is -U
 #pragma unroll
@@ -918,7 +930,8 @@ __global__ __launch_bounds__(256) void ba_backsub16_kernel(ba_dev d, double *__r
     const double *__restrict__ sf = d.scale + (size_t)d.n_e * E;   // Jacobi scales of the pose columns
     double acc[E], se[E], wp[3];
     for (int i = 0; i < E; ++i) { acc[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
-    for (int i = 0; i < 3; ++i) wp[i] = live ? d.wpt[(size_t)l * 3 + i] : 0.0;
+    wp[0] = wp[1] = wp[2] = 0.0;
+    if (live) load_wpt(d, (size_t)l, wp);
     // One row of the landmark: its jacobian entries scaled (je), residual (b) and p = F_row * step_poses, the part of J * step
     // that comes from the row's pose and anchor-pose blocks.  The kernel needs p twice (E' (r + F z) for the landmark step,
     // then J * step for the model cost): the first two trips of a group keep (je, b, p) in registers, so the second sweep
@@ -1907,7 +1920,8 @@ __global__ __launch_bounds__(256) void bb_posekeys_kernel(const int *__restrict_
 }
 
 __global__ __launch_bounds__(256) void bb_poseptr_kernel(const u64 *__restrict__ pks, int n2, u64 *__restrict__ hdr,
-                                                         int *__restrict__ pose_ptr, int *__restrict__ pose_ent, int fb)
+                                                         int *__restrict__ pose_ptr, int *__restrict__ pose_ent, int fb,
+                                                         const int *__restrict__ eb, int *__restrict__ ent_lm)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n2) return;
@@ -1916,7 +1930,9 @@ __global__ __launch_bounds__(256) void bb_poseptr_kernel(const u64 *__restrict__
         if (j == 0) { hdr[BH_ENT] = 0; pose_ptr[(int)hdr[BH_NF]] = 0; }
         return;
     }
-    pose_ent[j] = (int)(pks[j] & 0xffffffffull);
+    const int ent = (int)(pks[j] & 0xffffffffull);
+    pose_ent[j] = ent;
+    ent_lm[j] = eb[ent >> 1];
     if (j == 0 || (pks[j - 1] >> 32) != k) pose_ptr[(int)k] = j;   // every pose block of the reduced program has an entry
     if (j + 1 == n2 || (pks[j + 1] >> 32) == dead) { hdr[BH_ENT] = (u64)(j + 1); pose_ptr[(int)hdr[BH_NF]] = j + 1; }
 }
@@ -2174,7 +2190,8 @@ __global__ __launch_bounds__(256) void bs_landmark_kernel(ba_dev d, ba_cells C)
     double ete[E * E], g[E], se[E], wp[3];
     for (int i = 0; i < E * E; ++i) ete[i] = 0.0;
     for (int i = 0; i < E; ++i) { g[i] = 0.0; se[i] = live ? d.scale[(size_t)l * E + i] : 1.0; }
-    for (int i = 0; i < 3; ++i) wp[i] = live ? d.wpt[(size_t)l * 3 + i] : 0.0;
+    wp[0] = wp[1] = wp[2] = 0.0;
+    if (live) load_wpt(d, (size_t)l, wp);
     const bool has_anchor = nc > 0 && C.cell_row[c0 + nc - 1] < 0;
     const int nobs = has_anchor ? nc - 1 : nc;
     // W = F'E of one cell: the lane walks the (one or two) rows of the cell's run once
@@ -2406,7 +2423,8 @@ __device__ __forceinline__ void bs_pair_block(const ba_dev &d, const ba_cells &C
             // materialised per cell: the 288-byte F'Fa records were the largest store of the whole Schur complement).
             if (!(dbg & 4) && (eh < 0 || el < 0)) {
                 const int4 rr = C.qrow[el < 0 ? qh : ql];
-                const double *wp = d.wpt + (size_t)rr.z * 3;   // the rows of a cell belong to one landmark
+                double wp[3];   // the rows of a cell belong to one landmark
+                load_wpt(d, (size_t)rr.z, wp);
                 for (int k = 0; k < rr.y; ++k) {
                     double Uu[12], H[12], L[12];
                     load_U(d, (size_t)(rr.x + k), wp, Uu);
@@ -2735,7 +2753,7 @@ ov2_status build_program(ba_solver &S)
     const int n = S.n_res, L = S.n_lm, NP = S.n_pose;
     S.arena_off = S.persist_end;
     ov2_status s;
-    int *used_lm, *used_pose, *escan, *fscan, *eidx, *fidx, *lm_of_e, *pose_of_f, *rows, *row_ptr, *pose_ptr, *pose_ent;
+    int *used_lm, *used_pose, *escan, *fscan, *eidx, *fidx, *lm_of_e, *pose_of_f, *rows, *row_ptr, *pose_ptr, *pose_ent, *ent_lm;
     int *win_of_e, *win_of_f, *vb_start;
     u64 *hdr, *keys, *keys2, *pk, *pk2;
     ba_prog_out O;
@@ -2745,7 +2763,7 @@ ov2_status build_program(ba_solver &S)
     AL(keys, n); AL(keys2, n); AL(pk, 2 * (size_t)n); AL(pk2, 2 * (size_t)n);
     AL(O.type, n); AL(O.pose, n); AL(O.lm, n); AL(O.anch, n); AL(O.eb, n); AL(O.fk, n); AL(O.fa, n);
     AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.rows, n); AL(O.row_win, n);
-    AL(row_ptr, L + 1); AL(pose_ptr, NP + 1); AL(pose_ent, 2 * (size_t)n);
+    AL(row_ptr, L + 1); AL(pose_ptr, NP + 1); AL(pose_ent, 2 * (size_t)n); AL(ent_lm, 2 * (size_t)n);
     rows = O.rows;
     // row keys: [landmark block : bits(L)] [pose block + 1 : fb] [residual index : nbits], one dead bit above
     const int nbits = bits_for((size_t)n), fb = bits_for((size_t)NP + 1);
@@ -2785,7 +2803,7 @@ ov2_status build_program(ba_solver &S)
         BA_LAUNCH(S, K_MISC, bb_rowptr_kernel, gn, dim3(256), 0, st, O.eb, hdr, row_ptr);
         BA_LAUNCH(S, K_MISC, bb_posekeys_kernel, gn, dim3(256), 0, st, O.fk, O.fa, hdr, n, pk, fb);
         OV2_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, pk, pk2, 2 * n, 32, 32 + fb + 1, st));
-        BA_LAUNCH(S, K_MISC, bb_poseptr_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, pk2, 2 * n, hdr, pose_ptr, pose_ent, fb);
+        BA_LAUNCH(S, K_MISC, bb_poseptr_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, st, pk2, 2 * n, hdr, pose_ptr, pose_ent, fb, O.eb, ent_lm);
         BA_LAUNCH(S, K_MISC, bb_winfill_kernel, dim3((std::max(L, NP) + 255) / 256), dim3(256), 0, st, R, hdr, lm_of_e, pose_of_f,
                   win_of_e, win_of_f);
     }
@@ -2819,11 +2837,12 @@ ov2_status build_program(ba_solver &S)
     d.uv = O.uv; d.inv_sigma = O.isg; d.lm_auv = R.lm_auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
     d.row_win = O.row_win; d.win_of_e = win_of_e; d.win_of_f = win_of_f; d.vb_start = vb_start;
     S.rows = rows; S.pose_ptr = pose_ptr; S.pose_ent = pose_ent;
+    d.ent_lm = ent_lm;
     const int nr = d.n_rows;
 #undef AL
 #define AL(field, count) if ((s = dalloc(c, S.arena_off, &d.field, (size_t)(count))) != OV2_OK) return s
-    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(G, 6 * (size_t)nr); AL(wpt, 3 * (size_t)d.n_e + 3);
-    OV2_HIP(c, hipMemsetAsync(d.wpt, 0, (3 * (size_t)d.n_e + 3) * sizeof(double), st));
+    AL(res, 2 * (size_t)nr); AL(Je, 2 * (size_t)e * nr); AL(G, 6 * (size_t)nr); AL(wpt, WPT_S * (size_t)d.n_e + WPT_S);
+    OV2_HIP(c, hipMemsetAsync(d.wpt, 0, (WPT_S * (size_t)d.n_e + WPT_S) * sizeof(double), st));
     AL(scale, d.nc); AL(sqn, d.nc); AL(grad, d.nc); AL(diag, d.nc); AL(lmd, d.nc); AL(step, d.nc);
     AL(Spool, s_tot); AL(rhs, d.m + 1); AL(iete, (size_t)d.n_e * e * e); AL(ieg, (size_t)d.n_e * e); AL(FFp, (size_t)d.n_f * 21);
     AL(part, 3 * ((size_t)d.n_e + d.n_f) + (size_t)S.vblocks + 16);
@@ -3200,7 +3219,7 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
         const size_t n = (size_t)tn, L = (size_t)tl, NP = (size_t)tp;
         // per residual block: raw copy 33 B + flags 3 + chi2 8 + sort keys / values 80 + program records 85 + radix-sort
         // scratch (~ keys + values) + jacobian rows 256 -> 600 with slack
-        const size_t need = n * 600 + L * 720 + NP * 1280 + s_bound * 8 + chold_bound * 8 + (size_t)B * (sizeof(ba_win) + 1024) + (4u << 20);
+        const size_t need = n * 616 + L * 720 + NP * 1280 + s_bound * 8 + chold_bound * 8 + (size_t)B * (sizeof(ba_win) + 1024) + (4u << 20);
         if (need > c->ba_arena_cap) {
             OV2_HIP(c, hipStreamSynchronize(c->stream));
             if (c->ba_arena) OV2_HIP(c, hipFree(c->ba_arena));
