@@ -100,6 +100,7 @@ struct ba_dev {
     // a row is U = [-G | G x p] (p = the landmark's world point, kept once per landmark block in wpt): 48 bytes per row
     // instead of 96.  The anchor-pose block of an anchored inverse-depth row is -U, zero for every other type.
     double *res, *Je, *G, *wpt;    // wpt: WPT_S doubles per landmark block (x, y, z, 0): two 16-byte loads / stores
+    const int4 *rowrec;            // per sorted row: (landmark, anchor pose, pose, landmark block | type << 28): what the evaluation reads, in one load
     const int *ent_lm;             // per pose -> rows entry: landmark block of its row (what ba_pose_normal needs beside the row)
     // vectors over columns (E part first: n_e*e, then F part: n_f*6)
     double *scale, *sqn, *grad, *diag, *lmd, *step;
@@ -200,6 +201,7 @@ __device__ inline void se3_plus(const double *x, const double *d, double *out)
 struct row_eval {
     double r[2], G[6], wp[3], Jl[6], chi2;   // pose block = [-G | G x wp]; the anchor-pose block of an anchored row is its negative
     bool depth_pos;
+    int type, eb;   // from the row record
 };
 
 // R | t of a pose: from the workgroup's LDS table of its window's poses (EV_RT_STRIDE doubles per pose, filled by
@@ -220,7 +222,9 @@ template <bool JAC>
 __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const double *__restrict__ poses,
                                 const double *__restrict__ lms, int row, row_eval &o, const double *sRt = nullptr, int p0 = 0)
 {
-    const int type = d.type[row], l = d.lm[row];
+    const int4 rec = d.rowrec[row];
+    const int type = (int)((unsigned)rec.w >> 28), l = rec.x;
+    o.type = type; o.eb = rec.w & 0x0fffffff;
     const double inv_sigma = d.inv_sigma[row];
     const bool is_right = (type == OV2_BA_R_XYZ || type == OV2_BA_R_INV || type == OV2_BA_RANCH_INV);
     const bool inv = (type >= OV2_BA_L_INV);
@@ -233,7 +237,7 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
         anchpt[2] = zanch;
         if (type != OV2_BA_RANCH_INV) {
             double twa[3];
-            fetch_Rt(poses, sRt, p0, d.anch[row], Rwa, twa);
+            fetch_Rt(poses, sRt, p0, rec.y, Rwa, twa);
             for (int r = 0; r < 3; ++r)
                 wpt[r] = (Rwa[3 * r] * anchpt[0] + Rwa[3 * r + 1] * anchpt[1] + Rwa[3 * r + 2] * anchpt[2]) + twa[r];
         }
@@ -247,7 +251,7 @@ __device__ inline void eval_row(const ba_dev &d, const ba_wconst &wc, const doub
         for (int i = 0; i < 9; ++i) M[i] = wc.Rrl[i];
     } else {
         double Rwc[9], twc[3], lcam[3];
-        fetch_Rt(poses, sRt, p0, d.pose[row], Rwc, twc);
+        fetch_Rt(poses, sRt, p0, rec.z, Rwc, twc);
         const double dd[3] = {wpt[0] - twc[0], wpt[1] - twc[1], wpt[2] - twc[2]};
         for (int r = 0; r < 3; ++r) lcam[r] = Rwc[r] * dd[0] + Rwc[3 + r] * dd[1] + Rwc[6 + r] * dd[2];
         if (is_right) {
@@ -439,8 +443,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             double2 *G2 = reinterpret_cast<double2 *>(d.G + (size_t)row * 6);   // 48-byte rows: three 16-byte stores
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) G2[cc] = make_double2(ev.G[2 * cc], ev.G[2 * cc + 1]);
-            if (d.type[row] != OV2_BA_RANCH_INV) {   // every such row of a landmark holds the same point (same anchor, same depth)
-                const int eb = d.eb[row];
+            if (ev.type != OV2_BA_RANCH_INV) {   // every such row of a landmark holds the same point (same anchor, same depth)
+                const int eb = ev.eb;
                 double2 *W2 = reinterpret_cast<double2 *>(d.wpt + (size_t)eb * WPT_S);
                 W2[0] = make_double2(ev.wp[0], ev.wp[1]); W2[1] = make_double2(ev.wp[2], 0.0);
             }
@@ -1868,6 +1872,7 @@ __global__ __launch_bounds__(64) void bb_rows_kernel(u64 *__restrict__ hdr)
 
 struct ba_prog_out {   // the writable twins of the const program arrays in ba_dev
     unsigned char *type; int *pose, *lm, *anch, *eb, *fk, *fa; double *uv, *isg; int *rows, *row_win;
+    int4 *rowrec;
 };
 
 __global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const u64 *__restrict__ keys,
@@ -1892,6 +1897,7 @@ __global__ __launch_bounds__(256) void bb_fill_kernel(ba_raw R, const u64 *__res
     O.fa[r] = (t == OV2_BA_L_INV || t == OV2_BA_R_INV) ? fidx[pa] : -1;
     O.uv[2 * r] = R.uv[2 * i]; O.uv[2 * r + 1] = R.uv[2 * i + 1];
     O.isg[r] = 1.0 / (R.sigma ? R.sigma[i] : 1.0);
+    O.rowrec[r] = make_int4(l, pa, pk < 0 ? R.pose_off[w] : pk, eidx[l] | (t << 28));   // (landmark blocks < 2^28: checked with the sort keys)
 }
 
 __global__ __launch_bounds__(256) void bb_rowptr_kernel(const int *__restrict__ eb, const u64 *__restrict__ hdr,
@@ -2762,13 +2768,15 @@ ov2_status build_program(ba_solver &S)
     AL(lm_of_e, L); AL(pose_of_f, NP); AL(win_of_e, L); AL(win_of_f, NP); AL(vb_start, B + 1);
     AL(keys, n); AL(keys2, n); AL(pk, 2 * (size_t)n); AL(pk2, 2 * (size_t)n);
     AL(O.type, n); AL(O.pose, n); AL(O.lm, n); AL(O.anch, n); AL(O.eb, n); AL(O.fk, n); AL(O.fa, n);
-    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.rows, n); AL(O.row_win, n);
+    AL(O.uv, 2 * (size_t)n); AL(O.isg, n); AL(O.rows, n); AL(O.row_win, n); AL(O.rowrec, n);
     AL(row_ptr, L + 1); AL(pose_ptr, NP + 1); AL(pose_ent, 2 * (size_t)n); AL(ent_lm, 2 * (size_t)n);
     rows = O.rows;
     // row keys: [landmark block : bits(L)] [pose block + 1 : fb] [residual index : nbits], one dead bit above
     const int nbits = bits_for((size_t)n), fb = bits_for((size_t)NP + 1);
     const int dead_bit = bits_for((size_t)L) + fb + nbits;
     S.fb = fb;
+    if ((long long)L >= (1ll << 28))
+        return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large for the packed row records (%d landmarks): split it", L);
     if (dead_bit > 62)
         return ov2_set_err(c, OV2_ERR_UNSUPPORTED, "batch too large for the packed sort keys (%d residual blocks, %d landmarks, %d "
                            "poses): split it", n, L, NP);
@@ -2834,6 +2842,7 @@ ov2_status build_program(ba_solver &S)
         if (cov > S.cover_max) S.cover_max = (int)std::min<long long>(cov, 0x7fffffff);
     }
     d.type = O.type; d.pose = O.pose; d.lm = O.lm; d.anch = O.anch; d.eb = O.eb; d.fk = O.fk; d.fa = O.fa;
+    d.rowrec = O.rowrec;
     d.uv = O.uv; d.inv_sigma = O.isg; d.lm_auv = R.lm_auv; d.row_ptr = row_ptr; d.lm_of_e = lm_of_e; d.pose_of_f = pose_of_f;
     d.row_win = O.row_win; d.win_of_e = win_of_e; d.win_of_f = win_of_f; d.vb_start = vb_start;
     S.rows = rows; S.pose_ptr = pose_ptr; S.pose_ent = pose_ent;
@@ -3219,7 +3228,7 @@ static ov2_status ba_solve_batch_impl(ov2_ctx *c, int B, const ov2_ba_problem *P
         const size_t n = (size_t)tn, L = (size_t)tl, NP = (size_t)tp;
         // per residual block: raw copy 33 B + flags 3 + chi2 8 + sort keys / values 80 + program records 85 + radix-sort
         // scratch (~ keys + values) + jacobian rows 256 -> 600 with slack
-        const size_t need = n * 616 + L * 720 + NP * 1280 + s_bound * 8 + chold_bound * 8 + (size_t)B * (sizeof(ba_win) + 1024) + (4u << 20);
+        const size_t need = n * 632 + L * 720 + NP * 1280 + s_bound * 8 + chold_bound * 8 + (size_t)B * (sizeof(ba_win) + 1024) + (4u << 20);
         if (need > c->ba_arena_cap) {
             OV2_HIP(c, hipStreamSynchronize(c->stream));
             if (c->ba_arena) OV2_HIP(c, hipFree(c->ba_arena));
