@@ -1257,6 +1257,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void ba_chol_mfma_kernel(ba_dev d)
             // trip; issued step by step every matrix instruction waited for its own loads -- 53 us per panel at m = 354).
             // Measured and not kept: double-buffered trips (48 operands + 48 addresses live: 256 VGPRs, 636 B of scratch);
             // two tiles per wave and trip sharing the column operands (32 loads instead of 2 x 24: update phase 694 -> 765 us)
+            // ; the panel's 32 x j0 column block staged through LDS once per 32 columns for all waves, a wave keeping the accumulators
+            // of its three tiles (one round trip feeds 48 matrix instructions): 693 -> 942 us -- the two barriers per step make every
+            // step as slow as the slowest wave's loads, where independent waves overlap each other's latencies
             for (int k = 0; k < j0; k += 4 * CHOL_TRIP) {
                 double b[CHOL_TRIP], a0[CHOL_TRIP], a1[CHOL_TRIP];
 #pragma unroll
